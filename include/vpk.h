@@ -1,0 +1,162 @@
+/*
+ * vpk.h -- C-ABI of the MI355X-native vanishing-point hot path (libvpk.so).
+ *
+ * Drop-in boundary for the hot path of fkluger/vanishing_points_2017.  The reference is pure
+ * Python and has no FFI of its own; its boundary for this path is the call surface of
+ * evaluation.py (run_cnn :254, caffe_forward :34, run_em :295, run_em_single :332) plus
+ * vp_localisation.expectation_maximisation (:168-172).  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success or a negative vpk_status code; vpk_last_error()
+ *     returns a human-readable message for the last failure on that handle.
+ *   - unless a parameter is marked [host], buffers are DEVICE pointers (HBM-resident, e.g. a
+ *     torch tensor's data_ptr()); all work is enqueued on the handle's HIP stream
+ *     (vpk_set_stream) and is asynchronous with respect to the host unless stated.
+ *   - one handle per process/GPU; a handle is thread-compatible (not thread-safe).
+ *   - there is NO CPU fallback: on a machine without a gfx950 device vpk_create fails.
+ */
+#ifndef VPK_H_
+#define VPK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPK_VERSION 100
+
+typedef struct vpk_handle vpk_handle;
+
+enum vpk_status {
+    VPK_OK = 0,
+    VPK_ERR_ARG = -1,       /* bad argument (null pointer, size out of range)   */
+    VPK_ERR_HIP = -2,       /* a HIP runtime call failed                        */
+    VPK_ERR_NO_DEVICE = -3, /* no usable gfx950 device                          */
+    VPK_ERR_STATE = -4,     /* call order (e.g. cnn_forward before cnn_load)    */
+    VPK_ERR_LIMIT = -5      /* problem exceeds a compiled-in limit (max VPs...) */
+};
+
+/* per-image EM result status (status_out of vpk_em_batch) */
+enum vpk_em_status {
+    VPK_EM_OK = 0,            /* VPs returned                                                   */
+    VPK_EM_NO_VP = 1,         /* reference returns the all-None result (vp_localisation.py:258-260,
+                                 :402-404) -- also used where the reference would raise on an empty
+                                 argmax (M == 0 at :349)                                         */
+    VPK_EM_NO_INITIAL_VP = 2  /* reference raises ValueError from np.vstack([]) (:165)           */
+};
+/* bit flags OR-ed into flags_out: situations where third-party tie-breaking is implementation
+ * defined (Python heapq order inside sklearn's AgglomerativeClustering, vp_localisation.py:574) */
+#define VPK_EM_FLAG_SPLIT_TIE 1u         /* exact tie between cluster distances during a split   */
+#define VPK_EM_FLAG_SPLIT_DISCONNECTED 2u /* all-parallel line set: sklearn would complete graph */
+#define VPK_EM_FLAG_VP_OVERFLOW 4u       /* more VPs than max_vp: result truncated               */
+
+/* Mirrors the keyword defaults of expectation_maximisation (vp_localisation.py:168-172). */
+typedef struct vpk_em_params {
+    int32_t num_iter;          /* 100   */
+    int32_t do_merge;          /* 1     */
+    int32_t do_split;          /* 1     */
+    int32_t do_iterations;     /* 1     */
+    int32_t use_weights;       /* 1     */
+    int32_t num_init_vp;       /* 25    */
+    int32_t split_merge_freq;  /* 10    */
+    int32_t num_min_lines;     /* 3     */
+    double wbias;              /* 1.0   */
+    double merge_thresh;       /* 1e-3  */
+    double outlier_thresh;     /* 1.96^2 */
+    double final_convergence;  /* 5e-3  */
+    double s_thresh;           /* 1e-200 */
+} vpk_em_params;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces: caffe.set_mode_gpu(); caffe.set_device(gpu_id)  (evaluation.py:20-21) */
+int vpk_create(int device, vpk_handle** out);
+int vpk_destroy(vpk_handle* h);
+/* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int vpk_set_stream(vpk_handle* h, void* hip_stream);
+int vpk_synchronize(vpk_handle* h);
+const char* vpk_last_error(const vpk_handle* h);
+int vpk_version(void);
+void vpk_em_default_params(vpk_em_params* p);
+/* device properties as seen by the library: [0]=CU count, [1]=LDS bytes per block, [2]=gfx arch number */
+int vpk_device_info(const vpk_handle* h, int32_t info[4]);
+
+/* ---- CNN (AlexNet-500, cnn/deploy.prototxt:1-304) -------------------------------------------- */
+/* replaces: caffe.Net(model_def, model_weights, caffe.TEST) + read_mean_blob
+ * (evaluation.py:17-31).  blobs [host]: 16 host pointers to fp32 arrays in Caffe layout,
+ * order conv1.w, conv1.b, conv2.w, conv2.b, ..., conv5.b, fc6.w, fc6.b, fc7.w, fc7.b, fc8.w,
+ * fc8.b (OIHW / (out,in)); mean [host]: 500*500 fp32 (mean.binaryproto, 1x1x500x500).
+ * Copies to HBM (synchronous). */
+int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean);
+/* replaces: caffe_forward (evaluation.py:34-38) for a batch: sphere B x 500 x 500 uint8 ->
+ * out B x 20 x 20 fp32 (sigout).  max batch per call is unbounded (internally chunked). */
+int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out);
+/* debugging/parity: run the net and also return an intermediate blob by name index
+ * (0=conv1 relu, 1=pool1, 2=conv2, 3=pool2, 4=conv3, 5=conv4, 6=conv5, 7=pool5, 8=fc6, 9=fc7,
+ * 10=fc8 pre-sigmoid); tap_out must hold batch * blob_size fp32. */
+int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap,
+                        float* tap_out);
+
+/* ---- sphere rasteriser (sphere_mapping.py:36-72) ----------------------------------------------- */
+/* replaces: get_sphere_image / sphere_line_plot (evaluation.py:12-14).  l: sum(N) x 3 fp64
+ * homogeneous lines, offsets [host]: B+1 int64 prefix of line counts; out: B x size x size uint8,
+ * image row 0 = beta = +pi/2.  alpha = per-line blend weight (0.1 in the reference). */
+int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
+                      double alpha, uint8_t* out);
+
+/* ---- EM refinement (vp_localisation.py:168-450) ------------------------------------------------ */
+/* replaces: run_em / run_em_single -> expectation_maximisation (evaluation.py:295-354) for a
+ * batch of images.  One workgroup runs the whole EM of one image; images are independent.
+ *   offsets  [host] B+1 int64 prefix sums of per-image line counts N_b
+ *   l        sum(N) x 3 fp64, normalised IN PLACE (reference :185-186,:226)
+ *   lp       sum(N) x 4 fp64 segment end points (x1,y1,x2,y2)
+ *   cnn      B x 400 fp32 (20x20 sigout, row = beta bin)
+ *   sphere   B x size x size uint8
+ *   init_vp  NULL or B x n_init x 3 fp64 (reference keyword init_vp)
+ *   max_vp   row capacity of the per-image outputs below
+ * outputs (device): vp_out B x max_vp x 3, sigma_out / counts_out / counts_w_out B x max_vp,
+ *   num_vp_out B, assoc_out sum(N) int64 (-1 = outlier), iterations_out B, status_out B
+ *   (vpk_em_status), flags_out B (VPK_EM_FLAG_*), metric_out NULL or sum(N) x max_vp fp64
+ *   (decision_metric, [line][vp]), trace_out NULL or B x num_iter x 4 fp64
+ *   (per iteration: M after the M-step, max_err, M after merge, event bits). */
+int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
+                 const float* cnn, const uint8_t* sphere, int sphere_size, const double* init_vp,
+                 int n_init, const vpk_em_params* p, int max_vp, double* vp_out, double* sigma_out,
+                 double* counts_out, double* counts_w_out, int32_t* num_vp_out, int64_t* assoc_out,
+                 int32_t* iterations_out, int32_t* status_out, uint32_t* flags_out,
+                 double* metric_out, double* trace_out);
+/* bytes of device workspace the next vpk_em_batch with these sizes will hold (informational) */
+size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const vpk_em_params* p,
+                              int n_init);
+
+/* ---- fine-grained entry points (single image; unit parity against the reference functions) ---- */
+/* calc_lsim (vp_localisation.py:87-108) + line_rating_knn (:34-84) in one pass over the pairs:
+ * lsim_out n x n (row stride n), lscore_out n (before the clip), langle_out n (lines_angles). */
+int vpk_pairwise(vpk_handle* h, int n, const double* lp, double* lsim_out, double* lscore_out,
+                 double* langle_out);
+/* find_initial_vps (:111-165) + pdf_params (probability_functions.py:62-96):
+ * v0_out num_max x 3, m0_out 1 int32, weights_out 400 fp32. */
+int vpk_init_vps(vpk_handle* h, const float* cnn, const uint8_t* sphere, int sphere_size,
+                 int num_max, double* v0_out, int32_t* m0_out, float* weights_out);
+/* calc_probabilities (probability_functions.py:99-120): v m x 3, s m (floored in place),
+ * outputs p_v m, lvsq [m][n], p_vl [m][n], p_l n. */
+int vpk_estep(vpk_handle* h, int n, int m, const double* lp, const float* cnn, const double* v,
+              double* s, double* p_v_out, double* lvsq_out, double* p_vl_out, double* p_l_out);
+/* weight_matrix (vp_localisation.py:515-524): p_vl [m][n], lsim n x n -> w_out [m][n]. */
+int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const double* lweight,
+                      const double* lsim, double bias, double* w_out);
+/* calc_new_vanishing_point (:453-479) for every row of w [m][n]: vp_out m x 3, valid_out m. */
+int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, double* vp_out,
+              int32_t* valid_out);
+/* the clustering inside split_best_vp (:568-578): ldist n x n -> labels n (0/1), flags 1. */
+int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out,
+                 uint32_t* flags_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPK_H_ */

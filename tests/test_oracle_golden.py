@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/em_numpy.py) against golden vectors captured from the reference.
+
+The goldens were produced by oracle/make_golden.py, which runs the reference's own
+vp_localisation / probability_functions / calc_horizon modules in the build container.
+Tolerances: intermediates <= 1e-12 (abs or rel), final vp_assoc bit-exact, VP <= 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_cases
+from oracle import em_numpy as em
+
+CASES = golden_cases()
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def _kwargs(g):
+    kw = {}
+    for k in g:
+        if k.startswith("kw_"):
+            v = g[k]
+            kw[k[3:]] = v.item() if v.ndim == 0 else v
+    if "init_vp" in g:
+        kw["init_vp"] = g["init_vp"]
+    return kw
+
+
+def _close(a, b, tol=1e-12):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    err = np.abs(a - b) / np.maximum(1e-30, np.maximum(np.abs(a), np.abs(b))) if tol >= 1e-9 else np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert np.nanmax(err) <= tol if err.size else True
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+
+
+@pytest.mark.parametrize("name", [c for c in CASES])
+def test_intermediates(name):
+    g = _load(name)
+    if "i_v0" not in g:
+        pytest.skip("no intermediates stored for this case")
+    lp = g["lp"]
+    l = g["l"].copy()
+    cnn = g["cnn_response"]
+    sphere = g["sphere_image"]
+    dist = em.pair_distance_closest(lp)
+    lsim = em.calc_lsim(lp, sigma=1, dist=dist)
+    if "i_lsim" in g:
+        _close(lsim, g["i_lsim"], 1e-13)
+    else:
+        _close(lsim[::17, :], g["i_lsim_rows"], 1e-13)
+    _close(lsim.sum(axis=1), g["i_lsim_rowsum"], 1e-12)
+    assert np.array_equal(lsim, lsim.T)
+    lscore = em.line_rating_knn(lp, k2=4, dist=dist)
+    _close(lscore, g["i_lscore"], 1e-13)
+    _close(em.lines_angles(lp), g["i_langles"], 1e-14)
+    v0 = em.find_initial_vps(sphere, cnn, 25)
+    _close(v0, g["i_v0"], 1e-14)
+    par = em.pdf_params(cnn)
+    assert par.weights.dtype == np.float32
+    assert np.array_equal(par.weights, g["i_pdf_weights"])
+    _close(par.means, g["i_pdf_means"], 1e-15)
+    l /= np.sqrt(np.sum(l * l, axis=1))[:, None]
+    lweight = em.line_lengths(lp) * np.clip(lscore, 0.2, 1)
+    _close(lweight, g["i_lweight"], 1e-13)
+    s = np.ones(v0.shape[0]) * par.sigma * 1e-6
+    p = em.calc_probabilities(par, v0, lp, s)
+    _close(p.v, g["i_p_v0"], 1e-12)
+    _close(p.lvsq, g["i_lvsq0"], 1e-12)
+    # exponent = lvsq / (2 s) with s ~ 1.2e-7: a 1-ulp (1e-16) difference in lvsq is amplified
+    # to ~1e-9 relative in p_lv, hence the looser relative tolerance downstream of the exp
+    _close(p.l, g["i_p_l0"], 1e-8)
+    _close(p.vl, g["i_p_vl0"], 1e-8)
+    w = em.Smoother(lsim, lweight, 1)(p.vl)
+    _close(w, g["i_w0"], 1e-8)
+    counts, _, assoc = em.calc_vp_line_counts(v0, lp, s, w, lweight, 1.96 ** 2)
+    assert np.array_equal(counts, g["i_counts0"])
+    assert np.array_equal(assoc, g["i_assoc0"])
+    for m in range(v0.shape[0]):
+        new = em.calc_new_vanishing_point(l, w[m, :])
+        _close(new, g["i_mstep0"][m], 1e-9)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c != "stress_n1000"])
+def test_full_run(name):
+    _full(name)
+
+
+@pytest.mark.slow
+def test_full_run_stress_n1000():
+    _full("stress_n1000")
+
+
+def _full(name):
+    g = _load(name)
+    l = g["l"].copy()
+    res = em.expectation_maximisation(l, g["lp"].copy(), g["cnn_response"].copy(),
+                                      sphere_image=g["sphere_image"], **_kwargs(g))
+    _close(l, g["l_normalised"], 1e-15)
+    if int(g["o_status"]) != 0:
+        assert res["vp"] is None
+        return
+    assert res["iterations"] == int(g["o_iterations"])
+    assert res["vp"].shape == g["o_vp"].shape
+    assert np.array_equal(res["vp_assoc"], g["o_vp_assoc"])          # bit-exact assignments
+    _close(res["vp"], g["o_vp"], 1e-9)
+    assert np.array_equal(res["counts"], g["o_counts"])
+    _close(res["counts_weighted"], g["o_counts_weighted"], 1e-12)
+    rel = np.abs(res["sigma"] - g["o_sigma"]) / g["o_sigma"]
+    assert rel.max() <= 1e-6
