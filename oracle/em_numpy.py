@@ -519,7 +519,7 @@ class _EM(object):
                 self.nxt = np.vstack([self.nxt, np.zeros((1, 3))])
                 self.s = np.append(self.s, stdd)
         if self.trace is not None:
-            self.trace.setdefault("splits", []).append((int(worst), labels.copy(), assoc_lines.copy()))
+            self.trace.setdefault("splits", []).append((int(worst), labels.copy(), assoc_lines.copy(), ldist.copy()))
 
 
 def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=None, init_vp=None,
@@ -553,9 +553,12 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
     for i in range(num_iter):
         if em.cur.shape[0] == 0:                                            # :258-260
             return result
+        events = 0
         if i % split_merge_freq == 0 and 0 < i < split_merge_it and do_split:   # :262-269
+            mb = em.cur.shape[0]
             p = em.estep(em.cur)
             em.split(em.smooth(p.vl), merge_thresh)
+            events += int(em.cur.shape[0] != mb)
         m_n = em.cur.shape[0]
         p = em.estep(em.cur)                                                # :273
         w = em.smooth(p.vl)                                                 # :282
@@ -582,6 +585,9 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
         else:
             em.nxt[:, :] = em.cur                                           # :324-325
         em.delete(removed)                                                  # :329-331
+        row = [em.cur.shape[0], float(max_err), 0, 0]
+        if trace is not None:
+            trace.setdefault("iters", []).append(row)
         # (:332 recomputes the E-step and discards it; its only side effect, flooring s at
         #  1e-200, is a no-op after the clamp at :307)
 
@@ -629,12 +635,16 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
                     counts, counts_w, vp_assoc = em.counts(em.nxt, metric)
                 else:
                     vidx += 1
+            row[2], row[3] = em.cur.shape[0], events + 2
             return {"vp_assoc": vp_assoc, "vp": em.nxt, "counts": counts, "counts_weighted": counts_w,
                     "count_id": None, "decision_metric": metric, "iterations": i, "distribution": p,
                     "sigma": em.s}
 
         if i % split_merge_freq == 0 and 0 < i <= split_merge_it + split_merge_freq and do_merge:   # :444-448
+            mb = em.cur.shape[0]
             em.merge(True, merge_thresh)
+            events += 4 * int(em.cur.shape[0] != mb)
+        row[2], row[3] = em.cur.shape[0], events
         em.cur = em.nxt
         em.nxt = np.zeros_like(em.cur)
     return result

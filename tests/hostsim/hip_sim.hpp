@@ -1,0 +1,45 @@
+// hip_sim.hpp -- TEST-ONLY single-lane stand-in for csrc/wave_prims.hpp.
+//
+// The EM device code (csrc/em_device.hpp) is written against the small vocabulary of
+// wave_prims.hpp.  This header defines the same vocabulary for ONE thread per workgroup and a
+// wave width of 1, so the *unmodified* device source can be compiled with g++ and its control
+// flow / indexing checked against the oracle on a machine without a GPU (pytest -m "not gpu").
+// It is not a product path: nothing under vanishing_points_2017_amd/ builds, loads or links it,
+// and it says nothing about races or barriers -- those are covered by the -m gpu tests.
+#ifndef VPK_WAVE_PRIMS_HPP_
+#define VPK_WAVE_PRIMS_HPP_
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace vpk {
+
+constexpr int WAVE = 1;
+
+#define VPK_DEV static inline
+#define VPK_DEVFN static
+#define VPK_LDS static
+
+VPK_DEV int tid() { return 0; }
+VPK_DEV int nthreads() { return 1; }
+VPK_DEV int lane() { return 0; }
+VPK_DEV int wave_id() { return 0; }
+VPK_DEV int nwaves() { return 1; }
+VPK_DEV int block_id() { return 0; }
+VPK_DEV int nblocks() { return 1; }
+VPK_DEV void block_sync() {}
+VPK_DEV void wave_sync() {}
+VPK_DEV double wave_sum(double v) { return v; }
+VPK_DEV int wave_sum_int(int v) { return v; }
+VPK_DEV double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+VPK_DEV double wave_max(double v) { return v; }
+VPK_DEV int wave_max_int(int v) { return v; }
+VPK_DEV void wave_argmin(double&, int&) {}
+VPK_DEV double wave_bcast(double v, int) { return v; }
+VPK_DEV int wave_bcast_int(int v, int) { return v; }
+VPK_DEV int atomic_add_int(int* p, int v) { int o = *p; *p += v; return o; }
+VPK_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
+
+}  // namespace vpk
+#endif

@@ -1,0 +1,144 @@
+"""ctypes binding of libvpk.so (include/vpk.h).  There is no fallback: if the HIP library is
+missing or no MI355X is present, using the package raises."""
+import ctypes
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(PKG, "libvpk.so")
+
+c_void = ctypes.c_void_p
+
+
+class VpkError(RuntimeError):
+    pass
+
+
+class EmParams(ctypes.Structure):
+    """vpk_em_params: mirrors the keyword defaults of expectation_maximisation
+    (reference vp_localisation.py:168-172)."""
+    _fields_ = [("num_iter", ctypes.c_int32), ("do_merge", ctypes.c_int32), ("do_split", ctypes.c_int32),
+                ("do_iterations", ctypes.c_int32), ("use_weights", ctypes.c_int32),
+                ("num_init_vp", ctypes.c_int32), ("split_merge_freq", ctypes.c_int32),
+                ("num_min_lines", ctypes.c_int32), ("wbias", ctypes.c_double),
+                ("merge_thresh", ctypes.c_double), ("outlier_thresh", ctypes.c_double),
+                ("final_convergence", ctypes.c_double), ("s_thresh", ctypes.c_double)]
+
+
+EXPORTS = [
+    "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
+    "vpk_em_default_params", "vpk_device_info", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
+    "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
+    "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_cluster2",
+]
+
+_lib = None
+
+
+def load():
+    """Load libvpk.so; raises VpkError when it has not been built (python -m ...build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise VpkError("libvpk.so is missing (%s): build it with `python -m vanishing_points_2017_amd.build`"
+                       "; there is no CPU fallback" % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    lib.vpk_last_error.restype = ctypes.c_char_p
+    lib.vpk_last_error.argtypes = [c_void]
+    lib.vpk_em_workspace_bytes.restype = ctypes.c_size_t
+    lib.vpk_create.argtypes = [ctypes.c_int, ctypes.POINTER(c_void)]
+    lib.vpk_destroy.argtypes = [c_void]
+    lib.vpk_set_stream.argtypes = [c_void, c_void]
+    lib.vpk_synchronize.argtypes = [c_void]
+    lib.vpk_device_info.argtypes = [c_void, ctypes.POINTER(ctypes.c_int32)]
+    lib.vpk_em_default_params.argtypes = [ctypes.POINTER(EmParams)]
+    lib.vpk_em_batch.argtypes = [c_void, ctypes.c_int, c_void, c_void, c_void, c_void, c_void, ctypes.c_int,
+                                 c_void, ctypes.c_int, ctypes.POINTER(EmParams), ctypes.c_int] + [c_void] * 11
+    lib.vpk_em_workspace_bytes.argtypes = [c_void, ctypes.c_int, ctypes.c_int, ctypes.POINTER(EmParams),
+                                           ctypes.c_int]
+    lib.vpk_pairwise.argtypes = [c_void, ctypes.c_int, c_void, c_void, c_void, c_void]
+    lib.vpk_init_vps.argtypes = [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]
+    lib.vpk_estep.argtypes = [c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 8
+    lib.vpk_weight_matrix.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void,
+                                      ctypes.c_double, c_void]
+    lib.vpk_mstep.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]
+    lib.vpk_cluster2.argtypes = [c_void, ctypes.c_int, c_void, c_void, c_void]
+    lib.vpk_cnn_load.argtypes = [c_void, ctypes.POINTER(c_void), c_void]
+    lib.vpk_cnn_forward.argtypes = [c_void, c_void, ctypes.c_int, c_void]
+    lib.vpk_cnn_forward_tap.argtypes = [c_void, c_void, ctypes.c_int, c_void, ctypes.c_int, c_void]
+    lib.vpk_sphere_raster.argtypes = [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void]
+    _lib = lib
+    return lib
+
+
+def default_em_params(**overrides):
+    p = EmParams()
+    load().vpk_em_default_params(ctypes.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown EM parameter %r" % k)
+        cur = getattr(p, k)
+        setattr(p, k, int(v) if isinstance(cur, int) else float(v))
+    return p
+
+
+class Handle(object):
+    """One vpk_handle (one per process / GPU).  Work is enqueued on ``stream`` (a raw hipStream_t,
+    e.g. torch.cuda.current_stream().cuda_stream); None lets the library own a stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = c_void()
+        rc = self.lib.vpk_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise VpkError("vpk_create(device=%d) failed with %d: an MI355X (gfx950) is required, "
+                           "there is no CPU fallback" % (device, rc))
+        self.h = h
+        self.device = device
+        if stream:
+            self.check(self.lib.vpk_set_stream(self.h, c_void(stream)))
+
+    def check(self, rc):
+        if rc != 0:
+            raise VpkError("libvpk error %d: %s" % (rc, self.lib.vpk_last_error(self.h).decode()))
+
+    def synchronize(self):
+        self.check(self.lib.vpk_synchronize(self.h))
+
+    def device_info(self):
+        info = (ctypes.c_int32 * 4)()
+        self.check(self.lib.vpk_device_info(self.h, info))
+        return {"num_cu": info[0], "lds_per_block": info[1], "arch": info[2], "hbm_gib": info[3]}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vpk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_handles = {}
+
+
+def get_handle(device=0):
+    """Process-wide handle for ``device``.  The library owns a non-blocking HIP stream; callers
+    that mix torch work with library calls synchronise through Handle.synchronize() /
+    torch.cuda.synchronize() (see em.py)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise VpkError("no GPU visible: the vanishing-point hot path runs on MI355X only (no CPU fallback)")
+    key = int(device)
+    if key not in _handles:
+        _handles[key] = Handle(key)
+    return _handles[key]
+
+
+def host_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)

@@ -1,0 +1,1259 @@
+// em_device.hpp -- device-resident EM refinement of vanishing points, one workgroup per image.
+//
+// MI355X-first design: the whole EM of one image (setup, E-step, N x N smoothing, M-step,
+// split / merge / finalisation control flow) runs inside ONE persistent workgroup, so an
+// iteration costs barriers instead of kernel launches and the only HBM stream that matters is
+// the fp64 N x N line-similarity matrix read once per E-step (B_EM).  Hundreds
+// of images run concurrently (one per workgroup), which is where the throughput comes from.
+//
+// All arithmetic is fp64 (fp32 only where the reference is fp32: the prior weights).  The
+// translation unit is compiled with -ffp-contract=off so that products and sums round like the
+// reference's separate NumPy ufunc calls; the two bandwidth-bound accumulation loops use an
+// explicit fma().
+//
+// Conventions: every VPK_DEVFN below is called by ALL threads of the workgroup with uniform
+// arguments, expects its inputs to be visible (a barrier has happened) and ends with a barrier.
+// Citations are file:line under /root/reference.
+#ifndef VPK_EM_DEVICE_HPP_
+#define VPK_EM_DEVICE_HPP_
+
+#include "wave_prims.hpp"
+#include "../../include/vpk.h"
+#include "em_layout.hpp"
+
+namespace vpk {
+
+constexpr int MAXM = 64;            // capacity of simultaneously live VP hypotheses
+constexpr int GRIDN = 20;           // CNN output grid (cnn/deploy.prototxt:283-296)
+constexpr int NCELL = GRIDN * GRIDN;
+constexpr int MAXCOMP = 100;        // prior keeps the 100 strongest cells (probability_functions.py:87)
+constexpr int MT = 8;               // VP tile of the smoothing kernel (accumulators per column)
+constexpr int PART_DOUBLES = 4096;  // LDS partial-sum buffer (32 KiB)
+constexpr int KNN1 = 10;            // line_rating_knn k1 (vp_localisation.py:34,230)
+constexpr int KNN2 = 4;             // k2=4 at the call site (:230)
+constexpr double PI_D = 3.141592653589793238462643383279502884;
+
+struct Shared {
+    double cur[MAXM * 3];   // v[i]   of the reference's history array
+    double nxt[MAXM * 3];   // v[i+1]
+    double s[MAXM];         // per-VP variance
+    double pv[MAXM];        // prior p(v)
+    double vx[MAXM], vy[MAXM];  // VP projected to the image plane
+    double k2[MAXM];        // 1 / sqrt(2 pi s)
+    double cnt[MAXM], cntw[MAXM], err[MAXM];
+    int removed[MAXM];
+    int icnt[MAXM];
+    double red_v[32];
+    int red_i[32];
+    double pma[MAXCOMP], pmb[MAXCOMP], pw[MAXCOMP];  // prior mixture (alpha, beta, weight)
+    float wts[NCELL];
+    unsigned char mx[NCELL];
+    int ncomp;
+    int M;
+    int status;
+    unsigned flags;
+    int ibuf[8];
+    double dbuf[16];
+    double sigma_prior;
+    double part[PART_DOUBLES];
+};
+
+struct EmCtx {
+    int N;
+    int ldn;   // row stride of the [m][n] arrays (N rounded up to 8)
+    int ld;    // row stride of lsim
+    int mcap;  // row stride of wsrc ([n][m]); multiple of MT
+    double* l;
+    const double* lp;
+    const float* cnn;
+    const unsigned char* sphere;
+    int ssize;
+    const double* init_vp;
+    int n_init;
+    vpk_em_params prm;
+    // per-slot global scratch
+    double* lsim;     // N x ld
+    double* den;      // N   : 1 + bias * lweight[k] * sum_j lsim[j][k]
+    double* lweight;  // N
+    double* langle;   // N
+    double* lscore;   // N
+    double* lvsq;     // [m][n]
+    double* pvl;      // [m][n]
+    double* w;        // [m][n]
+    double* wsrc;     // [n][mcap] : p_vl * lweight, VP index contiguous (broadcast reads)
+    double* drow;     // nwaves x ldn closest-distance rows (kNN selection)
+    double* cl;       // split: Nw x Nw cluster distances (NULL when do_split == 0)
+    int* assoc;       // N
+    int* idx;         // N (split: gathered line indices, cluster membership)
+    Shared* sh;
+};
+
+// point the context's scratch pointers into one slot
+VPK_DEV void bind_scratch(EmCtx& c, double* base, const EmLayout& L, bool do_split) {
+    c.ldn = L.ldn; c.ld = L.ld; c.mcap = L.mcap;
+    c.lsim = base + L.lsim; c.den = base + L.den; c.lweight = base + L.lweight;
+    c.langle = base + L.langle; c.lscore = base + L.lscore; c.lvsq = base + L.lvsq;
+    c.pvl = base + L.pvl; c.w = base + L.w; c.wsrc = base + L.wsrc; c.drow = base + L.drow;
+    c.cl = do_split ? base + L.cl : nullptr;
+    c.assoc = (int*)(base + L.assoc);
+    c.idx = (int*)(base + L.idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+VPK_DEV double clip(double x, double lo, double hi) {  // np.clip (NaN passes through)
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+VPK_DEV bool is_nan(double x) { return x != x; }
+VPK_DEV double sign_np(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : (x == 0 ? 0.0 : x)); }
+
+// workgroup-wide lexicographic (value, index) minimum; result to every thread
+VPK_DEVFN void block_argmin(Shared& sh, double& v, int& idx) {
+    wave_argmin(v, idx);
+    if (lane() == 0) {
+        sh.red_v[wave_id()] = v;
+        sh.red_i[wave_id()] = idx;
+    }
+    block_sync();
+    double bv = sh.red_v[0];
+    int bi = sh.red_i[0];
+    for (int k = 1; k < nwaves(); ++k) {
+        double u = sh.red_v[k];
+        int j = sh.red_i[k];
+        bool take = (u < bv) || (u == bv && j < bi) || (bv != bv && u == u);
+        bv = take ? u : bv;
+        bi = take ? j : bi;
+    }
+    block_sync();
+    v = bv;
+    idx = bi;
+}
+VPK_DEVFN double block_max(Shared& sh, double v) {
+    v = wave_max(v);
+    if (lane() == 0) sh.red_v[wave_id()] = v;
+    block_sync();
+    double b = sh.red_v[0];
+    for (int k = 1; k < nwaves(); ++k) b = nanmax(b, sh.red_v[k]);
+    block_sync();
+    return b;
+}
+
+// symmetric 3x3 eigen-solver (cyclic Jacobi); returns the unit eigenvector of the SMALLEST
+// eigenvalue of [[a00,a01,a02],[a01,a11,a12],[a02,a12,a22]].  Stands in for the smallest right
+// singular vector of the row-weighted N x 3 line matrix (numpy.linalg.svd at
+// vp_localisation.py:466,595): V[:,2] of A equals the bottom eigenvector of A^T A.
+VPK_DEV void eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22,
+                           double out[3]) {
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (!(off > 0)) break;
+        for (int p = 0; p < 2; ++p) {
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = A[p][q];
+                if (apq == 0) continue;
+                double g = 100.0 * fabs(apq);
+                if (sweep > 2 && fabs(A[p][p]) + g == fabs(A[p][p]) && fabs(A[q][q]) + g == fabs(A[q][q])) {
+                    A[p][q] = 0; A[q][p] = 0;                 // negligible against both diagonals
+                    continue;
+                }
+                double theta = (A[q][q] - A[p][p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                if (!(fabs(theta) < 1e150)) t = 0.5 / theta;  // avoid overflow of theta^2
+                double cth = 1 / sqrt(t * t + 1);
+                double sth = t * cth;
+                double app = A[p][p], aqq = A[q][q];
+                A[p][p] = app - t * apq;
+                A[q][q] = aqq + t * apq;
+                A[p][q] = 0;
+                A[q][p] = 0;
+                int r = 3 - p - q;
+                double arp = A[r][p], arq = A[r][q];
+                A[r][p] = A[p][r] = cth * arp - sth * arq;
+                A[r][q] = A[q][r] = sth * arp + cth * arq;
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cth * vkp - sth * vkq;
+                    V[k][q] = sth * vkp + cth * vkq;
+                }
+            }
+        }
+    }
+    int b = 0;
+    if (A[1][1] < A[b][b]) b = 1;
+    if (A[2][2] < A[b][b]) b = 2;
+    double x = V[0][b], y = V[1][b], z = V[2][b];
+    double nrm = sqrt(x * x + y * y + z * z);
+    out[0] = x / nrm;
+    out[1] = y / nrm;
+    out[2] = z / nrm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment geometry (vp_localisation.py:700-776)
+// ---------------------------------------------------------------------------------------------
+// vp_localisation.py:743-758: the reference squares the NORM of (b - a) (:747)
+VPK_DEV double seg_point_dist(double ax, double ay, double bx, double by, double px, double py) {
+    double dx = bx - ax, dy = by - ay;
+    double nrm = sqrt(dx * dx + dy * dy);
+    double param = ((px - ax) * dx + (py - ay) * dy) / (nrm * nrm);
+    double cx, cy;
+    if (param < 0) {
+        cx = ax; cy = ay;
+    } else if (param > 1) {
+        cx = bx; cy = by;
+    } else {
+        cx = ax + param * dx; cy = ay + param * dy;
+    }
+    double ex = cx - px, ey = cy - py;
+    return sqrt(ex * ex + ey * ey);
+}
+// vp_localisation.py:727-740
+VPK_DEV double line_distance_closest(const double a[4], const double b[4]) {
+    double d1 = seg_point_dist(a[0], a[1], a[2], a[3], b[0], b[1]);
+    double d2 = seg_point_dist(a[0], a[1], a[2], a[3], b[2], b[3]);
+    double d4 = seg_point_dist(b[0], b[1], b[2], b[3], a[0], a[1]);
+    double d5 = seg_point_dist(b[0], b[1], b[2], b[3], a[2], a[3]);
+    double m = d1 < d2 ? d1 : d2;           // np.min of [d1,d2,d4,d5]; NaN handling not replicated
+    double q = d4 < d5 ? d4 : d5;
+    return m < q ? m : q;
+}
+// vp_localisation.py:715-724
+VPK_DEV double lines_cosangle(const double a[4], const double b[4], double f) {
+    double v1x = a[0] - a[2], v1y = a[1] - a[3];
+    double v2x = b[0] - b[2], v2y = b[1] - b[3];
+    double n1 = sqrt(v1x * v1x + v1y * v1y), n2 = sqrt(v2x * v2x + v2y * v2y);
+    double c = fabs((v1x * v2x + v1y * v2y) / (n1 * n2));
+    double dphi = fabs(acos(clip(c, -1.0, 1.0)));
+    return cos(clip(f * dphi, -PI_D / 2, PI_D / 2));
+}
+VPK_DEV double line_length(const double a[4]) {
+    double dx = a[0] - a[2], dy = a[1] - a[3];
+    return sqrt(dx * dx + dy * dy);
+}
+// vp_localisation.py:708-712 with the distance supplied
+VPK_DEV double proximity(double d, double len_a, double len_b, double sigma) {
+    double sg = sigma * (len_a < len_b ? len_a : len_b);
+    return exp(-(d * d) / (2 * sg * sg));
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup: line normalisation, pairwise similarity + kNN score, weights
+// ---------------------------------------------------------------------------------------------
+// vp_localisation.py:185-186 and again :226 (the second pass divides by ~1)
+VPK_DEVFN void normalise_lines(EmCtx& c) {
+    for (int n = tid(); n < c.N; n += nthreads()) {
+        double* r = c.l + 3 * (size_t)n;
+        for (int pass = 0; pass < 2; ++pass) {
+            double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            r[0] /= nr; r[1] /= nr; r[2] /= nr;
+        }
+    }
+    block_sync();
+}
+
+// calc_lsim (vp_localisation.py:87-108, sigma=1 at :178) and line_rating_knn (:34-84, k2=4 at
+// :230) in ONE pass over the pairs: the closest distance is shared by both.  One wave per row,
+// lanes over columns (coalesced lsim stores).  Also lines_angles (:765-776).
+VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
+    Shared& sh = *c.sh;
+    const int N = c.N;
+    double* drow = c.drow + (size_t)wave_id() * c.ldn;
+    // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
+    double* ks = sh.part + wave_id() * (4 * KNN1);
+    const int k1 = N < KNN1 ? N : KNN1;
+    const int k2 = N < KNN2 ? N : KNN2;
+    for (int i = wave_id(); i < N; i += nwaves()) {
+        double a[4] = {c.lp[4 * (size_t)i], c.lp[4 * (size_t)i + 1], c.lp[4 * (size_t)i + 2],
+                       c.lp[4 * (size_t)i + 3]};
+        const double len_a = line_length(a);
+        for (int j = lane(); j < N; j += WAVE) {
+            double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2],
+                           c.lp[4 * (size_t)j + 3]};
+            double d = line_distance_closest(a, b);
+            if (want_lsim) {
+                double sim = lines_cosangle(a, b, 9.0) * proximity(d, len_a, line_length(b), 1.0);
+                c.lsim[(size_t)i * c.ld + j] = (i == j) ? 0.0 : sim;
+            }
+            drow[j] = (i == j) ? 4.0 : d;  // :82
+        }
+        wave_sync();
+        // k1 nearest by k1 rounds of lexicographic (distance, index) selection
+        double last_d = -1.0;
+        int last_j = -1;
+        for (int r = 0; r < k1; ++r) {
+            double bd = 1e300;
+            int bj = 0x7fffffff;
+            for (int j = lane(); j < N; j += WAVE) {
+                double d = drow[j];
+                bool after = (d > last_d) || (d == last_d && j > last_j);
+                if (after && ((d < bd) || (d == bd && j < bj))) { bd = d; bj = j; }
+            }
+            wave_argmin(bd, bj);
+            if (lane() == 0) { ks[r] = (double)bj; ks[KNN1 + r] = bd; }
+            last_d = bd;
+            last_j = bj;
+        }
+        wave_sync();
+        for (int q = lane(); q < k1; q += WAVE) {
+            int j = (int)ks[q];
+            double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2],
+                           c.lp[4 * (size_t)j + 3]};
+            ks[2 * KNN1 + q] = lines_cosangle(a, b, 9.0);                          // :55
+            ks[3 * KNN1 + q] = proximity(ks[KNN1 + q], len_a, line_length(b), 1.0);  // :65
+        }
+        wave_sync();
+        if (lane() == 0) {
+            // np.argsort(cosphi)[::-1][0:k2] (:57-59): descending, ties -> later position first
+            double sum = 0.0;
+            for (int r = 0; r < k2; ++r) {
+                for (int q = 0; q < k1; ++q) {
+                    double cq = ks[2 * KNN1 + q];
+                    int rank = 0;
+                    for (int p = 0; p < k1; ++p) {
+                        double cp = ks[2 * KNN1 + p];
+                        rank += (cp > cq) || (cp == cq && p > q);
+                    }
+                    if (rank == r) sum += ks[3 * KNN1 + q] * cq;                     // :66-68
+                }
+            }
+            c.lscore[i] = sum / k2;                                                 // :70
+            // lines_angles (:765-776)
+            double vx = a[0] - a[2], vy = a[1] - a[3];
+            double nr = sqrt(vx * vx + vy * vy);
+            double phi = fabs(acos(clip(vx / nr, -1.0, 1.0)));
+            c.langle[i] = phi > PI_D / 2 ? PI_D - phi : phi;
+        }
+        wave_sync();
+    }
+    block_sync();
+}
+
+// lweight = len * clip(lscore, 0.2, 1) (vp_localisation.py:227-233) and the hoisted denominator
+// of weight_matrix (:522): den[k] = 1 + bias * lweight[k] * sum_j lsim[j][k]
+VPK_DEVFN void weights_setup(EmCtx& c) {
+    const int N = c.N;
+    const bool uw = c.prm.use_weights != 0;
+    for (int n = tid(); n < N; n += nthreads()) {
+        double a[4] = {c.lp[4 * (size_t)n], c.lp[4 * (size_t)n + 1], c.lp[4 * (size_t)n + 2],
+                       c.lp[4 * (size_t)n + 3]};
+        c.lweight[n] = uw ? line_length(a) * clip(c.lscore[n], 0.2, 1.0) : 1.0;
+    }
+    block_sync();
+    for (int k = tid(); k < N; k += nthreads()) {
+        double sum = 0.0;
+        if (uw)
+            for (int j = 0; j < N; ++j) sum += c.lsim[(size_t)j * c.ld + k];
+        c.den[k] = 1 + c.prm.wbias * c.lweight[k] * sum;
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// prior parameters and initial VPs from the CNN grid
+// ---------------------------------------------------------------------------------------------
+// numpy's float32 pairwise summation (np.sum over a contiguous float32 array), needed because
+// the prior weights are normalised in float32 (probability_functions.py:82-90)
+VPK_DEV float np_pairwise_block_f32(const float* a, int n) {   // 8 <= n <= 128
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+// n = 400 splits as (96 + 104) + (96 + 104): n2 = n/2 rounded down to a multiple of 8 at each level
+VPK_DEV float np_pairwise_sum_f32_400(const float* a) {
+    float lo = np_pairwise_block_f32(a, 96) + np_pairwise_block_f32(a + 96, 104);
+    float hi = np_pairwise_block_f32(a + 200, 96) + np_pairwise_block_f32(a + 296, 104);
+    return lo + hi;
+}
+
+// np.linspace(-(A-1)/A*pi/2, (A-1)/A*pi/2, A)[i] (probability_functions.py:73,75)
+VPK_DEV double grid_centre(int i) {
+    double start = -(GRIDN - 1.0) / GRIDN * PI_D / 2;
+    double stop = (GRIDN - 1.0) / GRIDN * PI_D / 2;
+    double step = (stop - start) / (GRIDN - 1);
+    return i == GRIDN - 1 ? stop : i * step + start;
+}
+
+// pdf_params (probability_functions.py:62-96): keep the 100 strongest cells, normalise in f32.
+VPK_DEVFN void prior_setup(EmCtx& c) {
+    Shared& sh = *c.sh;
+    for (int i = tid(); i < NCELL; i += nthreads()) sh.wts[i] = c.cnn[i];
+    block_sync();
+    float* keep = (float*)sh.part;  // 400 floats
+    for (int i = tid(); i < NCELL; i += nthreads()) {
+        float wi = sh.wts[i];
+        int rank = 0;  // position in argsort(weights)[::-1]: ties -> higher index first
+        for (int j = 0; j < NCELL; ++j) {
+            float wj = sh.wts[j];
+            rank += (wj > wi) || (wj == wi && j > i);
+        }
+        keep[i] = rank < MAXCOMP ? wi : 0.f;
+    }
+    block_sync();
+    if (tid() == 0) {
+        sh.sigma_prior = PI_D / (1.282 * GRIDN);  // :71
+        float sum = np_pairwise_sum_f32_400(keep);
+        float dv = (float)(2 * PI_D * sh.sigma_prior * sh.sigma_prior);
+        int nc = 0;
+        for (int i = 0; i < NCELL; ++i) {
+            float w = keep[i] / sum;
+            w = w / dv;
+            sh.wts[i] = w;
+            if (w > 0 && nc < MAXCOMP) {  // calc_pdf visits cells in index order (:20-21)
+                sh.pma[nc] = grid_centre(i % GRIDN);   // means[:,0] = alpha, varies along columns
+                sh.pmb[nc] = grid_centre(i / GRIDN);   // means[:,1] = beta, varies along rows
+                sh.pw[nc] = (double)w;
+                ++nc;
+            }
+        }
+        sh.ncomp = nc;
+    }
+    block_sync();
+}
+
+// find_maxima (vp_localisation.py:13-31) + find_initial_vps (:111-165).  Leaves the VPs in
+// sh.cur (row-major cell order), sh.M = count.  Uses sh.part as scratch.
+VPK_DEVFN void initial_vps(EmCtx& c) {
+    Shared& sh = *c.sh;
+    const float* r = c.cnn;
+    for (int i = tid(); i < NCELL; i += nthreads()) {
+        int b = i / GRIDN, a = i % GRIDN;
+        float vm = r[i];
+        float vu = (a + 1 < GRIDN) ? r[b * GRIDN + a + 1] : 0.f;
+        float vd = (a - 1 > 0) ? r[b * GRIDN + a - 1] : 0.f;   // quirk: index 0 never a neighbour
+        float vl = (b - 1 > 0) ? r[(b - 1) * GRIDN + a] : 0.f;
+        float vr = (b + 1 < GRIDN) ? r[(b + 1) * GRIDN + a] : 0.f;
+        sh.mx[i] = (vm > vu && vm > vd && vm > vl && vm > vr) ? 1 : 0;
+    }
+    block_sync();
+    unsigned char* keep = (unsigned char*)sh.part;          // 400 bytes
+    double* cand = sh.part + 64;                            // 400 x 4 doubles (x,y,z,valid)
+    const int num_max = c.prm.num_init_vp;
+    for (int i = tid(); i < NCELL; i += nthreads()) {
+        int k = 0;
+        if (sh.mx[i]) {
+            int rank = 0;  // argsort(resp[maxima])[::-1]: ties -> later maximum first (:123-125)
+            float vi = r[i];
+            for (int j = 0; j < NCELL; ++j)
+                if (sh.mx[j]) rank += (r[j] > vi) || (r[j] == vi && j > i);
+            k = rank < num_max;
+        }
+        keep[i] = (unsigned char)k;
+        cand[4 * i + 3] = 0.0;
+    }
+    block_sync();
+    const int S = c.ssize;
+    for (int cell = wave_id(); cell < NCELL; cell += nwaves()) {
+        if (!keep[cell]) continue;
+        int ra = cell / GRIDN, rb = cell % GRIDN;
+        int r0 = ra * S / GRIDN, r1 = (ra + 1) * S / GRIDN;   // rows of the FLIPPED image (:114,:133)
+        int c0 = rb * S / GRIDN, c1 = (rb + 1) * S / GRIDN;
+        int bw = c1 - c0, npix = (r1 - r0) * bw;
+        int mxv = 0;
+        for (int p = lane(); p < npix; p += WAVE) {
+            int rr = r0 + p / bw, cc = c0 + p % bw;
+            int v = c.sphere[(size_t)(S - 1 - rr) * S + cc];
+            mxv = v > mxv ? v : mxv;
+        }
+        mxv = wave_max_int(mxv);
+        if (mxv == 0) continue;                               // :137-142
+        int cntp = 0, sr = 0, sc = 0;
+        for (int p = lane(); p < npix; p += WAVE) {
+            int rr = p / bw, cc = p % bw;
+            int v = c.sphere[(size_t)(S - 1 - (r0 + rr)) * S + c0 + cc];
+            if (v == mxv) { ++cntp; sr += rr; sc += cc; }
+        }
+        cntp = wave_sum_int(cntp);
+        sr = wave_sum_int(sr);
+        sc = wave_sum_int(sc);
+        if (lane() == 0) {
+            double avg_r = (double)sr / cntp, avg_c = (double)sc / cntp;   // :148-151
+            double ia = avg_c + c0, ib = avg_r + r0;                       // :155-158 (col,row)
+            double alpha = (ia - 0.5 * S + 0.5) * PI_D / S;                // coordinate_conversion.py:14-15
+            double beta = (ib - 0.5 * S + 0.5) * PI_D / S;
+            double px = sin(alpha) * cos(beta), py = sin(beta), pz = cos(alpha) * cos(beta);
+            double sg = sign_np(pz);                                       // :48
+            cand[4 * cell + 0] = px * sg;
+            cand[4 * cell + 1] = py * sg;
+            cand[4 * cell + 2] = pz * sg;
+            cand[4 * cell + 3] = 1.0;
+        }
+    }
+    block_sync();
+    if (tid() == 0) {
+        int m = 0;
+        for (int cell = 0; cell < NCELL; ++cell) {
+            if (cand[4 * cell + 3] != 0.0 && m < MAXM) {
+                sh.cur[3 * m + 0] = cand[4 * cell + 0];
+                sh.cur[3 * m + 1] = cand[4 * cell + 1];
+                sh.cur[3 * m + 2] = cand[4 * cell + 2];
+                ++m;
+            }
+        }
+        sh.M = m;
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// E-step: calc_probabilities (probability_functions.py:99-147, "angle" branch)
+// ---------------------------------------------------------------------------------------------
+// X points at sh.cur or sh.nxt.  Writes lvsq[m][n], pvl[m][n], wsrc[n][m]; floors sh.s (:139).
+VPK_DEVFN void estep(EmCtx& c, const double* X) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    const double kk = -0.5 / (sh.sigma_prior * sh.sigma_prior);
+    // prior p(v): one wave per VP, lanes over mixture components (calc_angles :252-259, calc_pdf :8-40)
+    for (int m = wave_id(); m < M; m += nwaves()) {
+        double x0 = X[3 * m], x1 = X[3 * m + 1], x2 = X[3 * m + 2];
+        double beta = asin(x1);
+        double inner = x0 / cos(beta);
+        inner = inner < 1 ? inner : (is_nan(inner) ? inner : 1.0);
+        inner = inner > -1 ? inner : (is_nan(inner) ? inner : -1.0);
+        double alpha = asin(inner);
+        double acc = 0.0;
+        for (int q = lane(); q < sh.ncomp; q += WAVE) {
+            double ma = sh.pma[q], mb = sh.pmb[q];
+            double d1 = (alpha - ma) * (alpha - ma) + (beta - mb) * (beta - mb);
+            double d2 = (alpha - ma + PI_D) * (alpha - ma + PI_D) + (beta + mb) * (beta + mb);
+            double d3 = (alpha - ma - PI_D) * (alpha - ma - PI_D) + (beta + mb) * (beta + mb);
+            double d4 = (alpha + ma) * (alpha + ma) + (beta - mb - PI_D) * (beta - mb - PI_D);
+            double e4 = exp(d4 * kk);                        // the fifth term duplicates the fourth (:25-26)
+            double p = (((exp(d1 * kk) + exp(d2 * kk)) + exp(d3 * kk)) + e4) + e4;
+            acc += p * sh.pw[q];
+        }
+        acc = wave_sum(acc);
+        if (lane() == 0) {
+            sh.pv[m] = acc;
+            sh.vx[m] = x0 / x2;                              // calc_lvsq_angle :165-166
+            sh.vy[m] = x1 / x2;
+            double sm = sh.s[m];
+            sm = sm > 1e-200 ? sm : 1e-200;                  // calc_plv :139 (in place)
+            sh.s[m] = sm;
+            sh.k2[m] = 1.0 / sqrt(2 * PI_D * sm);            // :145
+        }
+    }
+    block_sync();
+    for (int n = tid(); n < N; n += nthreads()) {
+        const double* q = c.lp + 4 * (size_t)n;
+        double lmx = 0.5 * (q[0] + q[2]), lmy = 0.5 * (q[1] + q[3]);
+        double v2x = q[0] - q[2], v2y = q[1] - q[3];
+        double n2 = sqrt(v2x * v2x + v2y * v2y);
+        double pl = 0.0;
+        for (int m = 0; m < M; ++m) {
+            double v1x = lmx - sh.vx[m], v1y = lmy - sh.vy[m];
+            double n1 = sqrt(v1x * v1x + v1y * v1y);
+            double cc = 1 - fabs((v1x * v2x + v1y * v2y) / (n1 * n2));
+            double lv = cc * cc;                             // :174
+            c.lvsq[(size_t)m * c.ldn + n] = lv;
+            double plv = exp(-(lv / (2 * sh.s[m]))) * sh.k2[m];   // calc_plv :137-145
+            double t = plv * sh.pv[m];
+            c.pvl[(size_t)m * c.ldn + n] = t;
+            pl += t;                                         // p_l = dot(p_lv, p_v) :116
+        }
+        pl = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;        // :117
+        double lw = c.lweight[n];
+        double* ws = c.wsrc + (size_t)n * c.mcap;
+        for (int m = 0; m < M; ++m) {
+            double pvl = c.pvl[(size_t)m * c.ldn + n] / pl;  // calc_pvl :128
+            c.pvl[(size_t)m * c.ldn + n] = pvl;
+            ws[m] = pvl * lw;                                // weight_matrix :519
+        }
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothing: weight_matrix (vp_localisation.py:515-524), the (M x N) . (N x N) product
+// ---------------------------------------------------------------------------------------------
+// w[m][k] = (w_[m][k] + bias*lweight[k] * sum_j w_[m][j] lsim[j][k]) / den[k].
+// Each thread owns one column k (lanes -> consecutive k: coalesced lsim rows) and MT VP
+// accumulators; when N is small the j range is sliced across thread groups and combined
+// through LDS.  w_ is read as wsrc[j][m..m+MT) -- a wave-uniform (broadcast) address.
+VPK_DEVFN void smooth(EmCtx& c) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N, nt = nthreads();
+    if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl
+        for (int m = 0; m < M; ++m)
+            for (int k = tid(); k < N; k += nt) c.w[(size_t)m * c.ldn + k] = c.wsrc[(size_t)k * c.mcap + m];
+        block_sync();
+        return;
+    }
+    int ncols = ((N + WAVE - 1) / WAVE) * WAVE;
+    if (ncols > nt) ncols = nt;
+    int S = nt / ncols;
+    if (S * MT * ncols > PART_DOUBLES) S = PART_DOUBLES / (MT * ncols);
+    if (S < 1) S = 1;
+    const int col = tid() % ncols, slice = tid() / ncols;
+    const bool active = slice < S;
+    const int jchunk = (N + S - 1) / S;
+    const int j0 = slice * jchunk;
+    const int j1 = (j0 + jchunk) < N ? (j0 + jchunk) : N;
+    const double bias = c.prm.wbias;
+    for (int m0 = 0; m0 < M; m0 += MT) {
+        for (int k0 = 0; k0 < N; k0 += ncols) {
+            const int k = k0 + col;
+            double acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = 0.0;
+            if (active && k < N) {
+                const double* lcol = c.lsim + k;
+                const double* ws = c.wsrc + m0;
+                for (int j = j0; j < j1; ++j) {
+                    double a = lcol[(size_t)j * c.ld];
+                    const double* wj = ws + (size_t)j * c.mcap;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = fma(wj[t], a, acc[t]);
+                }
+            }
+            if (S > 1) {
+                if (active && slice > 0)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) sh.part[((slice - 1) * MT + t) * ncols + col] = acc[t];
+                block_sync();
+                if (slice == 0)
+                    for (int sl = 1; sl < S; ++sl)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] += sh.part[((sl - 1) * MT + t) * ncols + col];
+            }
+            if (slice == 0 && k < N) {
+                double lw = c.lweight[k], dn = c.den[k];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (m0 + t < M)
+                        c.w[(size_t)(m0 + t) * c.ldn + k] =
+                            (c.wsrc[(size_t)k * c.mcap + m0 + t] + bias * lw * acc[t]) / dn;
+            }
+            if (S > 1) block_sync();
+        }
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// line -> VP association and counts: calc_vp_line_counts (vp_localisation.py:482-512)
+// ---------------------------------------------------------------------------------------------
+// np.argmax over VPs (first maximum; a NaN counts as the maximum).  hard = apply the outlier test.
+VPK_DEVFN void assign_lines(EmCtx& c, bool hard) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    for (int n = tid(); n < N; n += nthreads()) {
+        int best = 0;
+        double bv = c.w[n];
+        for (int m = 1; m < M; ++m) {
+            double v = c.w[(size_t)m * c.ldn + n];
+            if (!is_nan(bv) && (v > bv || is_nan(v))) { bv = v; best = m; }
+        }
+        if (hard && M > 0) {
+            double dist = c.lvsq[(size_t)best * c.ldn + n];   // == calc_lvsq_single on the same VP slice
+            if (dist > c.prm.outlier_thresh * sqrt(sh.s[best]))
+                best = -1;                                    // :504
+            else if (c.lweight[n] == 0)
+                best = -1;                                    // :506
+        }
+        c.assoc[n] = best;
+    }
+    block_sync();
+}
+VPK_DEVFN void count_lines(EmCtx& c) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    for (int m = wave_id(); m < M; m += nwaves()) {
+        int cnt = 0;
+        double cw = 0.0;
+        for (int n = lane(); n < N; n += WAVE)
+            if (c.assoc[n] == m) { ++cnt; cw += c.lweight[n]; }
+        cnt = wave_sum_int(cnt);
+        cw = wave_sum(cw);
+        if (lane() == 0) { sh.cnt[m] = (double)cnt; sh.cntw[m] = cw; }
+    }
+    block_sync();
+}
+
+// remove the VPs flagged in sh.removed from cur / nxt / s (np.delete along the VP axis)
+VPK_DEVFN void compact_vps(EmCtx& c) {
+    Shared& sh = *c.sh;
+    if (tid() == 0) {
+        int k = 0;
+        for (int m = 0; m < sh.M; ++m) {
+            if (sh.removed[m]) continue;
+            if (k != m) {
+                for (int d = 0; d < 3; ++d) {
+                    sh.cur[3 * k + d] = sh.cur[3 * m + d];
+                    sh.nxt[3 * k + d] = sh.nxt[3 * m + d];
+                }
+                sh.s[k] = sh.s[m];
+            }
+            ++k;
+        }
+        sh.M = k;
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// M-step: calc_new_vanishing_point (vp_localisation.py:453-479) + variance (:301-307)
+// ---------------------------------------------------------------------------------------------
+// One wave per VP.  mode 0: soft (all lines, weights w[m]); mode 1: hard (lines with
+// assoc == m, :353-392).  On return sh.removed[] / sh.err[] are set; nxt and s updated.
+VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    for (int m = wave_id(); m < M; m += nwaves()) {
+        const double* wm = c.w + (size_t)m * c.ldn;
+        double wmax = -1e300;
+        int nsel = 0;
+        for (int n = lane(); n < N; n += WAVE) {
+            if (mode == 1 && c.assoc[n] != m) continue;
+            wmax = nanmax(wmax, wm[n]);
+            ++nsel;
+        }
+        wmax = wave_max(wmax);
+        nsel = wave_sum_int(nsel);
+        if (mode == 1 && nsel == 0) {                         // :355-356 `continue`
+            if (lane() == 0) { sh.removed[m] = 0; sh.err[m] = -1.0; }
+            continue;
+        }
+        bool valid = nsel > 0 && (wmax > 0 || wmax < 0);      // :456-460; NaN -> LinAlgError -> None
+        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, sv = 0, sp = 0;
+        const double* lvs = c.lvsq + (size_t)m * c.ldn;
+        const double* pvl = c.pvl + (size_t)m * c.ldn;
+        for (int n = lane(); n < N; n += WAVE) {
+            double pq = pvl[n];
+            sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
+            sp += pq;
+            if (mode == 1 && c.assoc[n] != m) continue;
+            double r = wm[n] / wmax;                          // :462 (hard mode: :358, then /1 at :462)
+            const double* ln = c.l + 3 * (size_t)n;
+            double x = r * ln[0], y = r * ln[1], z = r * ln[2];
+            a00 += x * x; a01 += x * y; a02 += x * z;
+            a11 += y * y; a12 += y * z; a22 += z * z;
+        }
+        a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
+        a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
+        sv = wave_sum(sv);
+        sp = wave_sum(sp);
+        if (lane() == 0) {
+            int rem = 0;
+            double err = -1.0;
+            if (!valid) {
+                rem = 1;                                      // newVP is None (:294-296)
+            } else {
+                double vp[3];
+                eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
+                double sg = sign_np(vp[2]);                   // :474
+                vp[0] *= sg; vp[1] *= sg; vp[2] *= sg;
+                sh.nxt[3 * m] = vp[0]; sh.nxt[3 * m + 1] = vp[1]; sh.nxt[3 * m + 2] = vp[2];
+                double sm = exp(log(sv) - log(sp));           // :303-304
+                sm = (sm < max_stdd || is_nan(sm)) ? sm : max_stdd;          // :306 np.minimum
+                if (mode == 0)
+                    sm = (sm > c.prm.s_thresh || is_nan(sm)) ? sm : c.prm.s_thresh;   // :307
+                sh.s[m] = sm;
+                if (is_nan(sm) || (mode == 1 && sm < c.prm.s_thresh)) {
+                    rem = 1;                                  // :309-310 / :379-380
+                } else {
+                    double d = fabs(sh.cur[3 * m] * vp[0] + sh.cur[3 * m + 1] * vp[1] + sh.cur[3 * m + 2] * vp[2]);
+                    err = acos(d < 1.0 ? d : 1.0);            // :312
+                    if (err > 1.5) rem = 1;                   // :316-317
+                }
+            }
+            sh.removed[m] = rem;
+            sh.err[m] = err;
+        }
+    }
+    block_sync();
+}
+
+// max over the per-VP errors with np.maximum semantics (NaN sticks); VPs without an error are -1
+VPK_DEV double max_err_of(const Shared& sh, int M) {
+    double mx = 0.0;
+    for (int m = 0; m < M; ++m) {
+        double e = sh.err[m];
+        if (e == -1.0) continue;
+        mx = (is_nan(mx) || is_nan(e)) ? (is_nan(mx) ? mx : e) : (e > mx ? e : mx);
+    }
+    return mx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge_vps (vp_localisation.py:633-697)
+// ---------------------------------------------------------------------------------------------
+VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
+    Shared& sh = *c.sh;
+    const int N = c.N;
+    for (int guard = 0; guard < 4 * MAXM; ++guard) {
+        const int M = sh.M;
+        if (M <= 1) break;
+        double* X = use_next ? sh.nxt : sh.cur;
+        double bv = 1e300;
+        int bi = 0x7fffffff;
+        for (int p = tid(); p < M * M; p += nthreads()) {
+            int j = p / M, k = p % M;
+            double d = X[3 * j] * X[3 * k] + X[3 * j + 1] * X[3 * k + 1] + X[3 * j + 2] * X[3 * k + 2];
+            double ang = (j == k) ? PI_D : fabs(acos(clip(fabs(clip(d, -1.0, 1.0)), -1.0, 1.0)));  // :691-696
+            if (ang < bv || (ang == bv && p < bi)) { bv = ang; bi = p; }
+        }
+        block_argmin(sh, bv, bi);                             // first row-major minimum (:650)
+        if (!(bv < thresh)) break;                            // :655,:679-680
+        const int j = bi / M, k = bi % M;
+        estep(c, X);                                          // :658 (at the caller's index)
+        smooth(c);
+        if (wave_id() == 0) {                                 // newVP from w[j] + w[k] (:661)
+            const double* wj = c.w + (size_t)j * c.ldn;
+            const double* wk = c.w + (size_t)k * c.ldn;
+            double wmax = -1e300;
+            for (int n = lane(); n < N; n += WAVE) wmax = nanmax(wmax, wj[n] + wk[n]);
+            wmax = wave_max(wmax);
+            bool valid = N > 0 && (wmax > 0 || wmax < 0);
+            double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, sv = 0, sp = 0;
+            const double* lj = c.lvsq + (size_t)j * c.ldn;
+            const double* lk = c.lvsq + (size_t)k * c.ldn;
+            const double* pj = c.pvl + (size_t)j * c.ldn;
+            const double* pk = c.pvl + (size_t)k * c.ldn;
+            for (int n = lane(); n < N; n += WAVE) {
+                double pq = pk[n] + pj[n];
+                sv += 0.5 * (lj[n] + lk[n]) * pq;             // :664
+                sp += pq;                                     // :663
+                double r = (wj[n] + wk[n]) / wmax;
+                const double* ln = c.l + 3 * (size_t)n;
+                double x = r * ln[0], y = r * ln[1], z = r * ln[2];
+                a00 += x * x; a01 += x * y; a02 += x * z;
+                a11 += y * y; a12 += y * z; a22 += z * z;
+            }
+            a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
+            a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
+            sv = wave_sum(sv);
+            sp = wave_sum(sp);
+            if (lane() == 0) {
+                double sk = exp(log(sv) - log(sp));
+                sh.s[k] = sk;                                 // :666 written BEFORE the abort test
+                int ok = valid && !(sk > 0.01);               // :668 (max_stdd = 0.01)
+                if (ok) {
+                    double vp[3];
+                    eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
+                    double sg = sign_np(vp[2]);
+                    X[3 * k] = vp[0] * sg; X[3 * k + 1] = vp[1] * sg; X[3 * k + 2] = vp[2] * sg;   // :672
+                    for (int m = 0; m < M; ++m) sh.removed[m] = (m == j);                            // :674-675
+                }
+                sh.ibuf[0] = ok;
+            }
+        }
+        block_sync();
+        if (!sh.ibuf[0]) break;
+        compact_vps(c);
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-cluster average-linkage agglomeration == sklearn AgglomerativeClustering(linkage='average',
+// connectivity=D, n_clusters=2, metric='precomputed') as called at vp_localisation.py:574-578.
+// sklearn 0.18..1.7 behaviour restated: edges are the non-zero entries of D + D^T; repeatedly
+// merge the closest connected pair; a neighbour shared by both gets (n_a d_a + n_b d_b)/(n_a+n_b),
+// a neighbour of only one keeps its distance; the full tree is built and cut at the root, the
+// cluster formed LAST (node 2n-3) gets label 0 (_hc_cut pops the larger node id first).
+// Exact ties between candidate merges are resolved by Python heap order in sklearn; here by the
+// smallest matrix position, and VPK_EM_FLAG_SPLIT_TIE is raised.
+// D: n x n working copy in global memory (destroyed); member: n ints; labels -> member (0/1).
+// ---------------------------------------------------------------------------------------------
+VPK_DEVFN void cluster2(Shared& sh, int n, double* D, int* member, int* csize) {
+    for (int p = tid(); p < n * n; p += nthreads()) {
+        int a = p / n, b = p % n;
+        double v = D[p];
+        if (a == b || !(v + D[(size_t)b * n + a] != 0.0)) D[p] = -1.0;   // no edge
+    }
+    for (int a = tid(); a < n; a += nthreads()) { member[a] = a; csize[a] = 1; }
+    block_sync();
+    int last_slot = -1;
+    for (int t = 0; t < n - 2; ++t) {
+        double bv = 1e300;
+        int bi = 0x7fffffff;
+        int ties = 0;
+        for (int p = tid(); p < n * n; p += nthreads()) {
+            int a = p / n, b = p % n;
+            if (a <= b || csize[a] == 0 || csize[b] == 0) continue;
+            double v = D[p];
+            if (v < 0) continue;
+            if (v < bv) { bv = v; bi = p; ties = 0; }
+            else if (v == bv) { ties = 1; }
+        }
+        const double myv = bv;
+        block_argmin(sh, bv, bi);
+        if (bi == 0x7fffffff) {                               // graph exhausted: disconnected
+            if (tid() == 0) sh.flags |= VPK_EM_FLAG_SPLIT_DISCONNECTED;
+            break;
+        }
+        // tie detection: the winning value occurs at more than one candidate position
+        if (tid() == 0) sh.ibuf[1] = 0;
+        block_sync();
+        if (myv == bv) atomic_add_int(&sh.ibuf[1], 1 + ties);
+        block_sync();
+        const int a = bi / n, b = bi % n;                     // a > b; the merged cluster lives in slot a
+        const int na = csize[a], nb = csize[b];
+        block_sync();
+        for (int cidx = tid(); cidx < n; cidx += nthreads()) {
+            if (cidx == a || cidx == b || csize[cidx] == 0) continue;
+            double da = D[(size_t)a * n + cidx], db = D[(size_t)b * n + cidx];
+            double nv;
+            if (da >= 0 && db >= 0)
+                nv = (na * da + nb * db) / (double)(na + nb);  // average_merge
+            else
+                nv = da >= 0 ? da : db;                        // only one side connected (or none: -1)
+            D[(size_t)a * n + cidx] = nv;
+            D[(size_t)cidx * n + a] = nv;
+        }
+        for (int q = tid(); q < n; q += nthreads())
+            if (member[q] == b) member[q] = a;
+        block_sync();
+        if (tid() == 0) {
+            csize[a] = na + nb;
+            csize[b] = 0;
+            if (sh.ibuf[1] >= 2) sh.flags |= VPK_EM_FLAG_SPLIT_TIE;
+        }
+        last_slot = a;
+        block_sync();
+    }
+    for (int q = tid(); q < n; q += nthreads()) member[q] = (member[q] == last_slot) ? 0 : 1;
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// split_best_vp (vp_localisation.py:527-630).  Expects w = weight matrix of sh.cur.
+// ---------------------------------------------------------------------------------------------
+VPK_DEVFN void split_vp(EmCtx& c) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    if (M == 0 || c.cl == nullptr) return;
+    assign_lines(c, false);                                   // weightIndices (:536) == vpAssoc (:551)
+    double wmx = -1e300;
+    for (int m = 0; m < M; ++m)
+        for (int n = tid(); n < N; n += nthreads()) wmx = nanmax(wmx, c.w[(size_t)m * c.ldn + n]);
+    wmx = block_max(sh, wmx);                                 // weightMatrix.max() (:539)
+    // per VP: std of the folded line angle over lines with greedy weight > 0 (:541-544)
+    for (int m = wave_id(); m < M; m += nwaves()) {
+        int cnt = 0, call = 0;
+        double sum = 0.0;
+        for (int n = lane(); n < N; n += WAVE) {
+            if (c.assoc[n] != m) continue;
+            ++call;
+            if (c.w[(size_t)m * c.ldn + n] / wmx > 0) { ++cnt; sum += c.langle[n]; }
+        }
+        cnt = wave_sum_int(cnt);
+        call = wave_sum_int(call);
+        sum = wave_sum(sum);
+        double mean = sum / cnt;
+        double sq = 0.0;
+        for (int n = lane(); n < N; n += WAVE)
+            if (c.assoc[n] == m && c.w[(size_t)m * c.ldn + n] / wmx > 0) {
+                double d = c.langle[n] - mean;
+                sq += d * d;
+            }
+        sq = wave_sum(sq);
+        if (lane() == 0) {
+            sh.err[m] = cnt > 0 ? sqrt(sq / cnt) : __builtin_nan("");   // np.std of an empty set is NaN
+            sh.icnt[m] = call;
+        }
+    }
+    block_sync();
+    if (tid() == 0) {
+        // worstVPs = argsort(stdd)[::-1] (:546-547): ascending with NaN last, reversed
+        int order[MAXM];
+        for (int m = 0; m < M; ++m) order[m] = m;
+        for (int i = 1; i < M; ++i) {                         // stable insertion sort
+            int key = order[i];
+            double kv = sh.err[key];
+            int j = i - 1;
+            while (j >= 0) {
+                double jv = sh.err[order[j]];
+                bool greater = (is_nan(jv) && !is_nan(kv)) || (jv > kv);
+                if (!greater) break;
+                order[j + 1] = order[j];
+                --j;
+            }
+            order[j + 1] = key;
+        }
+        int worst = -1;
+        for (int m = 0; m < M; ++m) {
+            int cand = order[M - 1 - m];
+            double px = sh.cur[3 * m] / sh.cur[3 * m + 2];    // :557 tests VP m, not worstVPs[m]
+            double py = sh.cur[3 * m + 1] / sh.cur[3 * m + 2];
+            if (sh.icnt[cand] > 8 && (px > -1 && py > -1 && px < 1 && py < 1)) { worst = cand; break; }
+        }
+        sh.ibuf[3] = worst;
+        int nw = 0;
+        if (worst >= 0)
+            for (int n = 0; n < N; ++n)
+                if (c.assoc[n] == worst) c.idx[nw++] = n;     // assocLines, ascending (:552)
+        sh.ibuf[4] = nw;
+    }
+    block_sync();
+    const int worst = sh.ibuf[3], nw = sh.ibuf[4];
+    if (worst < 0) return;
+    const double stdd = sh.s[worst] / 2;                      // :566
+    for (int p = tid(); p < nw * nw; p += nthreads()) {       // Ldist (:568-572)
+        int a = p / nw, b = p % nw;
+        double v = 0.0;
+        if (a != b) {
+            const double* qa = c.lp + 4 * (size_t)c.idx[a];
+            const double* qb = c.lp + 4 * (size_t)c.idx[b];
+            double la[4] = {qa[0], qa[1], qa[2], qa[3]}, lb[4] = {qb[0], qb[1], qb[2], qb[3]};
+            v = 1 - lines_cosangle(la, lb, 2.0);
+        }
+        c.cl[p] = v;
+    }
+    block_sync();
+    int* member = c.idx + N;          // idx has room for 3N ints
+    int* csize = c.idx + 2 * N;
+    cluster2(sh, nw, c.cl, member, csize);
+    // per cluster: smallest right singular vector of the lweight-scaled lines (:580-602)
+    for (int cidx = wave_id(); cidx < 2; cidx += nwaves()) {
+        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+        int cnt = 0;
+        for (int q = lane(); q < nw; q += WAVE) {
+            if (member[q] != cidx) continue;
+            ++cnt;
+            int n = c.idx[q];
+            double lw = c.lweight[n];
+            const double* ln = c.l + 3 * (size_t)n;
+            double x = ln[0] * lw, y = ln[1] * lw, z = ln[2] * lw;
+            a00 += x * x; a01 += x * y; a02 += x * z;
+            a11 += y * y; a12 += y * z; a22 += z * z;
+        }
+        cnt = wave_sum_int(cnt);
+        a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
+        a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
+        if (lane() == 0) {
+            double* o = sh.dbuf + 4 * cidx;
+            o[3] = 0.0;
+            if (cnt >= 3) {                                   // :592-593
+                double vp[3];
+                eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
+                if (vp[2] < 0) { vp[0] = -vp[0]; vp[1] = -vp[1]; vp[2] = -vp[2]; }   // :599-600
+                o[0] = vp[0]; o[1] = vp[1]; o[2] = vp[2]; o[3] = 1.0;
+            }
+        }
+    }
+    block_sync();
+    if (tid() == 0) {
+        double* v0 = sh.dbuf;
+        double* v1 = sh.dbuf + 4;
+        bool too_similar = true;                              // :604-615
+        if (v0[3] != 0.0 && v1[3] != 0.0) {
+            double cphi = clip(v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2], -1.0, 1.0);
+            double ang = fabs(acos(clip(fabs(cphi), -1.0, 1.0)));
+            if (ang > c.prm.merge_thresh) too_similar = false;
+        }
+        if (!too_similar) {                                   // :617-628 (both clusters valid here)
+            sh.cur[3 * worst] = v0[0]; sh.cur[3 * worst + 1] = v0[1]; sh.cur[3 * worst + 2] = v0[2];
+            sh.s[worst] = stdd;
+            if (sh.M < MAXM) {
+                int m = sh.M;
+                sh.cur[3 * m] = v1[0]; sh.cur[3 * m + 1] = v1[1]; sh.cur[3 * m + 2] = v1[2];
+                sh.nxt[3 * m] = 0; sh.nxt[3 * m + 1] = 0; sh.nxt[3 * m + 2] = 0;
+                sh.s[m] = stdd;
+                sh.M = m + 1;
+            } else {
+                sh.flags |= VPK_EM_FLAG_VP_OVERFLOW;
+            }
+        }
+    }
+    block_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// outputs
+// ---------------------------------------------------------------------------------------------
+struct EmOut {
+    double* vp;       // max_vp x 3
+    double* sigma;    // max_vp
+    double* counts;   // max_vp
+    double* counts_w; // max_vp
+    int* num_vp;
+    long long* assoc; // N
+    int* iterations;
+    int* status;
+    unsigned* flags;
+    double* metric;   // N x max_vp or null
+    double* trace;    // num_iter x 4 or null
+    int max_vp;
+};
+
+VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
+    Shared& sh = *c.sh;
+    const int N = c.N;
+    int M = status == VPK_EM_OK ? sh.M : 0;
+    if (M > o.max_vp) {
+        M = o.max_vp;
+        if (tid() == 0) sh.flags |= VPK_EM_FLAG_VP_OVERFLOW;
+    }
+    for (int m = tid(); m < o.max_vp; m += nthreads()) {
+        bool ok = m < M;
+        for (int d = 0; d < 3; ++d) o.vp[3 * m + d] = ok ? sh.nxt[3 * m + d] : 0.0;
+        o.sigma[m] = ok ? sh.s[m] : 0.0;
+        o.counts[m] = ok ? sh.cnt[m] : 0.0;
+        o.counts_w[m] = ok ? sh.cntw[m] : 0.0;
+    }
+    for (int n = tid(); n < N; n += nthreads()) {
+        int a = status == VPK_EM_OK ? c.assoc[n] : -1;
+        o.assoc[n] = (a >= M) ? -1 : a;
+        if (o.metric)
+            for (int m = 0; m < o.max_vp; ++m)
+                o.metric[(size_t)n * o.max_vp + m] = m < M ? c.w[(size_t)m * c.ldn + n] : 0.0;
+    }
+    block_sync();
+    if (tid() == 0) {
+        *o.num_vp = M;
+        *o.iterations = iterations;
+        *o.status = status;
+        *o.flags = sh.flags;
+    }
+    block_sync();
+}
+
+VPK_DEV void trace_put(EmOut& o, int i, int slot, double v) {
+    if (o.trace && tid() == 0) o.trace[4 * i + slot] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the driver: expectation_maximisation (vp_localisation.py:168-450)
+// ---------------------------------------------------------------------------------------------
+VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
+    Shared& sh = *c.sh;
+    const vpk_em_params& P = c.prm;
+    const double max_stdd = 1e-6;                             // :196-198 ("angle")
+    const double merge_thresh_final = P.merge_thresh * 10;    // :190
+    const int split_merge_it = 100;                           // :193
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; }
+    block_sync();
+    if (o.trace)
+        for (int q = tid(); q < 4 * P.num_iter; q += nthreads()) o.trace[q] = 0.0;
+    if (c.N <= 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }
+
+    if (P.use_weights) pairwise_setup(c, true);               // :177-178 (+ :230 kNN score)
+    else pairwise_setup(c, false);                            // only lines_angles is needed
+    normalise_lines(c);                                       // :185-186, :226
+    initial_vps(c);                                           // :208
+    const int m_found = sh.M;
+    prior_setup(c);                                           // :210
+    if (m_found == 0) { write_result(c, o, VPK_EM_NO_INITIAL_VP, 0); return; }   // ValueError at :165
+    if (c.init_vp) {                                          // :212-215
+        if (tid() == 0) {
+            int m = c.n_init < MAXM ? c.n_init : MAXM;
+            for (int k = 0; k < m; ++k) {
+                const double* q = c.init_vp + 3 * (size_t)k;
+                double nr = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                sh.cur[3 * k] = q[0] / nr; sh.cur[3 * k + 1] = q[1] / nr; sh.cur[3 * k + 2] = q[2] / nr;
+            }
+            sh.M = m;
+        }
+        block_sync();
+    }
+    weights_setup(c);                                         // :227-235
+    for (int m = tid(); m < MAXM; m += nthreads()) {
+        sh.s[m] = 1.0 * (sh.sigma_prior * 1e-6);              // :219,:239
+        sh.nxt[3 * m] = 0; sh.nxt[3 * m + 1] = 0; sh.nxt[3 * m + 2] = 0;
+    }
+    block_sync();
+
+    estep(c, sh.cur);                                         // :245
+    smooth(c);                                                // :246
+    assign_lines(c, true);                                    // :247
+    count_lines(c);
+    for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = sh.cnt[m] < 3;   // :250-251
+    block_sync();
+    compact_vps(c);
+
+    for (int i = 0; i < P.num_iter; ++i) {
+        if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }             // :258-260
+        double events = 0;
+        if (i % P.split_merge_freq == 0 && i > 0 && i < split_merge_it && P.do_split) {   // :262-269
+            int mb = sh.M;
+            estep(c, sh.cur);
+            smooth(c);
+            split_vp(c);
+            if (sh.M != mb) events += 1;
+        }
+        estep(c, sh.cur);                                     // :273
+        smooth(c);                                            // :282
+        double max_err = 0.0;
+        if (P.do_iterations) {
+            mstep(c, 0, max_stdd);                            // :284-322
+            max_err = max_err_of(sh, sh.M);
+            block_sync();
+            compact_vps(c);                                   // :329-331
+        } else {
+            for (int q = tid(); q < 3 * sh.M; q += nthreads()) sh.nxt[q] = sh.cur[q];   // :324-325
+            block_sync();
+        }
+        trace_put(o, i, 0, (double)sh.M);
+        trace_put(o, i, 1, max_err);
+        // (:332 recomputes and discards an E-step; its only side effect, the floor of s at
+        //  1e-200, cannot change s after the clamp at :307)
+
+        if (max_err < P.final_convergence || i == P.num_iter - 1 || !P.do_iterations) {   // :335
+            if (P.do_merge) merge_vps(c, true, merge_thresh_final);                       // :339
+            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, i); return; }   // reference: argmax of empty (:349)
+            estep(c, sh.cur);                                 // :344 (stale index i)
+            smooth(c);                                        // :346
+            assign_lines(c, false);                           // :349
+            mstep(c, 1, max_stdd);                            // :353-392
+            compact_vps(c);                                   // :394-396
+            estep(c, sh.cur);                                 // :398 (still index i)
+            smooth(c);                                        // :400
+            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }               // :402-404
+            assign_lines(c, false);                           // :406
+            for (int m = tid(); m < sh.M; m += nthreads()) sh.icnt[m] = 0;
+            block_sync();
+            for (int n = tid(); n < c.N; n += nthreads()) sh.icnt[c.assoc[n]] = 1;        // np.unique (:408)
+            block_sync();
+            for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = !sh.icnt[m];
+            block_sync();
+            compact_vps(c);                                   // :412-413
+            estep(c, sh.nxt);                                 // :415 (index i+1 at last)
+            smooth(c);                                        // :417
+            assign_lines(c, true);                            // :418
+            count_lines(c);
+            for (int guard = 0; guard < MAXM + 1; ++guard) {  // :423-437
+                int vidx = -1;
+                for (int m = 0; m < sh.M; ++m)
+                    if (sh.cnt[m] < P.num_min_lines) { vidx = m; break; }
+                block_sync();
+                if (vidx < 0) break;
+                for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = (m == vidx);
+                block_sync();
+                compact_vps(c);
+                estep(c, sh.nxt);
+                smooth(c);
+                assign_lines(c, true);
+                count_lines(c);
+            }
+            trace_put(o, i, 2, (double)sh.M);
+            trace_put(o, i, 3, events + 2);
+            write_result(c, o, VPK_EM_OK, i);                 // :439-442
+            return;
+        }
+        if (i % P.split_merge_freq == 0 && i > 0 && i <= split_merge_it + P.split_merge_freq && P.do_merge) {
+            int mb = sh.M;
+            merge_vps(c, true, P.merge_thresh);               // :444-448
+            if (sh.M != mb) events += 4;
+        }
+        trace_put(o, i, 2, (double)sh.M);
+        trace_put(o, i, 3, events);
+        for (int q = tid(); q < 3 * MAXM; q += nthreads()) {  // v[i+1] becomes v[i]; v[i+2] is zeros
+            sh.cur[q] = sh.nxt[q];
+            sh.nxt[q] = 0.0;
+        }
+        block_sync();
+    }
+    write_result(c, o, VPK_EM_NO_VP, 0);                      // :450
+}
+
+}  // namespace vpk
+#endif

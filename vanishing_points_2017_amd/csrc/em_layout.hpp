@@ -1,0 +1,64 @@
+// em_layout.hpp -- per-slot HBM scratch layout of the EM workgroup (host + device).
+//
+// One "slot" = the private working set of one image while its workgroup runs.  Sized for the
+// largest image of the batch; with 288 GB of HBM3E a few thousand slots of N = 1000 fit at once.
+//   lsim   N x ld   fp64   (the dominant stream: read once per E-step)
+//   lvsq / pvl / w  mcap x ldn fp64 ([vp][line]: lines contiguous -> coalesced per-line threads)
+//   wsrc   N x mcap fp64   ([line][vp]: VPs contiguous -> wave-uniform broadcast in the smoother)
+#ifndef VPK_EM_LAYOUT_HPP_
+#define VPK_EM_LAYOUT_HPP_
+
+#include <stddef.h>
+
+namespace vpk {
+
+struct EmLayout {
+    int ldn, ld, mcap, nwaves;
+    size_t lsim, den, lweight, langle, lscore, lvsq, pvl, w, wsrc, drow, cl, assoc, idx;
+    size_t total_doubles;
+};
+
+inline size_t em_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int em_mcap(int num_init_vp, int n_init, bool has_init, bool do_split, int num_iter, int freq,
+                   int maxm) {
+    int m0 = has_init ? n_init : num_init_vp;
+    int splits = 0;
+    if (do_split && freq > 0) {
+        splits = (num_iter - 1) / freq;
+        if (splits > 9) splits = 9;          // split only for 0 < i < 100 (vp_localisation.py:262)
+        if (splits < 0) splits = 0;
+    }
+    int m = m0 + splits;
+    if (m > maxm) m = maxm;
+    if (m < 1) m = 1;
+    return (int)em_align((size_t)m, 8);
+}
+
+inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool do_split) {
+    EmLayout L;
+    L.ldn = (int)em_align((size_t)(nmax > 0 ? nmax : 1), 8);
+    L.ld = L.ldn;
+    L.mcap = mcap;
+    L.nwaves = nwaves;
+    size_t o = 0;
+    const size_t n = (size_t)L.ldn;
+    L.lsim = o;    o += use_weights ? n * n : 8;
+    L.den = o;     o += n;
+    L.lweight = o; o += n;
+    L.langle = o;  o += n;
+    L.lscore = o;  o += n;
+    L.lvsq = o;    o += (size_t)mcap * n;
+    L.pvl = o;     o += (size_t)mcap * n;
+    L.w = o;       o += (size_t)mcap * n;
+    L.wsrc = o;    o += n * (size_t)mcap;
+    L.drow = o;    o += (size_t)nwaves * n;
+    L.cl = o;      o += do_split ? n * n : 8;
+    L.assoc = o;   o += em_align(n, 2) / 2;            // n ints
+    L.idx = o;     o += em_align(3 * n, 2) / 2;        // 3n ints
+    L.total_doubles = em_align(o, 32);                 // 256-byte aligned slots
+    return L;
+}
+
+}  // namespace vpk
+#endif

@@ -1,0 +1,401 @@
+// vpk_em.hip -- EM kernels and their C-ABI entry points (see include/vpk.h).
+//
+// Compiled with -ffp-contract=off (see em_device.hpp).  One persistent workgroup of EM_THREADS
+// threads per slot; workgroups pull images from a device-side queue (largest N first), so a
+// ragged batch keeps every CU busy without host round trips.
+#include "em_device.hpp"
+#include "vpk_internal.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+using namespace vpk;
+
+namespace {
+
+constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD, up to 3 workgroups per CU by LDS
+constexpr int EM_WAVES = EM_THREADS / 64;
+
+struct EmBatchArgs {
+    int B;
+    const long long* offsets;   // device, B+1
+    const int* order;           // device, B (image indices, largest first)
+    int* queue;                 // device counter
+    double* l;
+    const double* lp;
+    const float* cnn;
+    const unsigned char* sphere;
+    int ssize;
+    const double* init_vp;
+    int n_init;
+    vpk_em_params prm;
+    EmLayout L;
+    double* scratch;
+    int max_vp;
+    double* vp_out;
+    double* sigma_out;
+    double* counts_out;
+    double* counts_w_out;
+    int* num_vp_out;
+    long long* assoc_out;
+    int* iterations_out;
+    int* status_out;
+    unsigned* flags_out;
+    double* metric_out;
+    double* trace_out;
+};
+
+__global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
+    __shared__ Shared sh;
+    for (;;) {
+        if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
+        block_sync();
+        const int q = sh.ibuf[7];
+        block_sync();
+        if (q >= a.B) break;
+        const int img = a.order[q];
+        const long long off = a.offsets[img];
+        EmCtx c;
+        c.N = (int)(a.offsets[img + 1] - off);
+        c.l = a.l + 3 * off;
+        c.lp = a.lp + 4 * off;
+        c.cnn = a.cnn + (size_t)img * NCELL;
+        c.sphere = a.sphere + (size_t)img * a.ssize * a.ssize;
+        c.ssize = a.ssize;
+        c.init_vp = a.init_vp ? a.init_vp + (size_t)img * a.n_init * 3 : nullptr;
+        c.n_init = a.n_init;
+        c.prm = a.prm;
+        c.sh = &sh;
+        bind_scratch(c, a.scratch + (size_t)block_id() * a.L.total_doubles, a.L, a.prm.do_split != 0);
+        EmOut o;
+        o.max_vp = a.max_vp;
+        o.vp = a.vp_out + (size_t)img * a.max_vp * 3;
+        o.sigma = a.sigma_out + (size_t)img * a.max_vp;
+        o.counts = a.counts_out + (size_t)img * a.max_vp;
+        o.counts_w = a.counts_w_out + (size_t)img * a.max_vp;
+        o.num_vp = a.num_vp_out + img;
+        o.assoc = a.assoc_out + off;
+        o.iterations = a.iterations_out + img;
+        o.status = a.status_out + img;
+        o.flags = a.flags_out + img;
+        o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
+        o.trace = a.trace_out ? a.trace_out + (size_t)img * a.prm.num_iter * 4 : nullptr;
+        em_run(c, o);
+    }
+}
+
+// ---- fine-grained kernels (one workgroup, unit parity) ------------------------------------------
+__global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
+                                                              double* lsim_out, double* lscore_out,
+                                                              double* langle_out) {
+    __shared__ Shared sh;
+    EmCtx c;
+    c.N = n; c.lp = lp; c.sh = &sh;
+    c.prm.use_weights = 1;
+    bind_scratch(c, ws, L, false);
+    pairwise_setup(c, true);
+    for (int p = tid(); p < n * n; p += nthreads()) lsim_out[p] = c.lsim[(size_t)(p / n) * c.ld + p % n];
+    for (int i = tid(); i < n; i += nthreads()) { lscore_out[i] = c.lscore[i]; langle_out[i] = c.langle[i]; }
+}
+
+__global__ __launch_bounds__(EM_THREADS) void init_vps_kernel(const float* cnn, const unsigned char* sphere,
+                                                              int ssize, int num_max, double* v0_out,
+                                                              int* m0_out, float* weights_out) {
+    __shared__ Shared sh;
+    EmCtx c;
+    c.N = 0; c.cnn = cnn; c.sphere = sphere; c.ssize = ssize; c.sh = &sh;
+    c.prm.num_init_vp = num_max;
+    initial_vps(c);
+    for (int k = tid(); k < 3 * sh.M; k += nthreads()) v0_out[k] = sh.cur[k];
+    if (tid() == 0) *m0_out = sh.M;
+    block_sync();
+    prior_setup(c);
+    for (int k = tid(); k < NCELL; k += nthreads()) weights_out[k] = sh.wts[k];
+}
+
+__global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const double* lp, const float* cnn,
+                                                           const double* v, double* s, EmLayout L, double* ws,
+                                                           double* p_v_out, double* lvsq_out, double* p_vl_out,
+                                                           double* p_l_out) {
+    __shared__ Shared sh;
+    EmCtx c;
+    c.N = n; c.lp = lp; c.cnn = cnn; c.sh = &sh;
+    c.prm.use_weights = 1;
+    bind_scratch(c, ws, L, false);
+    prior_setup(c);
+    for (int k = tid(); k < n; k += nthreads()) c.lweight[k] = 1.0;
+    for (int k = tid(); k < 3 * m; k += nthreads()) sh.cur[k] = v[k];
+    for (int k = tid(); k < m; k += nthreads()) sh.s[k] = s[k];
+    if (tid() == 0) sh.M = m;
+    block_sync();
+    estep(c, sh.cur);
+    for (int k = tid(); k < m; k += nthreads()) { s[k] = sh.s[k]; p_v_out[k] = sh.pv[k]; }
+    for (int p = tid(); p < m * n; p += nthreads()) {
+        int k = p / n, q = p % n;
+        lvsq_out[p] = c.lvsq[(size_t)k * c.ldn + q];
+        p_vl_out[p] = c.pvl[(size_t)k * c.ldn + q];
+    }
+    // p_l is not kept by the E-step; re-evaluate sum_m p_lv * p_v with the floor (:116-117)
+    for (int q = tid(); q < n; q += nthreads()) {
+        double pl = 0.0;
+        for (int k = 0; k < m; ++k) {
+            double lv = c.lvsq[(size_t)k * c.ldn + q];
+            pl += exp(-(lv / (2 * sh.s[k]))) * sh.k2[k] * sh.pv[k];
+        }
+        p_l_out[q] = (pl > 1e-12 || pl != pl) ? pl : 1e-12;
+    }
+}
+
+__global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m, const double* p_vl,
+                                                                   const double* lweight, const double* lsim,
+                                                                   double bias, EmLayout L, double* ws,
+                                                                   double* w_out) {
+    __shared__ Shared sh;
+    EmCtx c;
+    c.N = n; c.sh = &sh;
+    c.prm.use_weights = 1;
+    c.prm.wbias = bias;
+    bind_scratch(c, ws, L, false);
+    c.lsim = const_cast<double*>(lsim);   // caller's matrix, row stride n
+    c.ld = n;
+    if (tid() == 0) sh.M = m;
+    for (int i = tid(); i < n; i += nthreads()) c.lweight[i] = lweight[i];
+    for (int p = tid(); p < n * m; p += nthreads()) {
+        int i = p / m, k = p % m;
+        c.wsrc[(size_t)i * c.mcap + k] = p_vl[(size_t)k * n + i] * lweight[i];
+    }
+    block_sync();
+    for (int k = tid(); k < n; k += nthreads()) {
+        double sum = 0.0;
+        for (int j = 0; j < n; ++j) sum += lsim[(size_t)j * n + k];
+        c.den[k] = 1 + bias * c.lweight[k] * sum;
+    }
+    block_sync();
+    smooth(c);
+    for (int p = tid(); p < m * n; p += nthreads()) w_out[p] = c.w[(size_t)(p / n) * c.ldn + p % n];
+}
+
+__global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const double* l, const double* w,
+                                                           EmLayout L, double* ws, double* vp_out,
+                                                           int* valid_out) {
+    __shared__ Shared sh;
+    EmCtx c;
+    c.N = n; c.l = const_cast<double*>(l); c.sh = &sh;
+    c.prm.s_thresh = 1e-200;
+    bind_scratch(c, ws, L, false);
+    if (tid() == 0) sh.M = m;
+    for (int p = tid(); p < m * n; p += nthreads()) {
+        int k = p / n, q = p % n;
+        c.w[(size_t)k * c.ldn + q] = w[p];
+        c.lvsq[(size_t)k * c.ldn + q] = 1.0;
+        c.pvl[(size_t)k * c.ldn + q] = 1.0;
+    }
+    for (int k = tid(); k < 3 * m; k += nthreads()) { sh.cur[k] = (k % 3 == 2) ? 1.0 : 0.0; sh.nxt[k] = 0.0; }
+    block_sync();
+    mstep(c, 0, 1e-6);
+    for (int k = tid(); k < m; k += nthreads()) {
+        // "valid" mirrors calc_new_vanishing_point returning a vector (not None)
+        bool none = sh.removed[k] && sh.err[k] == -1.0 && !(sh.s[k] != sh.s[k]);
+        valid_out[k] = none ? 0 : 1;
+        for (int d = 0; d < 3; ++d) vp_out[3 * k + d] = none ? 0.0 : sh.nxt[3 * k + d];
+    }
+}
+
+__global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, int* member, int* csize,
+                                                              int* labels_out, unsigned* flags_out) {
+    __shared__ Shared sh;
+    if (tid() == 0) sh.flags = 0;
+    block_sync();
+    cluster2(sh, n, D, member, csize);
+    for (int q = tid(); q < n; q += nthreads()) labels_out[q] = member[q];
+    if (tid() == 0) *flags_out = sh.flags;
+}
+
+int em_slots(const vpk_handle* h, int batch, size_t slot_bytes) {
+    int slots = h->num_cu * 2;                       // 2 workgroups of 512 threads per CU
+    if (slots > batch) slots = batch;
+    size_t budget = h->total_mem / 2;                // never claim more than half of HBM
+    while (slots > 1 && (size_t)slots * slot_bytes > budget) slots /= 2;
+    return slots < 1 ? 1 : slots;
+}
+
+int check_params(vpk_handle* h, const vpk_em_params* p, int n_init, bool has_init) {
+    if (!p) return vpk_fail(h, VPK_ERR_ARG, "params is null");
+    if (p->num_iter < 1 || p->num_iter > 100000) return vpk_fail(h, VPK_ERR_ARG, "num_iter out of range");
+    if (p->split_merge_freq < 1) return vpk_fail(h, VPK_ERR_ARG, "split_merge_freq < 1");
+    if (p->num_init_vp < 1 || p->num_init_vp > MAXM) return vpk_fail(h, VPK_ERR_LIMIT, "num_init_vp must be 1..64");
+    if (has_init && (n_init < 1 || n_init > MAXM)) return vpk_fail(h, VPK_ERR_LIMIT, "n_init must be 1..64");
+    return VPK_OK;
+}
+
+EmLayout small_layout(int n, int m) {
+    return em_layout(n, (int)em_align((size_t)(m > 0 ? m : 1), 8), EM_WAVES, true, false);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const vpk_em_params* p, int n_init) {
+    if (!h || !p || batch < 1) return 0;
+    int mcap = em_mcap(p->num_init_vp, n_init, n_init > 0, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
+    EmLayout L = em_layout(n_max, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
+    size_t slot = L.total_doubles * sizeof(double);
+    return (size_t)em_slots(h, batch, slot) * slot;
+}
+
+int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
+                 const float* cnn, const uint8_t* sphere, int sphere_size, const double* init_vp,
+                 int n_init, const vpk_em_params* p, int max_vp, double* vp_out, double* sigma_out,
+                 double* counts_out, double* counts_w_out, int32_t* num_vp_out, int64_t* assoc_out,
+                 int32_t* iterations_out, int32_t* status_out, uint32_t* flags_out,
+                 double* metric_out, double* trace_out) {
+    if (!h) return VPK_ERR_ARG;
+    if (batch < 1 || !offsets || !l || !lp || !cnn || !sphere || !vp_out || !sigma_out || !counts_out ||
+        !counts_w_out || !num_vp_out || !assoc_out || !iterations_out || !status_out || !flags_out)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_em_batch: null buffer or batch < 1");
+    if (sphere_size < GRIDN || max_vp < 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_batch: bad sphere_size/max_vp");
+    int rc = check_params(h, p, n_init, init_vp != nullptr);
+    if (rc) return rc;
+    VPK_HIP(h, hipSetDevice(h->device));
+    long long nmax = 0;
+    for (int b = 0; b < batch; ++b) {
+        long long n = offsets[b + 1] - offsets[b];
+        if (n < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_batch: offsets not monotone");
+        nmax = std::max(nmax, n);
+    }
+    if (nmax > 46000) return vpk_fail(h, VPK_ERR_LIMIT, "vpk_em_batch: more than 46000 lines in one image");
+    const bool has_init = init_vp != nullptr;
+    int mcap = em_mcap(p->num_init_vp, n_init, has_init, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
+    EmLayout L = em_layout((int)nmax, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
+    const size_t slot_bytes = L.total_doubles * sizeof(double);
+    const int slots = em_slots(h, batch, slot_bytes);
+    rc = vpk_reserve(h, &h->em_ws, &h->em_ws_bytes, (size_t)slots * slot_bytes, "hipMalloc(EM workspace)");
+    if (rc) return rc;
+    // header: offsets (B+1 i64) | order (B i32) | queue counter
+    const size_t off_bytes = em_align((size_t)(batch + 1) * 8, 256);
+    const size_t ord_bytes = em_align((size_t)batch * 4, 256);
+    rc = vpk_reserve(h, &h->em_hdr, &h->em_hdr_bytes, off_bytes + ord_bytes + 256, "hipMalloc(EM header)");
+    if (rc) return rc;
+    // the previous batch on this handle may still be reading the header / staging buffers
+    VPK_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->em_hdr_host_bytes < off_bytes + ord_bytes) {
+        if (h->em_hdr_host) VPK_HIP(h, hipHostFree(h->em_hdr_host));
+        h->em_hdr_host = nullptr;
+        h->em_hdr_host_bytes = 0;
+        VPK_HIP(h, hipHostMalloc(&h->em_hdr_host, (off_bytes + ord_bytes) * 2, hipHostMallocDefault));
+        h->em_hdr_host_bytes = (off_bytes + ord_bytes) * 2;
+    }
+    long long* st_off = (long long*)h->em_hdr_host;
+    int* order = (int*)((char*)h->em_hdr_host + off_bytes);
+    for (int b = 0; b <= batch; ++b) st_off[b] = offsets[b];
+    std::iota(order, order + batch, 0);
+    std::stable_sort(order, order + batch, [&](int x, int y) {
+        return (offsets[x + 1] - offsets[x]) > (offsets[y + 1] - offsets[y]);   // largest image first
+    });
+    char* hdr = (char*)h->em_hdr;
+    VPK_HIP(h, hipMemcpyAsync(hdr, h->em_hdr_host, off_bytes + ord_bytes, hipMemcpyHostToDevice, h->stream));
+    VPK_HIP(h, hipMemsetAsync(hdr + off_bytes + ord_bytes, 0, 256, h->stream));
+
+    EmBatchArgs a;
+    a.B = batch;
+    a.offsets = (const long long*)hdr;
+    a.order = (const int*)(hdr + off_bytes);
+    a.queue = (int*)(hdr + off_bytes + ord_bytes);
+    a.l = l; a.lp = lp; a.cnn = cnn; a.sphere = sphere; a.ssize = sphere_size;
+    a.init_vp = init_vp; a.n_init = n_init;
+    a.prm = *p;
+    a.L = L;
+    a.scratch = (double*)h->em_ws;
+    a.max_vp = max_vp;
+    a.vp_out = vp_out; a.sigma_out = sigma_out; a.counts_out = counts_out; a.counts_w_out = counts_w_out;
+    a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
+    a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), 0, h->stream, a);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_pairwise(vpk_handle* h, int n, const double* lp, double* lsim_out, double* lscore_out,
+                 double* langle_out) {
+    if (!h || n < 1 || !lp || !lsim_out || !lscore_out || !langle_out) return vpk_fail(h, VPK_ERR_ARG, "vpk_pairwise: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    EmLayout L = small_layout(n, 8);
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(pairwise_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, lp, L, (double*)h->small_ws,
+                       lsim_out, lscore_out, langle_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_init_vps(vpk_handle* h, const float* cnn, const uint8_t* sphere, int sphere_size, int num_max,
+                 double* v0_out, int32_t* m0_out, float* weights_out) {
+    if (!h || !cnn || !sphere || !v0_out || !m0_out || !weights_out || num_max < 1 || num_max > MAXM ||
+        sphere_size < GRIDN)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_init_vps: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(init_vps_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, cnn, sphere, sphere_size, num_max,
+                       v0_out, m0_out, weights_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_estep(vpk_handle* h, int n, int m, const double* lp, const float* cnn, const double* v, double* s,
+              double* p_v_out, double* lvsq_out, double* p_vl_out, double* p_l_out) {
+    if (!h || n < 1 || m < 1 || m > MAXM || !lp || !cnn || !v || !s || !p_v_out || !lvsq_out || !p_vl_out || !p_l_out)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_estep: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    EmLayout L = small_layout(n, m);
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(estep_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, lp, cnn, v, s, L,
+                       (double*)h->small_ws, p_v_out, lvsq_out, p_vl_out, p_l_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const double* lweight,
+                      const double* lsim, double bias, double* w_out) {
+    if (!h || n < 1 || m < 1 || m > MAXM || !p_vl || !lweight || !lsim || !w_out)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_weight_matrix: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, false, false);
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, p_vl, lweight, lsim,
+                       bias, L, (double*)h->small_ws, w_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, double* vp_out, int32_t* valid_out) {
+    if (!h || n < 1 || m < 1 || m > MAXM || !l || !w || !vp_out || !valid_out)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_mstep: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, false, false);
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mstep_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, l, w, L, (double*)h->small_ws,
+                       vp_out, valid_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out, uint32_t* flags_out) {
+    if (!h || n < 3 || !ldist || !labels_out || !flags_out) return vpk_fail(h, VPK_ERR_ARG, "vpk_cluster2: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    size_t need = (size_t)n * n * 8 + (size_t)2 * n * 4 + 64;
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, need, "hipMalloc(workspace)");
+    if (rc) return rc;
+    double* D = (double*)h->small_ws;
+    int* member = (int*)(D + (size_t)n * n);
+    VPK_HIP(h, hipMemcpyAsync(D, ldist, (size_t)n * n * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(cluster2_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, D, member, member + n,
+                       labels_out, flags_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+}  // extern "C"

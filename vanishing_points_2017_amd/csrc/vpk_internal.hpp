@@ -1,0 +1,45 @@
+// vpk_internal.hpp -- host-side state shared by the translation units of libvpk.so
+#ifndef VPK_INTERNAL_HPP_
+#define VPK_INTERNAL_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/vpk.h"
+
+struct vpk_cnn_state;   // vpk_cnn.hip
+
+struct vpk_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int num_cu = 0;
+    int lds_per_block = 0;
+    int arch = 0;
+    size_t total_mem = 0;
+    // EM workspace (grown on demand, never shrunk)
+    void* em_ws = nullptr;
+    size_t em_ws_bytes = 0;
+    void* em_hdr = nullptr;   // offsets + order + queue counter
+    size_t em_hdr_bytes = 0;
+    void* em_hdr_host = nullptr;   // pinned staging for the header
+    size_t em_hdr_host_bytes = 0;
+    void* small_ws = nullptr; // fine-grained entry points
+    size_t small_ws_bytes = 0;
+    vpk_cnn_state* cnn = nullptr;
+};
+
+int vpk_fail(vpk_handle* h, int code, const char* what);
+int vpk_fail_hip(vpk_handle* h, hipError_t e, const char* what);
+int vpk_reserve(vpk_handle* h, void** p, size_t* have, size_t want, const char* what);
+void vpk_cnn_free(vpk_handle* h);
+
+#define VPK_HIP(h, call)                                         \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return vpk_fail_hip(h, e_, #call); \
+    } while (0)
+
+#endif
