@@ -121,8 +121,10 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
  * outputs (device): vp_out B x max_vp x 3, sigma_out / counts_out / counts_w_out B x max_vp,
  *   num_vp_out B, assoc_out sum(N) int64 (-1 = outlier), iterations_out B, status_out B
  *   (vpk_em_status), flags_out B (VPK_EM_FLAG_*), metric_out NULL or sum(N) x max_vp fp64
- *   (decision_metric, [line][vp]), trace_out NULL or B x num_iter x 4 fp64
- *   (per iteration: M after the M-step, max_err, M after merge, event bits). */
+ *   (decision_metric, [line][vp]), trace_out NULL or B x (num_iter+1) x 8 fp64
+ *   (row i: M after the M-step, max_err, M at the end of the iteration, event bits, then device
+ *   microseconds spent in E-step / smoothing / M-step / whole iteration; row num_iter: microseconds
+ *   of pairwise setup, remaining setup, whole image). */
 int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
                  const float* cnn, const uint8_t* sphere, int sphere_size, const double* init_vp,
                  int n_init, const vpk_em_params* p, int max_vp, double* vp_out, double* sigma_out,

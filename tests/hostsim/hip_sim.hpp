@@ -38,6 +38,11 @@ VPK_DEV int wave_max_int(int v) { return v; }
 VPK_DEV void wave_argmin(double&, int&) {}
 VPK_DEV double wave_bcast(double v, int) { return v; }
 VPK_DEV int wave_bcast_int(int v, int) { return v; }
+template <int C> VPK_DEV void load_cols(const double* p, double (&out)[C]) {
+    for (int q = 0; q < C; ++q) out[q] = p[q];
+}
+VPK_DEV long long clock_ticks() { return 0; }
+constexpr double CLOCK_US = 0.01;
 VPK_DEV int atomic_add_int(int* p, int v) { int o = *p; *p += v; return o; }
 VPK_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 

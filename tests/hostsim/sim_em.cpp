@@ -8,6 +8,7 @@
 using namespace vpk;
 
 static Shared g_sh;
+static double g_wt[WT_DOUBLES];
 
 static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_params& p, bool has_init,
                      int n_init) {
@@ -18,6 +19,7 @@ static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_par
     c.N = n;
     c.prm = p;
     c.sh = &g_sh;
+    c.wt = g_wt;
     bind_scratch(c, buf.data(), L, p.do_split != 0);
 }
 
@@ -119,6 +121,7 @@ int sim_weight_matrix(int n, int m, const double* p_vl, const double* lweight, c
         double sum = 0;
         for (int j = 0; j < n; ++j) sum += c.lsim[(size_t)j * c.ld + k];
         c.den[k] = 1 + bias * c.lweight[k] * sum;
+        for (int q = m; q < c.mcap; ++q) c.wsrc[(size_t)k * c.mcap + q] = 0.0;
     }
     smooth(c);
     for (int k = 0; k < m; ++k)

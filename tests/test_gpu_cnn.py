@@ -1,0 +1,45 @@
+"""HIP AlexNet-500 forward vs the torch-CPU fp32 restatement (oracle/cnn_torch.py), seeded
+synthetic weights.  Tolerance (fp32 parity mode): per-layer max abs error <= 2e-4 * (1 + max|ref|),
+final 20x20 sigmoid map <= 2e-5 abs.  Different fp32 summation orders (MFMA k-order vs MKL-DNN)
+are the only source of difference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net_and_ref():
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, synth
+    w = cnn.synthetic_weights(3)
+    mean = cnn.synthetic_mean(3)
+    scenes = [synth.make_scene(7000 + i, 150 + 40 * i, 3) for i in range(3)]
+    sphere = np.stack([s["sphere_image"] for s in scenes])
+    ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
+    net = cnn.Net(w, mean)
+    return net, sphere, ref, taps
+
+
+@pytest.mark.parametrize("tap", list(range(11)))
+def test_layer_outputs(net_and_ref, tap):
+    from oracle import cnn_torch
+    net, sphere, ref, taps = net_and_ref
+    out, got = net.forward(sphere, tap=tap)
+    want = taps[cnn_torch.TAPS[tap]].reshape(got.shape)
+    scale = 1.0 + np.abs(want).max()
+    err = np.abs(got - want).max()
+    assert err <= 2e-4 * scale, (cnn_torch.TAPS[tap], err, scale)
+    assert np.abs(out - ref).max() <= 2e-5
+
+
+def test_batch_invariance_and_single_image_call(net_and_ref):
+    from vanishing_points_2017_amd import cnn
+    net, sphere, ref, _ = net_and_ref
+    full = net.forward(sphere)
+    assert np.abs(full - ref).max() <= 2e-5
+    one = cnn.caffe_forward(net, sphere[1])
+    assert one.shape == (20, 20) and one.dtype == np.float32
+    assert np.abs(one - full[1]).max() <= 1e-6        # batch composition does not change a result
+    big = net.forward(np.concatenate([sphere] * 5)[:13])
+    assert np.array_equal(big[:3], full)              # deterministic: same bits for the same image

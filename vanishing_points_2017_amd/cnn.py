@@ -1,0 +1,91 @@
+"""AlexNet-500 forward on the GPU (C-ABI: vpk_cnn_load / vpk_cnn_forward) behind the reference's
+evaluation.py CNN surface: init_caffe (:17), read_mean_blob (:25), caffe_forward (:34)."""
+import ctypes
+
+import numpy as np
+
+from .runtime import get_runtime
+
+# (name, weight shape in Caffe layout, fan-in) per cnn/deploy.prototxt
+LAYER_SHAPES = [
+    ("conv1", (96, 1, 11, 11)), ("conv2", (256, 48, 5, 5)), ("conv3", (384, 256, 3, 3)),
+    ("conv4", (384, 192, 3, 3)), ("conv5", (256, 192, 3, 3)), ("fc6", (4096, 57600)),
+    ("fc7", (4096, 4096)), ("fc8", (400, 4096)),
+]
+TAP_SHAPES = [(96, 123, 123), (96, 61, 61), (256, 61, 61), (256, 30, 30), (384, 30, 30), (384, 30, 30),
+              (256, 30, 30), (256, 15, 15), (4096,), (4096,), (400,)]
+
+
+def synthetic_weights(seed=0, scale=1.0):
+    """Seeded random-init weights of the deploy architecture (the trained caffemodel is a download
+    the offline build cannot reach).  He-style std = sqrt(2 / fan_in) keeps activations O(1)
+    through the 8 layers so that numerics tests are meaningful; biases as train_val.prototxt."""
+    rs = np.random.RandomState(seed)
+    bias_val = {"conv1": 0.0, "conv2": 0.1, "conv3": 0.0, "conv4": 0.1, "conv5": 0.1, "fc6": 0.1, "fc7": 0.1,
+                "fc8": 0.0}
+    out = {}
+    for name, shape in LAYER_SHAPES:
+        fan_in = int(np.prod(shape[1:]))
+        std = scale * np.sqrt(2.0 / fan_in)
+        if name == "conv1":
+            std /= 40.0          # input is raw 0..255 grey minus mean (no scaling, evaluation.py:35)
+        w = rs.standard_normal(size=shape).astype(np.float32)
+        w *= np.float32(std)
+        out[name] = (w, np.full((shape[0],), bias_val[name], dtype=np.float32))
+    return out
+
+
+def synthetic_mean(seed=0):
+    rs = np.random.RandomState(seed + 1)
+    return (12.0 + 4.0 * rs.random_sample((500, 500))).astype(np.float32)
+
+
+class Net(object):
+    """Counterpart of caffe.Net(model_def, model_weights, caffe.TEST) for this one topology."""
+
+    def __init__(self, weights, mean, device=0):
+        self.rt = get_runtime(device)
+        blobs = []
+        keep = []
+        for name, shape in LAYER_SHAPES:
+            w, b = weights[name]
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            if w.shape != shape or b.shape != (shape[0],):
+                raise ValueError("%s: expected weight %s / bias (%d,), got %s / %s" % (name, shape, shape[0], w.shape, b.shape))
+            keep += [w, b]
+            blobs += [w.ctypes.data, b.ctypes.data]
+        mean = np.ascontiguousarray(np.asarray(mean, dtype=np.float32).reshape(500, 500))
+        arr = (ctypes.c_void_p * 16)(*blobs)
+        self.rt.check(self.rt.lib.vpk_cnn_load(self.rt.h, arr, ctypes.c_void_p(mean.ctypes.data)))
+
+    def forward_device(self, sphere, tap=None):
+        """sphere: uint8 device tensor (B,500,500) -> float32 device tensor (B,20,20) [, tap tensor]."""
+        rt = self.rt
+        t = rt.torch
+        batch = int(sphere.shape[0])
+        with rt.on_stream():
+            out = t.empty((batch, 20, 20), dtype=t.float32, device=rt.tdev)
+            if tap is None:
+                rt.check(rt.lib.vpk_cnn_forward(rt.h, rt.ptr(sphere), batch, rt.ptr(out)))
+                return out
+            tp = t.empty((batch,) + TAP_SHAPES[tap], dtype=t.float32, device=rt.tdev)
+            rt.check(rt.lib.vpk_cnn_forward_tap(rt.h, rt.ptr(sphere), batch, rt.ptr(out), int(tap), rt.ptr(tp)))
+            return out, tp
+
+    def forward(self, sphere_u8, tap=None):
+        rt = self.rt
+        sphere_u8 = np.ascontiguousarray(sphere_u8, dtype=np.uint8).reshape(-1, 500, 500)
+        with rt.on_stream():
+            d = rt.torch.from_numpy(sphere_u8).to(rt.tdev)
+        res = self.forward_device(d, tap)
+        rt.synchronize()
+        if tap is None:
+            return res.cpu().numpy()
+        return res[0].cpu().numpy(), res[1].cpu().numpy()
+
+
+def caffe_forward(net, image, mean_arr=None):
+    """evaluation.py:34-38: one 500x500 uint8 raster -> (20,20) float32.  The mean blob was bound
+    at load time (it is fused into conv1's input load); mean_arr is accepted for signature parity."""
+    return net.forward(np.asarray(image)[None])[0]

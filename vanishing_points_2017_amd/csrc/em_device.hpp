@@ -28,8 +28,10 @@ constexpr int GRIDN = 20;           // CNN output grid (cnn/deploy.prototxt:283-
 constexpr int NCELL = GRIDN * GRIDN;
 constexpr int MAXCOMP = 100;        // prior keeps the 100 strongest cells (probability_functions.py:87)
 constexpr int MT = 8;               // VP tile of the smoothing kernel (accumulators per column)
-constexpr int PART_DOUBLES = 4096;  // LDS partial-sum buffer (32 KiB)
+constexpr int PART_DOUBLES = 2048;  // LDS scratch for the setup phases (16 KiB)
+constexpr int WT_DOUBLES = 6144;    // LDS operand tile of the smoother (48 KiB)
 constexpr int KNN1 = 10;            // line_rating_knn k1 (vp_localisation.py:34,230)
+constexpr int TRACE_COLS = 8;        // trace row: M, max_err, M_end, events, us_estep, us_smooth, us_mstep, us_total
 constexpr int KNN2 = 4;             // k2=4 at the call site (:230)
 constexpr double PI_D = 3.141592653589793238462643383279502884;
 
@@ -85,7 +87,9 @@ struct EmCtx {
     double* cl;       // split: Nw x Nw cluster distances (NULL when do_split == 0)
     int* assoc;       // N
     int* idx;         // N (split: gathered line indices, cluster membership)
+    double* rowsum;   // N : sum_j lsim[j][k]
     Shared* sh;
+    double* wt;       // LDS, WT_DOUBLES: operand tile of the smoother
 };
 
 // point the context's scratch pointers into one slot
@@ -95,6 +99,7 @@ VPK_DEV void bind_scratch(EmCtx& c, double* base, const EmLayout& L, bool do_spl
     c.langle = base + L.langle; c.lscore = base + L.lscore; c.lvsq = base + L.lvsq;
     c.pvl = base + L.pvl; c.w = base + L.w; c.wsrc = base + L.wsrc; c.drow = base + L.drow;
     c.cl = do_split ? base + L.cl : nullptr;
+    c.rowsum = base + L.rowsum;
     c.assoc = (int*)(base + L.assoc);
     c.idx = (int*)(base + L.idx);
 }
@@ -269,16 +274,21 @@ VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
         double a[4] = {c.lp[4 * (size_t)i], c.lp[4 * (size_t)i + 1], c.lp[4 * (size_t)i + 2],
                        c.lp[4 * (size_t)i + 3]};
         const double len_a = line_length(a);
+        double rsum = 0.0;
         for (int j = lane(); j < N; j += WAVE) {
             double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2],
                            c.lp[4 * (size_t)j + 3]};
             double d = line_distance_closest(a, b);
             if (want_lsim) {
                 double sim = lines_cosangle(a, b, 9.0) * proximity(d, len_a, line_length(b), 1.0);
-                c.lsim[(size_t)i * c.ld + j] = (i == j) ? 0.0 : sim;
+                sim = (i == j) ? 0.0 : sim;
+                c.lsim[(size_t)i * c.ld + j] = sim;
+                rsum += sim;
             }
             drow[j] = (i == j) ? 4.0 : d;  // :82
         }
+        rsum = wave_sum(rsum);                    // lsim is symmetric: row sum == column sum (:522)
+        if (lane() == 0) c.rowsum[i] = rsum;
         wave_sync();
         // k1 nearest by k1 rounds of lexicographic (distance, index) selection
         double last_d = -1.0;
@@ -342,12 +352,8 @@ VPK_DEVFN void weights_setup(EmCtx& c) {
         c.lweight[n] = uw ? line_length(a) * clip(c.lscore[n], 0.2, 1.0) : 1.0;
     }
     block_sync();
-    for (int k = tid(); k < N; k += nthreads()) {
-        double sum = 0.0;
-        if (uw)
-            for (int j = 0; j < N; ++j) sum += c.lsim[(size_t)j * c.ld + k];
-        c.den[k] = 1 + c.prm.wbias * c.lweight[k] * sum;
-    }
+    for (int k = tid(); k < N; k += nthreads())
+        c.den[k] = 1 + c.prm.wbias * c.lweight[k] * (uw ? c.rowsum[k] : 0.0);
     block_sync();
 }
 
@@ -566,6 +572,7 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
             c.pvl[(size_t)m * c.ldn + n] = pvl;
             ws[m] = pvl * lw;                                // weight_matrix :519
         }
+        for (int m = M; m < ((M + MT - 1) / MT) * MT; ++m) ws[m] = 0.0;   // padding of the last VP tile
     }
     block_sync();
 }
@@ -574,67 +581,106 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
 // smoothing: weight_matrix (vp_localisation.py:515-524), the (M x N) . (N x N) product
 // ---------------------------------------------------------------------------------------------
 // w[m][k] = (w_[m][k] + bias*lweight[k] * sum_j w_[m][j] lsim[j][k]) / den[k].
-// Each thread owns one column k (lanes -> consecutive k: coalesced lsim rows) and MT VP
-// accumulators; when N is small the j range is sliced across thread groups and combined
-// through LDS.  w_ is read as wsrc[j][m..m+MT) -- a wave-uniform (broadcast) address.
-VPK_DEVFN void smooth(EmCtx& c) {
+// Work decomposition: an output block = (64*C consecutive columns) x (MT VPs); every wave owns
+// whole blocks and walks ALL rows j for them, so no cross-wave reduction is needed and the result
+// is deterministic.  A lane holds C adjacent columns (C = 2: one 16-byte load per row, a wave reads
+// 1 KiB of contiguous lsim per row) and MT accumulators per column; rows are unrolled UNR deep so
+// UNR independent loads are in flight per lane (HBM latency is hidden by bytes in flight, not by
+// occupancy).  The w_ operand (wsrc[j][m]) is staged through LDS in row chunks and read as a
+// wave-uniform broadcast.
+template <int C, int UNR>
+VPK_DEVFN void smooth_blocks(EmCtx& c) {
     Shared& sh = *c.sh;
-    const int M = sh.M, N = c.N, nt = nthreads();
-    if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl
-        for (int m = 0; m < M; ++m)
-            for (int k = tid(); k < N; k += nt) c.w[(size_t)m * c.ldn + k] = c.wsrc[(size_t)k * c.mcap + m];
-        block_sync();
-        return;
-    }
-    int ncols = ((N + WAVE - 1) / WAVE) * WAVE;
-    if (ncols > nt) ncols = nt;
-    int S = nt / ncols;
-    if (S * MT * ncols > PART_DOUBLES) S = PART_DOUBLES / (MT * ncols);
-    if (S < 1) S = 1;
-    const int col = tid() % ncols, slice = tid() / ncols;
-    const bool active = slice < S;
-    const int jchunk = (N + S - 1) / S;
-    const int j0 = slice * jchunk;
-    const int j1 = (j0 + jchunk) < N ? (j0 + jchunk) : N;
+    const int M = sh.M, N = c.N;
+    const int colw = WAVE * C;
+    const int ncg = (N + colw - 1) / colw;
+    const int ntile = (M + MT - 1) / MT;
+    const int W = ntile * MT;                       // staged VPs per row (<= mcap)
+    const int nblk = ncg * ntile;
+    int JC = WT_DOUBLES / W;                        // rows per LDS chunk
+    if (JC > N) JC = N;
     const double bias = c.prm.wbias;
-    for (int m0 = 0; m0 < M; m0 += MT) {
-        for (int k0 = 0; k0 < N; k0 += ncols) {
-            const int k = k0 + col;
-            double acc[MT];
+    double* wt = c.wt;
+    for (int b0 = 0; b0 < nblk; b0 += nwaves()) {
+        const int b = b0 + wave_id();
+        const bool have = b < nblk;
+        const int cg = have ? b % ncg : 0, tile = have ? b / ncg : 0;
+        const int k = cg * colw + lane() * C;
+        const bool live = have && k < N;
+        double acc[MT][C];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = 0.0;
-            if (active && k < N) {
-                const double* lcol = c.lsim + k;
-                const double* ws = c.wsrc + m0;
-                for (int j = j0; j < j1; ++j) {
-                    double a = lcol[(size_t)j * c.ld];
-                    const double* wj = ws + (size_t)j * c.mcap;
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = fma(wj[t], a, acc[t]);
+            for (int q = 0; q < C; ++q) acc[t][q] = 0.0;
+        for (int jc = 0; jc < N; jc += JC) {
+            const int jn = (N - jc) < JC ? (N - jc) : JC;
+            block_sync();                           // the previous chunk has been consumed
+            for (int p = tid(); p < jn * W; p += nthreads()) {
+                int j = p / W, m = p - j * W;
+                wt[p] = c.wsrc[(size_t)(jc + j) * c.mcap + m];
+            }
+            block_sync();
+            if (live) {
+                const double* lrow = c.lsim + (size_t)jc * c.ld + k;
+                const double* wrow = wt + tile * MT;
+                int j = 0;
+                for (; j + UNR <= jn; j += UNR) {
+                    double a[UNR][C];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) load_cols<C>(lrow + (size_t)(j + u) * c.ld, a[u]);
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            const double wv = wrow[(j + u) * W + t];
+#pragma unroll
+                            for (int q = 0; q < C; ++q) acc[t][q] = fma(wv, a[u][q], acc[t][q]);
+                        }
+                }
+                for (; j < jn; ++j) {
+                    double a1[C];
+                    load_cols<C>(lrow + (size_t)j * c.ld, a1);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const double wv = wrow[j * W + t];
+#pragma unroll
+                        for (int q = 0; q < C; ++q) acc[t][q] = fma(wv, a1[q], acc[t][q]);
+                    }
                 }
             }
-            if (S > 1) {
-                if (active && slice > 0)
+        }
+        if (live) {
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) sh.part[((slice - 1) * MT + t) * ncols + col] = acc[t];
-                block_sync();
-                if (slice == 0)
-                    for (int sl = 1; sl < S; ++sl)
+            for (int q = 0; q < C; ++q) {
+                const int kk = k + q;
+                if (kk < N) {
+                    const double lw = c.lweight[kk], dn = c.den[kk];
 #pragma unroll
-                        for (int t = 0; t < MT; ++t) acc[t] += sh.part[((sl - 1) * MT + t) * ncols + col];
+                    for (int t = 0; t < MT; ++t) {
+                        const int m = tile * MT + t;
+                        if (m < M)
+                            c.w[(size_t)m * c.ldn + kk] =
+                                (c.wsrc[(size_t)kk * c.mcap + m] + bias * lw * acc[t][q]) / dn;
+                    }
+                }
             }
-            if (slice == 0 && k < N) {
-                double lw = c.lweight[k], dn = c.den[k];
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (m0 + t < M)
-                        c.w[(size_t)(m0 + t) * c.ldn + k] =
-                            (c.wsrc[(size_t)k * c.mcap + m0 + t] + bias * lw * acc[t]) / dn;
-            }
-            if (S > 1) block_sync();
         }
     }
     block_sync();
+}
+
+VPK_DEVFN void smooth(EmCtx& c) {
+    Shared& sh = *c.sh;
+    const int M = sh.M, N = c.N;
+    if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl
+        for (int m = 0; m < M; ++m)
+            for (int k = tid(); k < N; k += nthreads()) c.w[(size_t)m * c.ldn + k] = c.wsrc[(size_t)k * c.mcap + m];
+        block_sync();
+        return;
+    }
+    if (M == 0) return;
+    if (N > WAVE) smooth_blocks<2, 8>(c);
+    else smooth_blocks<1, 4>(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1118,7 +1164,17 @@ VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
 }
 
 VPK_DEV void trace_put(EmOut& o, int i, int slot, double v) {
-    if (o.trace && tid() == 0) o.trace[4 * i + slot] = v;
+    if (o.trace && tid() == 0) o.trace[TRACE_COLS * i + slot] = v;
+}
+VPK_DEV void trace_add(EmOut& o, int i, int slot, double v) {
+    if (o.trace && tid() == 0) o.trace[TRACE_COLS * i + slot] += v;
+}
+// phase stopwatch (thread 0, after a barrier): returns microseconds since the previous call
+VPK_DEV double lap(long long& t) {
+    long long now = clock_ticks();
+    double us = (double)(now - t) * CLOCK_US;
+    t = now;
+    return us;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1133,11 +1189,14 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
     if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; }
     block_sync();
     if (o.trace)
-        for (int q = tid(); q < 4 * P.num_iter; q += nthreads()) o.trace[q] = 0.0;
+        for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;
     if (c.N <= 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }
 
+    long long tk = clock_ticks();
+    const long long t_begin = tk;
     if (P.use_weights) pairwise_setup(c, true);               // :177-178 (+ :230 kNN score)
     else pairwise_setup(c, false);                            // only lines_angles is needed
+    trace_put(o, P.num_iter, 0, lap(tk));                     // last trace row: setup timings
     normalise_lines(c);                                       // :185-186, :226
     initial_vps(c);                                           // :208
     const int m_found = sh.M;
@@ -1169,8 +1228,10 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
     for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = sh.cnt[m] < 3;   // :250-251
     block_sync();
     compact_vps(c);
+    trace_put(o, P.num_iter, 1, lap(tk));
 
     for (int i = 0; i < P.num_iter; ++i) {
+        const long long t_iter = tk;
         if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }             // :258-260
         double events = 0;
         if (i % P.split_merge_freq == 0 && i > 0 && i < split_merge_it && P.do_split) {   // :262-269
@@ -1180,11 +1241,15 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             split_vp(c);
             if (sh.M != mb) events += 1;
         }
+        lap(tk);
         estep(c, sh.cur);                                     // :273
+        trace_put(o, i, 4, lap(tk));
         smooth(c);                                            // :282
+        trace_put(o, i, 5, lap(tk));
         double max_err = 0.0;
         if (P.do_iterations) {
             mstep(c, 0, max_stdd);                            // :284-322
+            trace_put(o, i, 6, lap(tk));
             max_err = max_err_of(sh, sh.M);
             block_sync();
             compact_vps(c);                                   // :329-331
@@ -1236,6 +1301,8 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             }
             trace_put(o, i, 2, (double)sh.M);
             trace_put(o, i, 3, events + 2);
+            trace_put(o, i, 7, (double)(clock_ticks() - t_iter) * CLOCK_US);
+            trace_put(o, P.num_iter, 2, (double)(clock_ticks() - t_begin) * CLOCK_US);
             write_result(c, o, VPK_EM_OK, i);                 // :439-442
             return;
         }
@@ -1246,6 +1313,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         }
         trace_put(o, i, 2, (double)sh.M);
         trace_put(o, i, 3, events);
+        trace_put(o, i, 7, (double)(clock_ticks() - t_iter) * CLOCK_US);
         for (int q = tid(); q < 3 * MAXM; q += nthreads()) {  // v[i+1] becomes v[i]; v[i+2] is zeros
             sh.cur[q] = sh.nxt[q];
             sh.nxt[q] = 0.0;

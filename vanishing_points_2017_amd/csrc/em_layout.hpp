@@ -14,7 +14,7 @@ namespace vpk {
 
 struct EmLayout {
     int ldn, ld, mcap, nwaves;
-    size_t lsim, den, lweight, langle, lscore, lvsq, pvl, w, wsrc, drow, cl, assoc, idx;
+    size_t lsim, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, cl, assoc, idx;
     size_t total_doubles;
 };
 
@@ -48,6 +48,7 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.lweight = o; o += n;
     L.langle = o;  o += n;
     L.lscore = o;  o += n;
+    L.rowsum = o;  o += n;
     L.lvsq = o;    o += (size_t)mcap * n;
     L.pvl = o;     o += (size_t)mcap * n;
     L.w = o;       o += (size_t)mcap * n;

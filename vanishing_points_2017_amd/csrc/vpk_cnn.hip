@@ -1,8 +1,476 @@
-// placeholder until the CNN kernels land (next milestone)
+// vpk_cnn.hip -- AlexNet-500 forward (cnn/deploy.prototxt:1-304) as hand-written gfx950 kernels.
+//
+// Caffe conventions reproduced: cross-correlation, OIHW weights, grouped
+// convolution splits input/output channels contiguously, MAX pooling with CEIL output size and
+// border-clipped windows, LRN across channels x * (1 + alpha/n * sum x^2)^-beta, InnerProduct
+// weight (out,in) over the C*H*W-flattened input, Dropout = identity at TEST, input = uint8
+// raster minus the mean blob with no scaling (evaluation.py:34-38).
+//
+// All arithmetic is fp32 ("parity mode"): the convolutions and the fully connected layers run as
+// implicit GEMMs on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32, 157 TF dense peak),
+// tiles staged through LDS (k-major, conflict-free fragment reads), global->register prefetch of
+// tile t+1 issued before the MFMAs of tile t, bias + ReLU fused in the epilogue.  Weights are
+// re-packed once at load time into k-major [K][M] panels so every staging load is a coalesced
+// 16-byte access.  Activations live in HBM for the whole batch (B x 96 x 123 x 123 fp32 is
+// 0.6 GB at B = 102; 288 GB of HBM3E makes chunking unnecessary up to B ~ 4000).
 #include "vpk_internal.hpp"
-void vpk_cnn_free(vpk_handle*) {}
-extern "C" {
-int vpk_cnn_load(vpk_handle* h, const float* const*, const float*) { return vpk_fail(h, VPK_ERR_STATE, "CNN not built yet"); }
-int vpk_cnn_forward(vpk_handle* h, const uint8_t*, int, float*) { return vpk_fail(h, VPK_ERR_STATE, "CNN not built yet"); }
-int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t*, int, float*, int, float*) { return vpk_fail(h, VPK_ERR_STATE, "CNN not built yet"); }
+
+#include <vector>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;          // K depth of one LDS stage
+constexpr int CONV_THREADS = 256;
+
+struct ConvDims {
+    int B, IC, H, W;            // input  (IC = channels per group)
+    int OC, OH, OW;             // output (OC = channels per group)
+    int groups;
+    int K;                      // IC*KH*KW (unpadded)
+    int Kp;                     // K padded to a multiple of BK
+    int Mp;                     // OC padded to a multiple of BM
+    long long N;                // B*OH*OW
+    int ksplit;                 // split-K factor (dense layers); 1 = fused epilogue
+    int relu;
+};
+
+// --------------------------------------------------------------------------------------------
+// implicit-GEMM convolution / dense layer
+//   C[m][n] = sum_k Wp[k][m] * X[k][n],  m = output channel, n = (b, oh, ow), k = (ic, kh, kw)
+// WAVES_M x WAVES_N waves, each owning TM x TN MFMA tiles of 32 x 32.
+// --------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int TM, int TN, int KH, int KW, int STRIDE, int PAD, bool U8IN, bool DENSE>
+__global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, const void* __restrict__ in_,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ wp,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out) {
+    constexpr int BM = WAVES_M * TM * 32;
+    constexpr int BN = WAVES_N * TN * 32;
+    static_assert(WAVES_M * WAVES_N * 64 == CONV_THREADS, "4 waves");
+    static_assert(BN == 128, "the B-tile loader assumes 128 columns");
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int mtiles = d.Mp / BM;
+    // blockIdx.x = ((g * ksplit + ks) * ntiles + nt) * mtiles + mt : m-tile fastest so that the
+    // blocks sharing one im2col panel are launched together
+    int bid = blockIdx.x;
+    const int mt = bid % mtiles; bid /= mtiles;
+    const long long ntiles = (d.N + BN - 1) / BN;
+    const int nt = (int)(bid % ntiles); bid = (int)(bid / ntiles);
+    const int ks = bid % d.ksplit;
+    const int g = bid / d.ksplit;
+
+    const int ksteps_total = d.Kp / BK;
+    const int ksteps_per = (ksteps_total + d.ksplit - 1) / d.ksplit;
+    const int kt0 = ks * ksteps_per;
+    const int kt1 = (kt0 + ksteps_per) < ksteps_total ? (kt0 + ksteps_per) : ksteps_total;
+
+    const float* wpan = wp + (size_t)g * d.Kp * d.Mp + (size_t)mt * BM;   // [Kp][Mp] panel of this group
+
+    // ---- B-tile loader state: this thread always serves column n_local and 8 consecutive k ----
+    const int n_local = tid & 127;
+    const int kset = tid >> 7;                       // 0/1 -> k offsets 0..7 / 8..15 of the stage
+    const long long n = (long long)nt * BN + n_local;
+    const bool n_ok = n < d.N;
+    const int ohw = d.OH * d.OW;
+    int b = 0, oh = 0, ow = 0;
+    if (n_ok) {
+        b = (int)(n / ohw);
+        int r = (int)(n - (long long)b * ohw);
+        oh = r / d.OW;
+        ow = r - oh * d.OW;
+    }
+    const int ih0 = oh * STRIDE - PAD, iw0 = ow * STRIDE - PAD;
+    const size_t in_base = ((size_t)b * d.groups * d.IC + (size_t)g * d.IC) * d.H * d.W;
+    const float* inf = reinterpret_cast<const float*>(in_);
+    const unsigned char* inu = reinterpret_cast<const unsigned char*>(in_);
+
+    float4 a_reg[(BK * BM) / (CONV_THREADS * 4) + 1];
+    float b_reg[8];
+    constexpr int A_F4 = (BK * BM) / 4;              // float4 per A stage
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        // A: k-major panel rows are contiguous in m -> coalesced float4
+#pragma unroll
+        for (int r = 0; r * CONV_THREADS < A_F4; ++r) {
+            int idx = tid + r * CONV_THREADS;
+            if (idx < A_F4) {
+                int kk = (idx * 4) / BM, m = (idx * 4) % BM;
+                a_reg[r] = *reinterpret_cast<const float4*>(wpan + (size_t)(k0 + kk) * d.Mp + m);
+            }
+        }
+        // B: gather
+        if (DENSE) {
+            const float* row = inf + (size_t)n * d.K + k0 + kset * 8;
+            if (n_ok && k0 + kset * 8 + 8 <= d.K) {
+                float4 v0 = *reinterpret_cast<const float4*>(row);
+                float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+                b_reg[0] = v0.x; b_reg[1] = v0.y; b_reg[2] = v0.z; b_reg[3] = v0.w;
+                b_reg[4] = v1.x; b_reg[5] = v1.y; b_reg[6] = v1.z; b_reg[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) b_reg[q] = (n_ok && k0 + kset * 8 + q < d.K) ? row[q] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int k = k0 + kset * 8 + q;
+                int ic = k / (KH * KW);
+                int rem = k - ic * (KH * KW);
+                int kh = rem / KW, kw = rem - kh * KW;
+                int ih = ih0 + kh, iw = iw0 + kw;
+                float v = 0.f;
+                if (n_ok && k < d.K && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
+                    size_t off = in_base + ((size_t)ic * d.H + ih) * d.W + iw;
+                    if (U8IN) v = (float)inu[off] - mean[(size_t)ih * d.W + iw];   // evaluation.py:35
+                    else v = inf[off];
+                }
+                b_reg[q] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r * CONV_THREADS < A_F4; ++r) {
+            int idx = tid + r * CONV_THREADS;
+            if (idx < A_F4) {
+                int kk = (idx * 4) / BM, m = (idx * 4) % BM;
+                *reinterpret_cast<float4*>(&As[buf][kk][m]) = a_reg[r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Bs[buf][kset * 8 + q][n_local] = b_reg[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int arow = wm * TM * 32 + (lane & 31);
+    const int bcol = wn * TN * 32 + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);         // global loads in flight under the MFMAs
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[buf][k2 + khalf][arow + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][k2 + khalf][bcol + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long long nn = (long long)nt * BN + wn * TN * 32 + j * 32 + (lane & 31);
+        if (nn >= d.N) continue;
+        const int bb = (int)(nn / ohw);
+        const int rr = (int)(nn - (long long)bb * ohw);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m >= d.OC) continue;
+                float v = acc[i][j][r];
+                if (d.ksplit == 1) {
+                    v += bias[g * d.OC + m];
+                    if (d.relu) v = v > 0.f ? v : 0.f;
+                    out[((size_t)bb * d.groups * d.OC + (size_t)g * d.OC + m) * ohw + rr] = v;
+                } else {
+                    // split-K partial: [ks][n][m] (deterministic two-pass reduction)
+                    out[((size_t)ks * d.N + nn) * d.OC + m] = v;
+                }
+            }
+        }
+    }
 }
+
+// sum the split-K partials, add bias, activation: act 0 = none, 1 = ReLU, 2 = sigmoid
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int ksplit,
+                                     long long N, int OC, int act, float* __restrict__ out, float* __restrict__ pre) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * OC) return;
+    int m = (int)(idx % OC);
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += part[(size_t)s * N * OC + idx];
+    v += bias[m];
+    if (pre) pre[idx] = v;
+    if (act == 1) v = v > 0.f ? v : 0.f;
+    else if (act == 2) v = 1.f / (1.f + expf(-v));          // Sigmoid layer (deploy.prototxt:298-304)
+    out[idx] = v;
+}
+
+// LRN across channels, local_size 5 (deploy.prototxt:34-44,82-92): one thread per (b, h, w) walks
+// the channels with a 5-deep register window, so every input element is read exactly once and the
+// window sum is a fresh 5-term sum (no running add/subtract drift).
+__global__ void lrn5_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW,
+                            float alpha, float beta) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * HW) return;
+    int b = (int)(idx / HW), p = (int)(idx % HW);
+    const float* x = in + (size_t)b * C * HW + p;
+    float* y = out + (size_t)b * C * HW + p;
+    const float an = alpha / 5.f;
+    float v0 = 0.f, v1 = 0.f;                       // x[c-2], x[c-1]
+    float v2 = x[0];                                // x[c]
+    float v3 = C > 1 ? x[(size_t)HW] : 0.f;         // x[c+1]
+    for (int c = 0; c < C; ++c) {
+        float v4 = (c + 2 < C) ? x[(size_t)(c + 2) * HW] : 0.f;
+        float sum = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4;
+        float scale = 1.f + an * sum;
+        y[(size_t)c * HW] = v2 * powf(scale, -beta);
+        v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+    }
+}
+
+// MAX pooling 3x3 stride 2, Caffe ceil mode with clipped windows (deploy.prototxt:45-55)
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, long long BC, int H, int W,
+                               int PH, int PW, int ksz, int stride) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BC * PH * PW) return;
+    int pw = (int)(idx % PW);
+    int ph = (int)((idx / PW) % PH);
+    long long bc = idx / ((long long)PW * PH);
+    int h0 = ph * stride, w0 = pw * stride;
+    int h1 = h0 + ksz < H ? h0 + ksz : H, w1 = w0 + ksz < W ? w0 + ksz : W;
+    const float* x = in + (size_t)bc * H * W;
+    float m = -3.402823466e38f;
+    for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) { float v = x[(size_t)h * W + w]; m = v > m ? v : m; }
+    out[idx] = m;
+}
+
+// weight re-pack: Caffe [G*OC][K] (K contiguous) -> k-major panels [G][Kp][Mp], zero padded
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int OC, int K,
+                                    int Kp, int Mp) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)G * Kp * Mp) return;
+    int m = (int)(idx % Mp);
+    int k = (int)((idx / Mp) % Kp);
+    int g = (int)(idx / ((long long)Mp * Kp));
+    wp[idx] = (m < OC && k < K) ? w[((size_t)g * OC + m) * K + k] : 0.f;
+}
+
+struct Layer {
+    ConvDims d;
+    float* wp = nullptr;     // packed weights
+    float* bias = nullptr;
+};
+
+int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
+
+}  // namespace
+
+struct vpk_cnn_state {
+    Layer L[8];              // conv1..5, fc6..8
+    float* mean = nullptr;
+    bool loaded = false;
+    // activations (grown on demand)
+    float* act = nullptr;
+    size_t act_bytes = 0;
+    int act_batch = 0;
+};
+
+void vpk_cnn_free(vpk_handle* h) {
+    if (!h->cnn) return;
+    for (auto& l : h->cnn->L) {
+        if (l.wp) (void)hipFree(l.wp);
+        if (l.bias) (void)hipFree(l.bias);
+    }
+    if (h->cnn->mean) (void)hipFree(h->cnn->mean);
+    if (h->cnn->act) (void)hipFree(h->cnn->act);
+    delete h->cnn;
+    h->cnn = nullptr;
+}
+
+namespace {
+
+// static topology of cnn/deploy.prototxt (per-group channel counts)
+struct Topo { int IC, H, W, OC, OH, OW, G, KH, S, P, BM; };
+const Topo TOPO[8] = {
+    {1, 500, 500, 96, 123, 123, 1, 11, 4, 0, 96},     // conv1 (:9-27)
+    {48, 61, 61, 128, 61, 61, 2, 5, 1, 2, 128},       // conv2 (:56-75) group 2
+    {256, 30, 30, 384, 30, 30, 1, 3, 1, 1, 128},      // conv3 (:104-122)
+    {192, 30, 30, 192, 30, 30, 2, 3, 1, 1, 96},       // conv4 (:129-148) group 2
+    {192, 30, 30, 128, 30, 30, 2, 3, 1, 1, 128},      // conv5 (:155-174) group 2
+    {57600, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128},       // fc6 (:192-210)
+    {4096, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128},        // fc7 (:224-242)
+    {4096, 1, 1, 400, 1, 1, 1, 1, 1, 0, 128},         // fc8_20x20 (:257-275)
+};
+const int KSPLIT[8] = {1, 1, 1, 1, 1, 8, 8, 8};
+
+// activation buffer layout (floats per image)
+constexpr size_t A_CONV1 = 96ull * 123 * 123, A_POOL1 = 96ull * 61 * 61;
+constexpr size_t A_CONV2 = 256ull * 61 * 61, A_POOL2 = 256ull * 30 * 30;
+constexpr size_t A_CONV3 = 384ull * 900, A_CONV4 = 384ull * 900, A_CONV5 = 256ull * 900, A_POOL5 = 256ull * 225;
+constexpr size_t A_FC6 = 4096, A_FC7 = 4096, A_FC8 = 400;
+// two ping-pong regions big enough for the largest producer/consumer pair
+constexpr size_t A_BIG = A_CONV1;     // 1.45M floats: the largest blob per image
+
+template <typename KernelT>
+void launch_conv(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const void* in, const float* mean,
+                 const Layer& l, float* out) {
+    long long ntiles = (d.N + 127) / 128;
+    long long blocks = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, mean, l.wp, l.bias, out);
+}
+
+int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
+    vpk_cnn_state* S = h->cnn;
+    // workspace: 2 big ping-pong activation regions + split-K partials
+    const size_t per_img = 2 * A_BIG;
+    const size_t part_floats = 8ull * 4096 * (size_t)batch;
+    size_t need = ((size_t)batch * per_img + part_floats) * sizeof(float);
+    int rc = vpk_reserve(h, (void**)&S->act, &S->act_bytes, need, "hipMalloc(CNN activations)");
+    if (rc) return rc;
+    float* bufA = S->act;
+    float* bufB = S->act + (size_t)batch * A_BIG;
+    float* part = S->act + (size_t)batch * per_img;
+    hipStream_t st = h->stream;
+    auto tapcopy = [&](int id, const float* src, size_t per) -> int {
+        if (tap == id && tap_out)
+            VPK_HIP(h, hipMemcpyAsync(tap_out, src, per * batch * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return VPK_OK;
+    };
+    auto dims = [&](int li) {
+        ConvDims d = S->L[li].d;
+        d.B = batch;
+        d.N = (long long)batch * d.OH * d.OW;
+        return d;
+    };
+    auto ew_blocks = [](long long n) { return (unsigned)((n + 255) / 256); };
+
+    // conv1 + relu1 (fused uint8 - mean load)
+    launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 11, 11, 4, 0, true, false>, dims(0), 96, sphere, S->mean, S->L[0], bufA);
+    if ((rc = tapcopy(0, bufA, A_CONV1))) return rc;
+    // norm1, pool1
+    hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 123 * 123)), dim3(256), 0, st, bufA, bufB, batch, 96, 123 * 123, 1e-4f, 0.75f);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 96 * 61 * 61)), dim3(256), 0, st, bufB, bufA, (long long)batch * 96, 123, 123, 61, 61, 3, 2);
+    if ((rc = tapcopy(1, bufA, A_POOL1))) return rc;
+    // conv2 + relu2
+    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 5, 5, 1, 2, false, false>, dims(1), 128, bufA, nullptr, S->L[1], bufB);
+    if ((rc = tapcopy(2, bufB, A_CONV2))) return rc;
+    hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 61 * 61)), dim3(256), 0, st, bufB, bufA, batch, 256, 61 * 61, 1e-4f, 0.75f);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 900)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 61, 61, 30, 30, 3, 2);
+    if ((rc = tapcopy(3, bufB, A_POOL2))) return rc;
+    // conv3..5
+    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(2), 128, bufB, nullptr, S->L[2], bufA);
+    if ((rc = tapcopy(4, bufA, A_CONV3))) return rc;
+    launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 3, 3, 1, 1, false, false>, dims(3), 96, bufA, nullptr, S->L[3], bufB);
+    if ((rc = tapcopy(5, bufB, A_CONV4))) return rc;
+    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(4), 128, bufB, nullptr, S->L[4], bufA);
+    if ((rc = tapcopy(6, bufA, A_CONV5))) return rc;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 30, 30, 15, 15, 3, 2);
+    if ((rc = tapcopy(7, bufB, A_POOL5))) return rc;
+    // fc6 / fc7 / fc8: split-K partials + deterministic reduction (+ bias, ReLU / sigmoid)
+    float* fc_in = bufB;
+    float* fc_out = bufA;
+    for (int li = 5; li < 8; ++li) {
+        ConvDims d = dims(li);
+        launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 1, 1, 1, 0, false, true>, d, 128, fc_in, nullptr, S->L[li], part);
+        const long long tot = d.N * d.OC;
+        float* dst = li == 7 ? out : fc_out;
+        float* pre = (li == 7 && tap == 10) ? tap_out : nullptr;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, part, S->L[li].bias, d.ksplit,
+                           d.N, d.OC, li == 7 ? 2 : 1, dst, pre);
+        if (li == 5 && (rc = tapcopy(8, fc_out, A_FC6))) return rc;
+        if (li == 6 && (rc = tapcopy(9, fc_out, A_FC7))) return rc;
+        float* t = fc_in; fc_in = fc_out; fc_out = t;
+    }
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean) {
+    if (!h || !blobs || !mean) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_load: null argument");
+    for (int i = 0; i < 16; ++i)
+        if (!blobs[i]) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_load: null blob");
+    VPK_HIP(h, hipSetDevice(h->device));
+    vpk_cnn_free(h);
+    h->cnn = new vpk_cnn_state();
+    vpk_cnn_state* S = h->cnn;
+    VPK_HIP(h, hipMalloc((void**)&S->mean, 500 * 500 * sizeof(float)));
+    VPK_HIP(h, hipMemcpy(S->mean, mean, 500 * 500 * sizeof(float), hipMemcpyHostToDevice));
+    for (int li = 0; li < 8; ++li) {
+        const Topo& t = TOPO[li];
+        Layer& l = S->L[li];
+        ConvDims& d = l.d;
+        d.B = 0; d.IC = t.IC; d.H = t.H; d.W = t.W; d.OC = t.OC; d.OH = t.OH; d.OW = t.OW; d.groups = t.G;
+        d.K = t.IC * t.KH * t.KH;
+        d.Kp = (d.K + BK - 1) / BK * BK;
+        d.Mp = (t.OC + t.BM - 1) / t.BM * t.BM;
+        d.N = 0;
+        d.ksplit = KSPLIT[li];
+        d.relu = 1;
+        const size_t w_floats = (size_t)t.G * t.OC * d.K;
+        const size_t p_floats = (size_t)t.G * d.Kp * d.Mp;
+        float* raw = nullptr;
+        VPK_HIP(h, hipMalloc((void**)&raw, w_floats * sizeof(float)));
+        VPK_HIP(h, hipMemcpy(raw, blobs[2 * li], w_floats * sizeof(float), hipMemcpyHostToDevice));
+        VPK_HIP(h, hipMalloc((void**)&l.wp, p_floats * sizeof(float)));
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((p_floats + 255) / 256)), dim3(256), 0, h->stream, raw,
+                           l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
+        VPK_HIP(h, hipStreamSynchronize(h->stream));
+        VPK_HIP(h, hipFree(raw));
+        VPK_HIP(h, hipMalloc((void**)&l.bias, (size_t)t.G * t.OC * sizeof(float)));
+        VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
+    }
+    S->loaded = true;
+    return VPK_OK;
+}
+
+int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
+    if (!h || !sphere || !out || batch < 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_forward: bad argument");
+    if (!h->cnn || !h->cnn->loaded) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_forward before vpk_cnn_load");
+    VPK_HIP(h, hipSetDevice(h->device));
+    // activations for the whole batch stay in HBM; chunk only if they would exceed a third of it
+    const size_t per_img = (2 * A_BIG + 8ull * 4096) * sizeof(float);
+    int chunk = (int)std::min<size_t>((size_t)batch, std::max<size_t>(1, (h->total_mem / 3) / per_img));
+    static const size_t tap_size[11] = {A_CONV1, A_POOL1, A_CONV2, A_POOL2, A_CONV3, A_CONV4, A_CONV5, A_POOL5,
+                                        A_FC6, A_FC7, A_FC8};
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        int nb = std::min(chunk, batch - b0);
+        float* tp = (tap_out && tap >= 0 && tap <= 10) ? tap_out + (size_t)b0 * tap_size[tap] : nullptr;
+        int rc = run_forward(h, sphere + (size_t)b0 * 500 * 500, nb, out + (size_t)b0 * 400, tp ? tap : -1, tp);
+        if (rc) return rc;
+    }
+    return VPK_OK;
+}
+
+int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out) {
+    return vpk_cnn_forward_tap(h, sphere, batch, out, -1, nullptr);
+}
+
+}  // extern "C"

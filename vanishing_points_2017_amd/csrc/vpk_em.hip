@@ -16,6 +16,12 @@ namespace {
 
 constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD, up to 3 workgroups per CU by LDS
 constexpr int EM_WAVES = EM_THREADS / 64;
+// dynamic LDS: [Shared | smoother operand tile]; ~77 KiB -> two workgroups per CU (160 KiB)
+constexpr size_t SH_BYTES = (sizeof(Shared) + 15) / 16 * 16;
+constexpr size_t EM_LDS_BYTES = SH_BYTES + WT_DOUBLES * sizeof(double);
+extern __shared__ __attribute__((aligned(16))) unsigned char vpk_smem[];
+#define VPK_SHARED_DECL Shared& sh = *reinterpret_cast<Shared*>(vpk_smem)
+#define VPK_WT (reinterpret_cast<double*>(vpk_smem + SH_BYTES))
 
 struct EmBatchArgs {
     int B;
@@ -47,7 +53,7 @@ struct EmBatchArgs {
 };
 
 __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     for (;;) {
         if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
         block_sync();
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
         c.init_vp = a.init_vp ? a.init_vp + (size_t)img * a.n_init * 3 : nullptr;
         c.n_init = a.n_init;
         c.prm = a.prm;
-        c.sh = &sh;
+        c.sh = &sh; c.wt = VPK_WT;
         bind_scratch(c, a.scratch + (size_t)block_id() * a.L.total_doubles, a.L, a.prm.do_split != 0);
         EmOut o;
         o.max_vp = a.max_vp;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
         o.status = a.status_out + img;
         o.flags = a.flags_out + img;
         o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
-        o.trace = a.trace_out ? a.trace_out + (size_t)img * a.prm.num_iter * 4 : nullptr;
+        o.trace = a.trace_out ? a.trace_out + (size_t)img * (a.prm.num_iter + 1) * TRACE_COLS : nullptr;
         em_run(c, o);
     }
 }
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
 __global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
                                                               double* lsim_out, double* lscore_out,
                                                               double* langle_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.lp = lp; c.sh = &sh;
+    c.N = n; c.lp = lp; c.sh = &sh; c.wt = VPK_WT;
     c.prm.use_weights = 1;
     bind_scratch(c, ws, L, false);
     pairwise_setup(c, true);
@@ -102,9 +108,9 @@ __global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const doubl
 __global__ __launch_bounds__(EM_THREADS) void init_vps_kernel(const float* cnn, const unsigned char* sphere,
                                                               int ssize, int num_max, double* v0_out,
                                                               int* m0_out, float* weights_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     EmCtx c;
-    c.N = 0; c.cnn = cnn; c.sphere = sphere; c.ssize = ssize; c.sh = &sh;
+    c.N = 0; c.cnn = cnn; c.sphere = sphere; c.ssize = ssize; c.sh = &sh; c.wt = VPK_WT;
     c.prm.num_init_vp = num_max;
     initial_vps(c);
     for (int k = tid(); k < 3 * sh.M; k += nthreads()) v0_out[k] = sh.cur[k];
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const d
                                                            const double* v, double* s, EmLayout L, double* ws,
                                                            double* p_v_out, double* lvsq_out, double* p_vl_out,
                                                            double* p_l_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.lp = lp; c.cnn = cnn; c.sh = &sh;
+    c.N = n; c.lp = lp; c.cnn = cnn; c.sh = &sh; c.wt = VPK_WT;
     c.prm.use_weights = 1;
     bind_scratch(c, ws, L, false);
     prior_setup(c);
@@ -151,19 +157,19 @@ __global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m,
                                                                    const double* lweight, const double* lsim,
                                                                    double bias, EmLayout L, double* ws,
                                                                    double* w_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.sh = &sh;
+    c.N = n; c.sh = &sh; c.wt = VPK_WT;
     c.prm.use_weights = 1;
     c.prm.wbias = bias;
     bind_scratch(c, ws, L, false);
-    c.lsim = const_cast<double*>(lsim);   // caller's matrix, row stride n
-    c.ld = n;
+    for (int p = tid(); p < n * n; p += nthreads())      // caller's matrix (row stride n) -> padded rows
+        c.lsim[(size_t)(p / n) * c.ld + p % n] = lsim[p];
     if (tid() == 0) sh.M = m;
     for (int i = tid(); i < n; i += nthreads()) c.lweight[i] = lweight[i];
-    for (int p = tid(); p < n * m; p += nthreads()) {
-        int i = p / m, k = p % m;
-        c.wsrc[(size_t)i * c.mcap + k] = p_vl[(size_t)k * n + i] * lweight[i];
+    for (int p = tid(); p < n * c.mcap; p += nthreads()) {
+        int i = p / c.mcap, k = p % c.mcap;
+        c.wsrc[(size_t)i * c.mcap + k] = k < m ? p_vl[(size_t)k * n + i] * lweight[i] : 0.0;
     }
     block_sync();
     for (int k = tid(); k < n; k += nthreads()) {
@@ -179,9 +185,9 @@ __global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m,
 __global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const double* l, const double* w,
                                                            EmLayout L, double* ws, double* vp_out,
                                                            int* valid_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.l = const_cast<double*>(l); c.sh = &sh;
+    c.N = n; c.l = const_cast<double*>(l); c.sh = &sh; c.wt = VPK_WT;
     c.prm.s_thresh = 1e-200;
     bind_scratch(c, ws, L, false);
     if (tid() == 0) sh.M = m;
@@ -204,12 +210,32 @@ __global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const d
 
 __global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, int* member, int* csize,
                                                               int* labels_out, unsigned* flags_out) {
-    __shared__ Shared sh;
+    VPK_SHARED_DECL;
     if (tid() == 0) sh.flags = 0;
     block_sync();
     cluster2(sh, n, D, member, csize);
     for (int q = tid(); q < n; q += nthreads()) labels_out[q] = member[q];
     if (tid() == 0) *flags_out = sh.flags;
+}
+
+template <typename K>
+int allow_lds(vpk_handle* h, K kernel) {
+    VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EM_LDS_BYTES));
+    return VPK_OK;
+}
+int em_prepare(vpk_handle* h) {
+    if (h->em_ready) return VPK_OK;
+    int rc;
+    if ((rc = allow_lds(h, em_batch_kernel))) return rc;
+    if ((rc = allow_lds(h, pairwise_kernel))) return rc;
+    if ((rc = allow_lds(h, init_vps_kernel))) return rc;
+    if ((rc = allow_lds(h, estep_kernel))) return rc;
+    if ((rc = allow_lds(h, weight_matrix_kernel))) return rc;
+    if ((rc = allow_lds(h, mstep_kernel))) return rc;
+    if ((rc = allow_lds(h, cluster2_kernel))) return rc;
+    h->em_ready = true;
+    return VPK_OK;
 }
 
 int em_slots(const vpk_handle* h, int batch, size_t slot_bytes) {
@@ -259,6 +285,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     int rc = check_params(h, p, n_init, init_vp != nullptr);
     if (rc) return rc;
     VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
     long long nmax = 0;
     for (int b = 0; b < batch; ++b) {
         long long n = offsets[b + 1] - offsets[b];
@@ -312,7 +339,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.vp_out = vp_out; a.sigma_out = sigma_out; a.counts_out = counts_out; a.counts_w_out = counts_w_out;
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), 0, h->stream, a);
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, a);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
@@ -321,10 +348,11 @@ int vpk_pairwise(vpk_handle* h, int n, const double* lp, double* lsim_out, doubl
                  double* langle_out) {
     if (!h || n < 1 || !lp || !lsim_out || !lscore_out || !langle_out) return vpk_fail(h, VPK_ERR_ARG, "vpk_pairwise: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
     EmLayout L = small_layout(n, 8);
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
-    hipLaunchKernelGGL(pairwise_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, lp, L, (double*)h->small_ws,
+    hipLaunchKernelGGL(pairwise_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, lp, L, (double*)h->small_ws,
                        lsim_out, lscore_out, langle_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
@@ -336,7 +364,8 @@ int vpk_init_vps(vpk_handle* h, const float* cnn, const uint8_t* sphere, int sph
         sphere_size < GRIDN)
         return vpk_fail(h, VPK_ERR_ARG, "vpk_init_vps: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(init_vps_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, cnn, sphere, sphere_size, num_max,
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
+    hipLaunchKernelGGL(init_vps_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, cnn, sphere, sphere_size, num_max,
                        v0_out, m0_out, weights_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
@@ -347,10 +376,11 @@ int vpk_estep(vpk_handle* h, int n, int m, const double* lp, const float* cnn, c
     if (!h || n < 1 || m < 1 || m > MAXM || !lp || !cnn || !v || !s || !p_v_out || !lvsq_out || !p_vl_out || !p_l_out)
         return vpk_fail(h, VPK_ERR_ARG, "vpk_estep: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
     EmLayout L = small_layout(n, m);
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
-    hipLaunchKernelGGL(estep_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, lp, cnn, v, s, L,
+    hipLaunchKernelGGL(estep_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, lp, cnn, v, s, L,
                        (double*)h->small_ws, p_v_out, lvsq_out, p_vl_out, p_l_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
@@ -361,10 +391,11 @@ int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const dou
     if (!h || n < 1 || m < 1 || m > MAXM || !p_vl || !lweight || !lsim || !w_out)
         return vpk_fail(h, VPK_ERR_ARG, "vpk_weight_matrix: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
-    EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, false, false);
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
+    EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, true, false);
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
-    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, p_vl, lweight, lsim,
+    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, p_vl, lweight, lsim,
                        bias, L, (double*)h->small_ws, w_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
@@ -374,10 +405,11 @@ int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, dou
     if (!h || n < 1 || m < 1 || m > MAXM || !l || !w || !vp_out || !valid_out)
         return vpk_fail(h, VPK_ERR_ARG, "vpk_mstep: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
     EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, false, false);
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
-    hipLaunchKernelGGL(mstep_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, m, l, w, L, (double*)h->small_ws,
+    hipLaunchKernelGGL(mstep_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, l, w, L, (double*)h->small_ws,
                        vp_out, valid_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
@@ -386,13 +418,14 @@ int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, dou
 int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out, uint32_t* flags_out) {
     if (!h || n < 3 || !ldist || !labels_out || !flags_out) return vpk_fail(h, VPK_ERR_ARG, "vpk_cluster2: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
     size_t need = (size_t)n * n * 8 + (size_t)2 * n * 4 + 64;
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, need, "hipMalloc(workspace)");
     if (rc) return rc;
     double* D = (double*)h->small_ws;
     int* member = (int*)(D + (size_t)n * n);
     VPK_HIP(h, hipMemcpyAsync(D, ldist, (size_t)n * n * 8, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(cluster2_kernel, dim3(1), dim3(EM_THREADS), 0, h->stream, n, D, member, member + n,
+    hipLaunchKernelGGL(cluster2_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, D, member, member + n,
                        labels_out, flags_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;

@@ -75,6 +75,19 @@ VPK_DEV void wave_argmin(double& v, int& idx) {
 VPK_DEV double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
 VPK_DEV int wave_bcast_int(int v, int src_lane) { return __shfl(v, src_lane); }
 
+// C adjacent doubles as one load: 16-byte global_load_dwordx4 when C == 2 (p must be 16-byte aligned)
+template <int C> VPK_DEV void load_cols(const double* p, double (&out)[C]);
+template <> VPK_DEV void load_cols<1>(const double* p, double (&out)[1]) { out[0] = p[0]; }
+template <> VPK_DEV void load_cols<2>(const double* p, double (&out)[2]) {
+    const double2 v = *reinterpret_cast<const double2*>(p);
+    out[0] = v.x;
+    out[1] = v.y;
+}
+
+// constant-rate (100 MHz) device clock for the optional phase timing in the EM trace
+VPK_DEV long long clock_ticks() { return (long long)wall_clock64(); }
+constexpr double CLOCK_US = 0.01;
+
 VPK_DEV int atomic_add_int(int* p, int v) { return atomicAdd(p, v); }
 VPK_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { return atomicOr(p, v); }
 
