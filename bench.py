@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s through the vanishing-point hot path (CNN forward -> EM refinement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload yud|stress]
+
+One "step" = one pass of the hot path over one batch of synthetic images whose inputs (sphere
+rasters, line segments) are already resident in HBM: AlexNet-500 forward on the B x 500 x 500
+uint8 rasters -> 20 x 20 response maps -> EM refinement of every image (the CNN's own output is
+the EM's prior).  Default workload = BASELINE.json configs[1]: YUD-shape, 102 images per GPU,
+N ~ U{100..400} lines, 3 VPs (seeded synthetic; random-init weights: the datasets and the trained
+caffemodel are not reachable offline).
+
+N > 1: launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`;
+images shard across ranks (weak scaling: 102 images per rank), no data-path collective, one RCCL
+all_gather of the fixed-size result records per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
+    ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="images timed on the CPU (default 6 yud / 1 stress)")
+    return ap.parse_args()
+
+
+def make_workload(kind, rank, count):
+    from vanishing_points_2017_amd import synth
+    if kind == "yud":
+        scenes = list(synth.config_scenes(2, count=count, start=rank * count))
+        kw = {}
+    else:
+        distinct = min(count, 16)
+        base = []
+        for i in range(distinct):
+            s = synth.make_scene(5000 + 16 * rank + i, 1000, 8)
+            s["init_vp"] = synth.stress_init_vps(5000 + 16 * rank + i)
+            base.append(s)
+        scenes = [base[i % distinct] for i in range(count)]
+        kw = dict(num_iter=50, do_split=False, do_merge=False, final_convergence=-1)
+    return scenes, kw
+
+
+def cpu_baseline(scenes, kw, weights, mean, sample):
+    """The oracle (numpy EM port + torch-CPU CNN restatement) timed on this host's cores on a
+    bounded sample of the same workload.  Reported beside the GPU number, never the target."""
+    import torch
+    from oracle import cnn_torch, em_numpy
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sub = scenes[:sample]
+    t0 = time.time()
+    sphere = np.stack([s["sphere_image"] for s in sub])
+    resp = cnn_torch.forward(weights, mean, sphere)
+    for s, r in zip(sub, resp):
+        try:
+            em_numpy.expectation_maximisation(s["l"].copy(), s["lp"].copy(), r.copy(), sphere_image=s["sphere_image"],
+                                              init_vp=s.get("init_vp"), **kw)
+        except ValueError:
+            pass
+    dt = time.time() - t0
+    return {"value": len(sub) / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images of the same workload (torch-CPU fp32 CNN + vectorised numpy EM oracle), %.1f s"
+                      % (len(sub), dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+
+    from vanishing_points_2017_amd import cnn, em as gem
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(local_rank)
+    count = args.images or (102 if args.workload == "yud" else 512)
+    scenes, kw = make_workload(args.workload, rank, count)
+    weights = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    net = cnn.Net(weights, mean, device=local_rank)
+    net.set_profiling(True)
+    params = gem._params(kw)
+    d = gem.upload_batch(rt, scenes)                     # inputs resident in HBM before the timed region
+    l_pristine = d["l"].clone()
+    n_lines = np.diff(d["offsets"])
+    max_vp = 64
+
+    def step():
+        with rt.on_stream():
+            d["l"].copy_(l_pristine)                     # EM normalises l in place; restore the input
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            resp = net.forward_device(d["sphere"])       # B x 20 x 20 fp32
+            e[1].record()
+            out = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], resp.reshape(-1, 400), d["sphere"],
+                                      d["init_vp"], params, max_vp=max_vp)
+            e[2].record()
+            if dist is not None:                         # the one collective: gather the result records
+                rec = torch.cat([out["num_vp"].to(torch.float64).unsqueeze(1),
+                                 out["vp"].reshape(count, -1)[:, :60], out["counts"][:, :20]], 1)
+                gathered = [torch.empty_like(rec) for _ in range(world)]
+                dist.all_gather(gathered, rec)
+        return e, out
+
+    def sync_all():
+        if dist is not None:
+            with rt.on_stream():
+                dist.barrier()
+        rt.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(args.steps):
+        e, out = step()
+        evs.append(e)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    layer_ms = net.last_layer_ms()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rt.tdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    cnn_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    em_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    iters = out["iterations"].cpu().numpy()
+    status = out["status"].cpu().numpy()
+    nvp = out["num_vp"].cpu().numpy()
+
+    if rank == 0:
+        total_images = count * world * args.steps
+        value = total_images / elapsed
+        # ---- roofline of the dominant kernel (live HIP-event timings from this run) ----
+        if em_ms >= cnn_ms or args.workload == "stress":
+            # EM batch kernel (one launch per step): algorithmic bytes B_EM of SURVEY 8d,
+            # 8 N^2 (I+1) + I (64 N + 16 M N) per image with I = E-step evaluations
+            m_avg = np.maximum(nvp, 1)
+            evals = iters + 1 + 5                       # loop E-steps + initial + finalisation (>= 4) + slack 1
+            b_em = float(np.sum(8.0 * n_lines ** 2 * (evals + 1) + evals * (64.0 * n_lines + 16.0 * m_avg * n_lines)))
+            roof = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        else:
+            name = max(cnn.Net.LAYER_FLOP, key=lambda k: layer_ms[k])
+            flop = cnn.Net.LAYER_FLOP[name] * count
+            roof = {"kernel": "conv_gemm_kernel(%s)" % name, "bound": "mfma",
+                    "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "traffic": None}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        line = {
+            "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (CNN, MFMA) + f64 (EM)",
+            "data": "synthetic (seeded YUD-shape line sets and rasters; random-init AlexNet-500 weights)",
+            "config": {"workload": "configs[1] YUD-shape: %d images/GPU, N~U{100..400} lines, 3 VPs, CNN+EM"
+                                   % count if args.workload == "yud" else
+                                   "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
+                       "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
+            "stage_ms": {"cnn": cnn_ms, "em": em_ms},
+            "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
+            "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
+                         "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample or (6 if args.workload == "yud" else 1)
+            line["cpu_baseline"] = cpu_baseline(scenes, kw, weights, mean, sample)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

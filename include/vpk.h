@@ -101,6 +101,12 @@ int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out)
 int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap,
                         float* tap_out);
 
+/* per-layer device time of the last vpk_cnn_forward (single chunk), from HIP events recorded on
+ * the handle's stream between the layers: ms[13] = conv1, norm1, pool1, conv2, norm2, pool2, conv3,
+ * conv4, conv5, pool5, fc6, fc7, fc8.  vpk_cnn_last_layer_ms waits for the pass to finish. */
+int vpk_cnn_set_profiling(vpk_handle* h, int on);
+int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
+
 /* ---- sphere rasteriser (sphere_mapping.py:36-72) ----------------------------------------------- */
 /* replaces: get_sphere_image / sphere_line_plot (evaluation.py:12-14).  l: sum(N) x 3 fp64
  * homogeneous lines, offsets [host]: B+1 int64 prefix of line counts; out: B x size x size uint8,

@@ -73,6 +73,21 @@ class Net(object):
             rt.check(rt.lib.vpk_cnn_forward_tap(rt.h, rt.ptr(sphere), batch, rt.ptr(out), int(tap), rt.ptr(tp)))
             return out, tp
 
+    LAYER_NAMES = ["conv1", "norm1", "pool1", "conv2", "norm2", "pool2", "conv3", "conv4", "conv5", "pool5",
+                   "fc6", "fc7", "fc8"]
+    # 2*MAC per image of the MFMA layers, for roofline accounting
+    LAYER_FLOP = {"conv1": 2 * 96 * 15129 * 121, "conv2": 2 * 256 * 3721 * 1200, "conv3": 2 * 384 * 900 * 2304,
+                  "conv4": 2 * 384 * 900 * 1728, "conv5": 2 * 256 * 900 * 1728, "fc6": 2 * 57600 * 4096,
+                  "fc7": 2 * 4096 * 4096, "fc8": 2 * 4096 * 400}
+
+    def set_profiling(self, on=True):
+        self.rt.check(self.rt.lib.vpk_cnn_set_profiling(self.rt.h, int(bool(on))))
+
+    def last_layer_ms(self):
+        ms = (ctypes.c_float * 13)()
+        self.rt.check(self.rt.lib.vpk_cnn_last_layer_ms(self.rt.h, ms))
+        return dict(zip(self.LAYER_NAMES, [float(x) for x in ms]))
+
     def forward(self, sphere_u8, tap=None):
         rt = self.rt
         sphere_u8 = np.ascontiguousarray(sphere_u8, dtype=np.uint8).reshape(-1, 500, 500)

@@ -297,6 +297,11 @@ struct vpk_cnn_state {
     float* act = nullptr;
     size_t act_bytes = 0;
     int act_batch = 0;
+    // optional per-layer timing (HIP events on the handle's stream)
+    bool profiling = false;
+    hipEvent_t ev[14] = {};
+    bool ev_ready = false;
+    bool ev_valid = false;
 };
 
 void vpk_cnn_free(vpk_handle* h) {
@@ -307,6 +312,8 @@ void vpk_cnn_free(vpk_handle* h) {
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
+    if (h->cnn->ev_ready)
+        for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
     delete h->cnn;
     h->cnn = nullptr;
 }
@@ -367,28 +374,43 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         return d;
     };
     auto ew_blocks = [](long long n) { return (unsigned)((n + 255) / 256); };
+    int evi = 0;
+    auto mark = [&]() {
+        if (S->profiling && evi < 14) (void)hipEventRecord(S->ev[evi++], st);
+    };
+    mark();
 
     // conv1 + relu1 (fused uint8 - mean load)
     launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 11, 11, 4, 0, true, false>, dims(0), 96, sphere, S->mean, S->L[0], bufA);
+    mark();
     if ((rc = tapcopy(0, bufA, A_CONV1))) return rc;
     // norm1, pool1
     hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 123 * 123)), dim3(256), 0, st, bufA, bufB, batch, 96, 123 * 123, 1e-4f, 0.75f);
+    mark();
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 96 * 61 * 61)), dim3(256), 0, st, bufB, bufA, (long long)batch * 96, 123, 123, 61, 61, 3, 2);
+    mark();
     if ((rc = tapcopy(1, bufA, A_POOL1))) return rc;
     // conv2 + relu2
     launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 5, 5, 1, 2, false, false>, dims(1), 128, bufA, nullptr, S->L[1], bufB);
+    mark();
     if ((rc = tapcopy(2, bufB, A_CONV2))) return rc;
     hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 61 * 61)), dim3(256), 0, st, bufB, bufA, batch, 256, 61 * 61, 1e-4f, 0.75f);
+    mark();
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 900)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 61, 61, 30, 30, 3, 2);
+    mark();
     if ((rc = tapcopy(3, bufB, A_POOL2))) return rc;
     // conv3..5
     launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(2), 128, bufB, nullptr, S->L[2], bufA);
+    mark();
     if ((rc = tapcopy(4, bufA, A_CONV3))) return rc;
     launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 3, 3, 1, 1, false, false>, dims(3), 96, bufA, nullptr, S->L[3], bufB);
+    mark();
     if ((rc = tapcopy(5, bufB, A_CONV4))) return rc;
     launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(4), 128, bufB, nullptr, S->L[4], bufA);
+    mark();
     if ((rc = tapcopy(6, bufA, A_CONV5))) return rc;
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 30, 30, 15, 15, 3, 2);
+    mark();
     if ((rc = tapcopy(7, bufB, A_POOL5))) return rc;
     // fc6 / fc7 / fc8: split-K partials + deterministic reduction (+ bias, ReLU / sigmoid)
     float* fc_in = bufB;
@@ -401,10 +423,12 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         float* pre = (li == 7 && tap == 10) ? tap_out : nullptr;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, part, S->L[li].bias, d.ksplit,
                            d.N, d.OC, li == 7 ? 2 : 1, dst, pre);
+        mark();
         if (li == 5 && (rc = tapcopy(8, fc_out, A_FC6))) return rc;
         if (li == 6 && (rc = tapcopy(9, fc_out, A_FC7))) return rc;
         float* t = fc_in; fc_in = fc_out; fc_out = t;
     }
+    if (S->profiling) S->ev_valid = (evi == 14);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
@@ -412,6 +436,26 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
 }  // namespace
 
 extern "C" {
+
+int vpk_cnn_set_profiling(vpk_handle* h, int on) {
+    if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_profiling before vpk_cnn_load");
+    VPK_HIP(h, hipSetDevice(h->device));
+    if (on && !h->cnn->ev_ready) {
+        for (auto& e : h->cnn->ev) VPK_HIP(h, hipEventCreate(&e));
+        h->cnn->ev_ready = true;
+    }
+    h->cnn->profiling = on != 0;
+    h->cnn->ev_valid = false;
+    return VPK_OK;
+}
+
+int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]) {
+    if (!h || !ms || !h->cnn) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_last_layer_ms: bad argument");
+    if (!h->cnn->ev_valid) return vpk_fail(h, VPK_ERR_STATE, "no profiled forward pass recorded");
+    VPK_HIP(h, hipEventSynchronize(h->cnn->ev[13]));
+    for (int i = 0; i < 13; ++i) VPK_HIP(h, hipEventElapsedTime(&ms[i], h->cnn->ev[i], h->cnn->ev[i + 1]));
+    return VPK_OK;
+}
 
 int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean) {
     if (!h || !blobs || !mean) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_load: null argument");
