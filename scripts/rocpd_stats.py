@@ -1,0 +1,34 @@
+"""Summarise a rocprofv3 rocpd SQLite database into a per-kernel stats CSV (name, calls,
+total/avg/min/max duration in microseconds, percentage) -- the same content as
+`rocprofv3 --stats` kernel_stats.csv."""
+import csv
+import sqlite3
+import sys
+
+
+def main(db, out):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    disp = [t for t in tables if t.startswith("rocpd_kernel_dispatch")][0]
+    sym = [t for t in tables if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in cur.execute("pragma table_info(%s)" % disp)]
+    scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
+    name_col = "kernel_name" if "kernel_name" in scols else "display_name"
+    q = ("select s.%s, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), "
+         "max(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s order by 3 desc"
+         % (name_col, disp, sym, name_col))
+    rows = list(cur.execute(q))
+    total = sum(r[2] for r in rows) or 1
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "MinUs", "MaxUs", "Percentage"])
+        for r in rows:
+            w.writerow([r[0], r[1], "%.1f" % (r[2] / 1e3), "%.2f" % (r[3] / 1e3), "%.2f" % (r[4] / 1e3),
+                        "%.2f" % (r[5] / 1e3), "%.2f" % (100.0 * r[2] / total)])
+    for r in rows[:14]:
+        print("%-90s calls %4d avg %10.1f us  %5.1f%%" % (r[0][:90], r[1], r[3] / 1e3, 100.0 * r[2] / total))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -73,6 +73,7 @@ int vpk_destroy(vpk_handle* h) {
     if (h->em_hdr) (void)hipFree(h->em_hdr);
     if (h->em_hdr_host) (void)hipHostFree(h->em_hdr_host);
     if (h->small_ws) (void)hipFree(h->small_ws);
+    if (h->raster_hdr) (void)hipFree(h->raster_hdr);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return VPK_OK;

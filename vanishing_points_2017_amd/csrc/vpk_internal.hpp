@@ -28,6 +28,9 @@ struct vpk_handle {
     size_t em_hdr_host_bytes = 0;
     void* small_ws = nullptr; // fine-grained entry points
     size_t small_ws_bytes = 0;
+    bool raster_ready = false;
+    void* raster_hdr = nullptr;
+    size_t raster_hdr_bytes = 0;
     bool em_ready = false;    // dynamic-LDS attribute set on the EM kernels
     vpk_cnn_state* cnn = nullptr;
 };

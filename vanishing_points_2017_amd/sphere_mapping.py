@@ -1,0 +1,42 @@
+"""Inverse-gnomonic sphere raster on the GPU (C-ABI: vpk_sphere_raster) behind the reference's
+sphere_mapping.sphere_line_plot (sphere_mapping.py:36-72) / evaluation.get_sphere_image (:12-14)."""
+import ctypes
+
+import numpy as np
+
+from .runtime import get_runtime
+
+
+def raster_batch_device(rt, l, offsets, size=500, alpha=0.1):
+    """l: device tensor (sum N x 3, f64); offsets: host int64 (B+1).  Returns uint8 (B,size,size)."""
+    t = rt.torch
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    batch = offsets.shape[0] - 1
+    with rt.on_stream():
+        out = t.empty((batch, size, size), dtype=t.uint8, device=rt.tdev)
+        rt.check(rt.lib.vpk_sphere_raster(rt.h, rt.ptr(l), offsets.ctypes.data_as(ctypes.c_void_p), batch,
+                                          int(size), float(alpha), rt.ptr(out)))
+    return out
+
+
+def raster_batch(lines_list, size=500, alpha=0.1, device=0):
+    """Host convenience: list of (N_i x 3) arrays -> (B, size, size) uint8."""
+    rt = get_runtime(device)
+    counts = [int(a.shape[0]) for a in lines_list]
+    offsets = np.zeros(len(counts) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(counts)
+    cat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, 3) for a in lines_list], 0))
+    with rt.on_stream():
+        d = rt.torch.from_numpy(cat).to(rt.tdev)
+    out = raster_batch_device(rt, d, offsets, size, alpha)
+    rt.synchronize()
+    return out.cpu().numpy()
+
+
+def sphere_line_plot(lines, size, alpha=0.1, f=1.0, alternative=False, device=0):
+    """sphere_mapping.py:36-72.  Scales lines[:, 0:2] by f IN PLACE like the reference (:55-56)."""
+    if alternative:
+        raise NotImplementedError("the 'alternative' parametrisation (:58-59) is never used by the reference")
+    lines[:, 0] *= f
+    lines[:, 1] *= f
+    return raster_batch([lines], size=size, alpha=alpha, device=device)[0]
