@@ -29,6 +29,63 @@ import numpy as np
 
 PI = np.pi
 
+
+# ----------------------------------------------------------------------------------------------
+# fused dot products: the reference's scalar code calls np.dot / np.linalg.norm on 2- and 3-vectors,
+# which NumPy's BLAS evaluates as fma(x_{n-1}, y_{n-1}, ... fma(x1, y1, x0*y0)).  NumPy has no fma
+# ufunc, so a 10-line C helper (oracle/_fma.c, built on first use with gcc) provides it.
+# ----------------------------------------------------------------------------------------------
+_FMA = None
+
+
+def _fma_lib():
+    global _FMA
+    if _FMA is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "_build", "libvpkfma.so")
+        src = os.path.join(here, "_fma.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-builtin", src, "-o", so, "-lm"])
+        _FMA = ctypes.CDLL(so)
+        _FMA.vpk_vfma.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t]
+        _FMA.vpk_vpow2.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t]
+    return _FMA
+
+
+def pow2_scalar(a):
+    """x ** 2 as a NumPy float64 scalar computes it: libm pow(x, 2.0)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty(a.shape)
+    _fma_lib().vpk_vpow2(a.ctypes.data, out.ctypes.data, out.size)
+    return out
+
+
+def fma(a, b, c):
+    """Element-wise fused multiply-add round(a*b + c) with broadcasting."""
+    a, b, c = np.broadcast_arrays(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64),
+                                  np.asarray(c, dtype=np.float64))
+    a, b, c = np.ascontiguousarray(a), np.ascontiguousarray(b), np.ascontiguousarray(c)
+    out = np.empty(a.shape)
+    _fma_lib().vpk_vfma(a.ctypes.data, b.ctypes.data, c.ctypes.data, out.ctypes.data, out.size)
+    return out
+
+
+def dot2(ax, ay, bx, by):
+    """np.dot of 2-vectors as the reference's BLAS rounds it."""
+    return fma(ay, by, np.asarray(ax) * np.asarray(bx))
+
+
+def dot3(ax, ay, az, bx, by, bz):
+    return fma(az, bz, fma(ay, by, np.asarray(ax) * np.asarray(bx)))
+
+
+def norm2(x, y):
+    return np.sqrt(dot2(x, y, x, y))
+
 PDFParams = namedtuple("PDFParams", "means weights sigma")      # probability_functions.py:4
 PDF = namedtuple("PDF", "v lv vl l lvsq angles")                # probability_functions.py:5
 
@@ -172,11 +229,11 @@ def calc_lvsq_angle(v, lp):
     v2y = lp[:, 1] - lp[:, 3]
     v1x = lmx[:, None] - vx[None, :]
     v1y = lmy[:, None] - vy[None, :]
-    dot = v1x * v2x[:, None] + v1y * v2y[:, None]
-    n1 = np.sqrt(v1x * v1x + v1y * v1y)
-    n2 = np.sqrt(v2x * v2x + v2y * v2y)
+    dot = dot2(v1x, v1y, v2x[:, None], v2y[:, None])
+    n1 = norm2(v1x, v1y)
+    n2 = norm2(v2x, v2y)
     c = 1 - np.abs(dot / (n1 * n2[:, None]))
-    return c * c
+    return pow2_scalar(c)                                    # (...)**2 on a float64 scalar (:174)
 
 
 def calc_probabilities(pdfpar, v, lp, s):
@@ -204,13 +261,13 @@ def _seg_point_dist(ax, ay, bx, by, px, py):
     """vp_localisation.py:743-758: distance from point p to segment a-b (clamped projection).
     The reference squares the *norm* of (b-a) (:747), reproduced as sqrt-then-square."""
     dx, dy = bx - ax, by - ay
-    nrm = np.sqrt(dx * dx + dy * dy)
+    nrm = norm2(dx, dy)
     with np.errstate(divide="ignore", invalid="ignore"):
-        param = ((px - ax) * dx + (py - ay) * dy) / np.square(nrm)
+        param = dot2(px - ax, py - ay, dx, dy) / np.square(nrm)
     cx = np.where(param < 0, ax, np.where(param > 1, bx, ax + param * dx))
     cy = np.where(param < 0, ay, np.where(param > 1, by, ay + param * dy))
     ex, ey = cx - px, cy - py
-    return np.sqrt(ex * ex + ey * ey)
+    return norm2(ex, ey)
 
 
 def pair_distance_closest(lp):
@@ -229,7 +286,7 @@ def pair_cosangle(lp, f, rows=None, cols=None):
     """vp_localisation.py:715-724 for pairs: cos(clip(f * acos(|cos angle|), -pi/2, pi/2))."""
     vx = lp[:, 0] - lp[:, 2]
     vy = lp[:, 1] - lp[:, 3]
-    nrm = np.sqrt(vx * vx + vy * vy)
+    nrm = norm2(vx, vy)
     if rows is None:
         ax, ay, an = vx[:, None], vy[:, None], nrm[:, None]
         bx, by, bn = vx[None, :], vy[None, :], nrm[None, :]
@@ -237,7 +294,7 @@ def pair_cosangle(lp, f, rows=None, cols=None):
         ax, ay, an = vx[rows], vy[rows], nrm[rows]
         bx, by, bn = vx[cols], vy[cols], nrm[cols]
     with np.errstate(divide="ignore", invalid="ignore"):
-        c = np.abs((ax * bx + ay * by) / (an * bn))
+        c = np.abs(dot2(ax, ay, bx, by) / (an * bn))
     dphi = np.abs(np.arccos(np.clip(c, -1, 1)))
     return np.cos(np.clip(f * dphi, -PI / 2, PI / 2))
 
@@ -246,7 +303,7 @@ def line_lengths(lp):
     """vp_localisation.py:761-762."""
     dx = lp[:, 0] - lp[:, 2]
     dy = lp[:, 1] - lp[:, 3]
-    return np.sqrt(dx * dx + dy * dy)
+    return norm2(dx, dy)
 
 
 def pair_proximity(lp, dist, sigma):
@@ -300,7 +357,7 @@ def lines_angles(lp):
     """vp_localisation.py:765-776: undirected segment angle folded into [0, pi/2]."""
     vx = lp[:, 0] - lp[:, 2]
     vy = lp[:, 1] - lp[:, 3]
-    nrm = np.sqrt(vx * vx + vy * vy)
+    nrm = norm2(vx, vy)
     phi = np.abs(np.arccos(np.clip(vx / nrm, -1, 1)))
     return np.where(phi > PI / 2, PI - phi, phi)
 
@@ -348,8 +405,8 @@ def calc_lvsq_single(v, lp):
     v1y = 0.5 * (lp[:, 1] + lp[:, 3]) - vy
     v2x = lp[:, 0] - lp[:, 2]
     v2y = lp[:, 1] - lp[:, 3]
-    c = 1 - np.abs((v1x * v2x + v1y * v2y) / (np.sqrt(v1x * v1x + v1y * v1y) * np.sqrt(v2x * v2x + v2y * v2y)))
-    return c * c
+    c = 1 - np.abs(dot2(v1x, v1y, v2x, v2y) / (norm2(v1x, v1y) * norm2(v2x, v2y)))
+    return pow2_scalar(c)                                    # :222
 
 
 def calc_vp_line_counts(vp, lp, s, metric, lweights, thresh):
@@ -389,14 +446,14 @@ class _EM(object):
         self.n = n
         dist = pair_distance_closest(lp) if use_weights else None
         lsim = calc_lsim(lp, sigma=1, dist=dist) if use_weights else np.zeros((n, n))  # :177-180
-        l /= np.sqrt(np.sum(l * l, axis=1))[:, None]                                   # :185-186 (in place)
+        l /= np.sqrt(dot3(l[:, 0], l[:, 1], l[:, 2], l[:, 0], l[:, 1], l[:, 2]))[:, None]  # :185-186 (in place)
         v0 = find_initial_vps(sphere_image, cnn_response, num_init_vp)                 # :208
         self.pdfpar = pdf_params(cnn_response)                                         # :210
         if init_vp is not None:                                                        # :212-215
             v0 = init_vp.copy()
-            v0 /= np.sqrt(np.sum(v0 * v0, axis=1))[:, None]
+            v0 /= np.sqrt(dot3(v0[:, 0], v0[:, 1], v0[:, 2], v0[:, 0], v0[:, 1], v0[:, 2]))[:, None]
         self.langles = lines_angles(lp)                                                # :217
-        l /= np.sqrt(np.sum(l * l, axis=1))[:, None]                                   # :226 (again)
+        l /= np.sqrt(dot3(l[:, 0], l[:, 1], l[:, 2], l[:, 0], l[:, 1], l[:, 2]))[:, None]  # :226 (again)
         self.l = l
         llen = line_lengths(lp)                                                        # :227
         if use_weights:
@@ -560,6 +617,8 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
             em.split(em.smooth(p.vl), merge_thresh)
             events += int(em.cur.shape[0] != mb)
         m_n = em.cur.shape[0]
+        if trace is not None and trace.get("want_states"):
+            trace.setdefault("states", []).append((em.cur.copy(), em.s.copy()))
         p = em.estep(em.cur)                                                # :273
         w = em.smooth(p.vl)                                                 # :282
         max_err = 0
@@ -594,6 +653,7 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
         if max_err < final_convergence or i == num_iter - 1 or not do_iterations:   # :335
             if do_merge:
                 em.merge(True, merge_thresh_final)                          # :339 (index i+1)
+            fin = [em.cur.shape[0]]
             p = em.estep(em.cur)                                            # :344 (stale index i)
             w = em.smooth(p.vl)
             removed = []
@@ -617,12 +677,16 @@ def expectation_maximisation(l, lp, cnn_response, num_iter=100, sphere_image=Non
                     if err > 1.5:
                         removed.append(m)
             em.delete(removed)                                              # :394-396
+            fin.append(em.cur.shape[0])
             p = em.estep(em.cur)                                            # :398 (still index i)
             metric = em.smooth(p.vl)
             if metric.size <= 0:                                            # :402-404
                 return result
             good = np.unique(np.argmax(metric, axis=0))                     # :406-413
             em.cur, em.nxt, em.s = em.cur[good], em.nxt[good], em.s[good]
+            fin.append(em.cur.shape[0])
+            if trace is not None:
+                trace["final"] = fin
             p = em.estep(em.nxt)                                            # :415 (index i+1 at last)
             metric = em.smooth(p.vl)
             counts, counts_w, vp_assoc = em.counts(em.nxt, metric)

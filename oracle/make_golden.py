@@ -42,6 +42,10 @@ CASES = {
     "stress_n300": dict(seed=5001, n=300, vps=8, stress=True,
                         em=dict(num_iter=50, do_split=False, do_merge=False, final_convergence=-1)),
     "tiny_n12": dict(seed=2020, n=12, vps=2, outlier_frac=0.0),
+    # inputs captured from the GPU pipeline (GPU-rasterised sphere image) where a VP wins exactly one
+    # line in the hard-assignment M-step, so LAPACK's 1 x 3 null vector decides (:353-392)
+    "hard1row_n387": dict(inputs="hard1row_n387"),
+    "hard1row_n289": dict(inputs="hard1row_n289"),
 }
 FULL_INTERMEDIATES_MAX_N = 260
 
@@ -58,13 +62,20 @@ def run_case(name, spec, mods):
     prob = mods["probability_functions"]
     ch = mods["calc_horizon"]
     sm = mods["sphere_mapping"]
-    sc = synth.make_scene(spec["seed"], spec["n"], spec["vps"],
-                          outlier_frac=spec.get("outlier_frac", 0.25), raster=None)
+    if "inputs" in spec:     # stored inputs (tests/golden_inputs/*.npz): data only
+        src = dict(np.load(os.path.join(ROOT, "tests", "golden_inputs", spec["inputs"] + ".npz")))
+        sc = {"l": src["l"], "lp": src["lp"], "cnn_response": src["cnn_response"],
+              "true_vps": np.zeros((0, 3)), "true_horizon": np.zeros(3)}
+        sphere = src["sphere_image"]
+    else:
+        sc = synth.make_scene(spec["seed"], spec["n"], spec["vps"],
+                              outlier_frac=spec.get("outlier_frac", 0.25), raster=None)
+        sphere = reference_raster(sm, sc["l"])
     l0, lp = sc["l"], sc["lp"]
     cnn = sc["cnn_response"]
-    sphere = reference_raster(sm, l0)
     kwargs = dict(spec.get("em", {}))
     init_vp = synth.stress_init_vps(spec["seed"]) if spec.get("stress") else None
+    spec = dict(spec, n=lp.shape[0])
     out = {"l": l0, "lp": lp, "cnn_response": cnn, "sphere_image": sphere,
            "true_vps": sc["true_vps"], "true_horizon": sc["true_horizon"]}
     if init_vp is not None:

@@ -9,6 +9,7 @@ using namespace vpk;
 
 static Shared g_sh;
 static double g_wt[WT_DOUBLES];
+static std::vector<double> g_dbg;
 
 static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_params& p, bool has_init,
                      int n_init) {
@@ -39,9 +40,13 @@ int sim_em_single(int n, double* l, const double* lp, const float* cnn, const un
     o.vp = vp_out; o.sigma = sigma_out; o.counts = counts_out; o.counts_w = counts_w_out;
     o.num_vp = num_vp_out; o.assoc = assoc_out; o.iterations = iterations_out; o.status = status_out;
     o.flags = flags_out; o.metric = metric_out; o.trace = trace_out; o.max_vp = max_vp;
+    g_dbg.assign((size_t)p->num_iter * (1 + 4 * MAXM), 0.0);
+    o.dbg = g_dbg.data();
     em_run(c, o);
     return 0;
 }
+
+const double* sim_last_states() { return g_dbg.data(); }
 
 int sim_pairwise(int n, const double* lp, double* lsim_out, double* lscore_out, double* langle_out) {
     vpk_em_params p;
@@ -126,6 +131,27 @@ int sim_weight_matrix(int n, int m, const double* p_vl, const double* lweight, c
     smooth(c);
     for (int k = 0; k < m; ++k)
         for (int q = 0; q < n; ++q) w_out[(size_t)k * n + q] = c.w[(size_t)k * c.ldn + q];
+    return 0;
+}
+
+int sim_mstep(int n, int m, const double* l, const double* w, double* vp_out) {
+    vpk_em_params p;
+    memset(&p, 0, sizeof(p));
+    p.use_weights = 1; p.num_init_vp = m; p.num_iter = 1; p.split_merge_freq = 10; p.s_thresh = 1e-200;
+    EmCtx c;
+    std::vector<double> buf;
+    make_ctx(c, buf, n, p, false, 0);
+    c.l = const_cast<double*>(l);
+    g_sh.M = m;
+    for (int k = 0; k < m; ++k)
+        for (int q = 0; q < n; ++q) {
+            c.w[(size_t)k * c.ldn + q] = w[(size_t)k * n + q];
+            c.lvsq[(size_t)k * c.ldn + q] = 1.0;
+            c.pvl[(size_t)k * c.ldn + q] = 1.0;
+        }
+    for (int k = 0; k < 3 * m; ++k) { g_sh.cur[k] = (k % 3 == 2) ? 1.0 : 0.0; g_sh.nxt[k] = 0.0; }
+    mstep(c, 0, 1e-6);
+    for (int k = 0; k < 3 * m; ++k) vp_out[k] = g_sh.nxt[k];
     return 0;
 }
 

@@ -74,7 +74,10 @@ def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, **
                         max_vp, _p(vp, D), _p(sigma, D), _p(counts, D), _p(cw, D), _p(num, I), _p(assoc, L),
                         _p(it, I), _p(st, I), _p(fl, U), _p(metric, D), _p(trace, D))
     m = int(num[0])
-    return {"status": int(st[0]), "flags": int(fl[0]), "iterations": int(it[0]), "vp": vp[:m],
+    lib().sim_last_states.restype = ctypes.POINTER(ctypes.c_double)
+    raw = np.ctypeslib.as_array(lib().sim_last_states(), shape=(p.num_iter, 1 + 4 * 64)).copy()
+    states = [(raw[i, 65:65 + 3 * int(raw[i, 0])].reshape(-1, 3), raw[i, 1:1 + int(raw[i, 0])]) for i in range(p.num_iter)]
+    return {"states": states, "status": int(st[0]), "flags": int(fl[0]), "iterations": int(it[0]), "vp": vp[:m],
             "sigma": sigma[:m], "counts": counts[:m], "counts_weighted": cw[:m], "vp_assoc": assoc,
             "l": l, "trace": trace, "decision_metric": None if metric is None else metric[:, :m].T}
 
@@ -123,3 +126,12 @@ def cluster2(ldist):
     labels = np.zeros(n, np.int32); fl = np.zeros(1, np.uint32)
     lib().sim_cluster2(n, _p(ldist, ctypes.c_double), _p(labels, ctypes.c_int32), _p(fl, ctypes.c_uint32))
     return labels, int(fl[0])
+
+
+def mstep(l, w):
+    m, n = w.shape
+    l = np.ascontiguousarray(l, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64)
+    vp = np.zeros((m, 3))
+    D = ctypes.c_double
+    lib().sim_mstep(n, m, _p(l, D), _p(w, D), _p(vp, D))
+    return vp

@@ -1,0 +1,113 @@
+"""Benchmark driver with the reference's CLI (benchmark.py:16-26):
+
+    python -m vanishing_points_2017_amd.benchmark --yud --result_dir /tmp/vp --update_datalist \\
+        --update_datafiles --run_cnn --run_em [--synthetic [--count N]]
+
+``--synthetic`` replaces the dataset directory (YUD / ECD / HLW are not reachable offline,
+config.py:3-5) by the seeded synthetic set of the same shape (synth.CONFIGS): line segments and
+ground-truth horizons come from the generator, rasters from the GPU rasteriser, and -- unless
+--run_cnn is given together with real weight files -- the generator's response map stands in for a
+trained CNN's prediction.  The scoring loop is the reference's (:108-266): horizon from the best
+orthogonal triplet, error = max end-point deviation / image height, AUC up to 0.25.
+Ground-truth loaders for the real datasets (.mat / .csv, :142-220) are out of scope."""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import auc as auc_mod, calc_horizon as ch, config, evaluation, sphere_mapping, synth
+
+SHAPES = {"york": 2, "eurasian": 3, "horizon": 4}
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='')
+    p.add_argument('--yud', dest='yud', action='store_true', help='Run benchmark on YUD')
+    p.add_argument('--ecd', dest='ecd', action='store_true', help='Run benchmark on ECD')
+    p.add_argument('--hlw', dest='hlw', action='store_true', help='Run benchmark on HLW')
+    p.add_argument('--result_dir', default='/tmp/', type=str, help='Directory to store (intermediate) results')
+    p.add_argument('--gpu', default=0, type=int, help='GPU ID to use')
+    p.add_argument('--update_datalist', dest='update_datalist', action='store_true', help='Update the dataset list')
+    p.add_argument('--update_datafiles', dest='update_datafiles', action='store_true', help='Update the dataset files')
+    p.add_argument('--run_cnn', dest='run_cnn', action='store_true', help='Evaluate CNN on the data')
+    p.add_argument('--run_em', dest='run_em', action='store_true', help='Run EM refinement on the data')
+    p.add_argument('--synthetic', action='store_true', help='use the seeded synthetic set of the dataset shape')
+    p.add_argument('--count', type=int, default=None, help='number of synthetic images (default: dataset size)')
+    return p
+
+
+def synthetic_dataset(name, result_dir, count, update):
+    """Writes reference-schema pickles for the synthetic set and returns the dataset dict."""
+    cfg = SHAPES[name]
+    dest = os.path.join(result_dir, name, "synthetic_angle_weights_split_merge")
+    os.makedirs(dest, exist_ok=True)
+    scenes = list(synth.config_scenes(cfg, count=count, raster=None))
+    files = [os.path.join(dest, "img%05d.data.pkl" % i) for i in range(len(scenes))]
+    dataset = {'source_folder': "synthetic:%s" % name, 'destination_folder': dest, 'use_weights': True,
+               'distance_measure': "angle", 'do_split': True, 'do_merge': True, 'name': "synthetic_" + name,
+               'image_files': ["synthetic:%s:%d" % (name, s["seed"]) for s in scenes], 'pickle_files': files,
+               'true_horizon': [s["true_horizon"] for s in scenes], 'image_shape': [s["image_shape"] for s in scenes]}
+    if update or not all(os.path.isfile(f) for f in files):
+        rasters = sphere_mapping.raster_batch([s["l"] for s in scenes], size=500, alpha=0.1)
+        for s, f, r in zip(scenes, files, rasters):
+            datum = {"dataset": dataset["name"], "image_file": "synthetic", "image_shape": s["image_shape"],
+                     "image": None, "line_segments": s["lp"], "lines": s["l"]}
+            evaluation._dump_pickle({'lines': datum, 'sphere_image': r, 'cnn_prediction': s["cnn_response"]}, f)
+    return dataset
+
+
+def score(dataset, start=0, n_vp=20, theta_vmin=np.pi / 10, err_cutoff=0.25):
+    """benchmark.py:108-266 with the ground truth supplied by the dataset dict."""
+    errors = []
+    for idx, data_file in enumerate(dataset['pickle_files']):
+        if idx < start:
+            continue
+        datum = evaluation._load_pickle(data_file)
+        em_result = datum.get('EM_result')
+        assert em_result is not None, "no EM result!"                        # :231
+        if em_result['vp'] is None:
+            em_result = {'vp': np.zeros((0, 3)), 'counts': np.zeros(0)}
+        hp1, hp2, _, _, _, _ = ch.calculate_horizon_and_ortho_vp(em_result, maxbest=n_vp, theta_vmin=theta_vmin)
+        errors.append(ch.horizon_error(hp1, hp2, dataset['true_horizon'][idx], dataset['image_shape'][idx]))
+    errors = np.array(errors)
+    auc, pts = auc_mod.calc_auc(errors, cutoff=err_cutoff)
+    return auc, errors, pts
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.yud:
+        name = "york"
+    elif args.ecd:
+        name = "eurasian"
+    elif args.hlw:
+        name = "horizon"
+    else:
+        assert False                                                         # benchmark.py:49
+    if not args.synthetic:
+        raise NotImplementedError(
+            "the real %s dataset and its ground-truth loaders are out of scope (no dataset offline, LSD not "
+            "vendored); run with --synthetic, or use evaluation.run_cnn / run_em on existing reference pickles" % name)
+    dataset = synthetic_dataset(name, args.result_dir, args.count, args.update_datafiles or args.update_datalist)
+    if args.run_cnn:
+        if not all(os.path.isfile(f) for f in (config.cnn_weights_path, config.cnn_mean_path)):
+            print("no trained weights at %s: keeping the generator's response maps as cnn_prediction"
+                  % config.cnn_weights_path)
+        else:
+            evaluation.run_cnn(dataset, mean_file=config.cnn_mean_path, model_def=config.cnn_config_path,
+                               model_weights=config.cnn_weights_path, gpu=args.gpu)
+    if args.run_em:
+        t0 = time.time()
+        evaluation.run_em(dataset)
+        print("EM time: ", time.time() - t0)
+    start = 25 if (args.yud or args.ecd) else 0                              # :69
+    t0 = time.time()
+    auc, errors, _ = score(dataset, start=start)
+    print("time elapsed: ", time.time() - t0)
+    print("AUC: ", auc)
+    return auc
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,12 @@ class Net(object):
         self.rt.check(self.rt.lib.vpk_cnn_last_layer_ms(self.rt.h, ms))
         return dict(zip(self.LAYER_NAMES, [float(x) for x in ms]))
 
+    def forward_batch(self, sphere_u8, mean_arr=None):
+        return self.forward(sphere_u8)
+
+    def forward_single(self, image, mean_arr=None):
+        return self.forward(np.asarray(image)[None])[0]
+
     def forward(self, sphere_u8, tap=None):
         rt = self.rt
         sphere_u8 = np.ascontiguousarray(sphere_u8, dtype=np.uint8).reshape(-1, 500, 500)
@@ -100,7 +106,39 @@ class Net(object):
         return res[0].cpu().numpy(), res[1].cpu().numpy()
 
 
+class LazyNet(object):
+    """What evaluation.init_caffe returns: weights are known at construction, the mean blob only at
+    the first forward (the reference passes it to caffe_forward, evaluation.py:34-35).  The HIP net is
+    (re)built when the mean changes, because `image - mean` is fused into conv1's input load."""
+
+    def __init__(self, weights, device=0, mean=None):
+        self.weights = weights
+        self.device = device
+        self._mean = None
+        self._net = None
+        if mean is not None:
+            self._bind(mean)
+
+    def _bind(self, mean_arr):
+        mean = np.ascontiguousarray(np.asarray(mean_arr, dtype=np.float32).reshape(500, 500))
+        if self._net is None or not np.array_equal(mean, self._mean):
+            self._net = Net(self.weights, mean, device=self.device)
+            self._mean = mean
+        return self._net
+
+    def forward_batch(self, sphere_u8, mean_arr=None):
+        net = self._bind(mean_arr) if mean_arr is not None else self._net
+        if net is None:
+            raise ValueError("no mean blob bound: pass mean_arr")
+        return net.forward(sphere_u8)
+
+    def forward_single(self, image, mean_arr=None):
+        return self.forward_batch(np.asarray(image)[None], mean_arr)[0]
+
+
 def caffe_forward(net, image, mean_arr=None):
     """evaluation.py:34-38: one 500x500 uint8 raster -> (20,20) float32.  The mean blob was bound
     at load time (it is fused into conv1's input load); mean_arr is accepted for signature parity."""
+    if isinstance(net, LazyNet):
+        return net.forward_single(image, mean_arr)
     return net.forward(np.asarray(image)[None])[0]

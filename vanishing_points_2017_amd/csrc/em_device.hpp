@@ -111,6 +111,16 @@ VPK_DEV double clip(double x, double lo, double hi) {  // np.clip (NaN passes th
     return x < lo ? lo : (x > hi ? hi : x);
 }
 VPK_DEV bool is_nan(double x) { return x != x; }
+// The reference's scalar code calls np.dot / np.linalg.norm on 2- and 3-vectors; NumPy's BLAS
+// evaluates those as a fused chain  fma(x_{n-1}, y_{n-1}, ... fma(x1, y1, x0*y0))  (verified on the
+// build container's NumPy 2.2.6 / OpenBLAS).  These helpers round the same way, which matters when a
+// VP collapses onto a single line and 1 - |cos| is 0 or 1 ulp (sigma^2 at its 1e-200 floor).
+VPK_DEV double dot2(double ax, double ay, double bx, double by) { return fma(ay, by, ax * bx); }
+VPK_DEV double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    return fma(az, bz, fma(ay, by, ax * bx));
+}
+VPK_DEV double norm2(double x, double y) { return sqrt(dot2(x, y, x, y)); }
+VPK_DEV double norm3(double x, double y, double z) { return sqrt(dot3(x, y, z, x, y, z)); }
 VPK_DEV double sign_np(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : (x == 0 ? 0.0 : x)); }
 
 // workgroup-wide lexicographic (value, index) minimum; result to every thread
@@ -144,14 +154,12 @@ VPK_DEVFN double block_max(Shared& sh, double v) {
     return b;
 }
 
-// symmetric 3x3 eigen-solver (cyclic Jacobi); returns the unit eigenvector of the SMALLEST
-// eigenvalue of [[a00,a01,a02],[a01,a11,a12],[a02,a12,a22]].  Stands in for the smallest right
-// singular vector of the row-weighted N x 3 line matrix (numpy.linalg.svd at
-// vp_localisation.py:466,595): V[:,2] of A equals the bottom eigenvector of A^T A.
-VPK_DEV void eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22,
-                           double out[3]) {
+// symmetric 3x3 eigen-solver (cyclic Jacobi): A = J diag(ev) J^T, J orthogonal (columns = eigenvectors)
+VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a12, double a22,
+                       double ev[3], double J[3][3]) {
     double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) J[i][k] = (i == k) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 32; ++sweep) {
         double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
         if (!(off > 0)) break;
@@ -179,21 +187,80 @@ VPK_DEV void eig3_smallest(double a00, double a01, double a02, double a11, doubl
                 A[r][p] = A[p][r] = cth * arp - sth * arq;
                 A[r][q] = A[q][r] = sth * arp + cth * arq;
                 for (int k = 0; k < 3; ++k) {
-                    double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = cth * vkp - sth * vkq;
-                    V[k][q] = sth * vkp + cth * vkq;
+                    double vkp = J[k][p], vkq = J[k][q];
+                    J[k][p] = cth * vkp - sth * vkq;
+                    J[k][q] = sth * vkp + cth * vkq;
                 }
             }
         }
     }
+    ev[0] = A[0][0]; ev[1] = A[1][1]; ev[2] = A[2][2];
+}
+
+// Smallest right singular vector of the row-weighted line matrix diag(r) * L (N x 3), cooperatively
+// by ONE wave -- stands in for V[:,2] of numpy.linalg.svd (vp_localisation.py:466,595).
+// rw(n) returns the row weight r_n (0 = row not selected).  Pass 0 diagonalises the 3x3 scatter
+// sum r^2 l l^T (normal equations: error ~ eps * cond^2 in the small direction); every further pass
+// re-accumulates the scatter IN THE ROTATED BASIS V^T l, where the entries that couple to the small
+// direction are sums of small numbers (no cancellation against the large ones), and applies the
+// Jacobi correction -- an implicit one-sided Jacobi SVD, accurate like LAPACK's after 2-3 passes.
+template <class RowWeight>
+VPK_DEV void wave_null_vector(const double* l, int N, RowWeight rw, double out[3]) {
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double ev[3] = {0, 0, 0};
+    for (int pass = 0; pass < 5; ++pass) {
+        double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
+        for (int n = lane(); n < N; n += WAVE) {
+            const double r = rw(n);
+            if (r == 0) continue;
+            const double* ln = l + 3 * (size_t)n;
+            double y0, y1, y2;
+            if (pass == 0) {
+                y0 = r * ln[0]; y1 = r * ln[1]; y2 = r * ln[2];
+            } else {
+                y0 = r * (ln[0] * V[0][0] + ln[1] * V[1][0] + ln[2] * V[2][0]);
+                y1 = r * (ln[0] * V[0][1] + ln[1] * V[1][1] + ln[2] * V[2][1]);
+                y2 = r * (ln[0] * V[0][2] + ln[1] * V[1][2] + ln[2] * V[2][2]);
+            }
+            g00 += y0 * y0; g01 += y0 * y1; g02 += y0 * y2;
+            g11 += y1 * y1; g12 += y1 * y2; g22 += y2 * y2;
+        }
+        g00 = wave_sum(g00); g01 = wave_sum(g01); g02 = wave_sum(g02);
+        g11 = wave_sum(g11); g12 = wave_sum(g12); g22 = wave_sum(g22);
+        const double tol = 4e-16;
+        const bool conv = pass > 0 && fabs(g01) <= tol * sqrt(g00 * g11) && fabs(g02) <= tol * sqrt(g00 * g22) &&
+                          fabs(g12) <= tol * sqrt(g11 * g22);
+        double J[3][3];
+        eig3_full(g00, g01, g02, g11, g12, g22, ev, J);
+        double Vn[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) Vn[i][k] = V[i][0] * J[0][k] + V[i][1] * J[1][k] + V[i][2] * J[2][k];
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) V[i][k] = Vn[i][k];
+        if (conv) break;
+    }
     int b = 0;
-    if (A[1][1] < A[b][b]) b = 1;
-    if (A[2][2] < A[b][b]) b = 2;
+    if (ev[1] < ev[b]) b = 1;
+    if (ev[2] < ev[b]) b = 2;
     double x = V[0][b], y = V[1][b], z = V[2][b];
-    double nrm = sqrt(x * x + y * y + z * z);
-    out[0] = x / nrm;
-    out[1] = y / nrm;
-    out[2] = z / nrm;
+    double nrm = norm3(x, y, z);                              // vp /= np.linalg.norm(vp) (:472)
+    out[0] = x / nrm; out[1] = y / nrm; out[2] = z / nrm;
+}
+
+// Third right singular vector of a 1 x 3 matrix [a b c] as LAPACK returns it (numpy.linalg.svd with
+// full_matrices on one row: dgesdd -> dgelqf -> one Householder reflector H = I - tau v v^T with
+// beta = -sign(a)|x|, tau = (beta - a)/beta, v = (1, b/(a-beta), c/(a-beta)); V^T = H up to the sign
+// of its first row).  The reference reaches this in the hard-assignment M-step when a VP wins a
+// single line (vp_localisation.py:353-369) and its `err > 1.5` test (:387) depends on this vector.
+VPK_DEV void lapack_null_1row(double a, double b, double c, double out[3]) {
+    double nrm = sqrt(a * a + b * b + c * c);
+    double beta = a >= 0 ? -nrm : nrm;
+    if (a == 0 && 1.0 / a < 0) beta = nrm;                   // sign(-0.0)
+    double tau = (beta - a) / beta;
+    double v1 = b / (a - beta), v2 = c / (a - beta);
+    out[0] = -tau * v2;
+    out[1] = -tau * v2 * v1;
+    out[2] = 1 - tau * v2 * v2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,8 +269,8 @@ VPK_DEV void eig3_smallest(double a00, double a01, double a02, double a11, doubl
 // vp_localisation.py:743-758: the reference squares the NORM of (b - a) (:747)
 VPK_DEV double seg_point_dist(double ax, double ay, double bx, double by, double px, double py) {
     double dx = bx - ax, dy = by - ay;
-    double nrm = sqrt(dx * dx + dy * dy);
-    double param = ((px - ax) * dx + (py - ay) * dy) / (nrm * nrm);
+    double nrm = norm2(dx, dy);
+    double param = dot2(px - ax, py - ay, dx, dy) / (nrm * nrm);
     double cx, cy;
     if (param < 0) {
         cx = ax; cy = ay;
@@ -213,7 +280,7 @@ VPK_DEV double seg_point_dist(double ax, double ay, double bx, double by, double
         cx = ax + param * dx; cy = ay + param * dy;
     }
     double ex = cx - px, ey = cy - py;
-    return sqrt(ex * ex + ey * ey);
+    return norm2(ex, ey);
 }
 // vp_localisation.py:727-740
 VPK_DEV double line_distance_closest(const double a[4], const double b[4]) {
@@ -229,14 +296,13 @@ VPK_DEV double line_distance_closest(const double a[4], const double b[4]) {
 VPK_DEV double lines_cosangle(const double a[4], const double b[4], double f) {
     double v1x = a[0] - a[2], v1y = a[1] - a[3];
     double v2x = b[0] - b[2], v2y = b[1] - b[3];
-    double n1 = sqrt(v1x * v1x + v1y * v1y), n2 = sqrt(v2x * v2x + v2y * v2y);
-    double c = fabs((v1x * v2x + v1y * v2y) / (n1 * n2));
+    double n1 = norm2(v1x, v1y), n2 = norm2(v2x, v2y);
+    double c = fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
     double dphi = fabs(acos(clip(c, -1.0, 1.0)));
     return cos(clip(f * dphi, -PI_D / 2, PI_D / 2));
 }
 VPK_DEV double line_length(const double a[4]) {
-    double dx = a[0] - a[2], dy = a[1] - a[3];
-    return sqrt(dx * dx + dy * dy);
+    return norm2(a[0] - a[2], a[1] - a[3]);
 }
 // vp_localisation.py:708-712 with the distance supplied
 VPK_DEV double proximity(double d, double len_a, double len_b, double sigma) {
@@ -252,7 +318,7 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
     for (int n = tid(); n < c.N; n += nthreads()) {
         double* r = c.l + 3 * (size_t)n;
         for (int pass = 0; pass < 2; ++pass) {
-            double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            double nr = norm3(r[0], r[1], r[2]);
             r[0] /= nr; r[1] /= nr; r[2] /= nr;
         }
     }
@@ -332,7 +398,7 @@ VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
             c.lscore[i] = sum / k2;                                                 // :70
             // lines_angles (:765-776)
             double vx = a[0] - a[2], vy = a[1] - a[3];
-            double nr = sqrt(vx * vx + vy * vy);
+            double nr = norm2(vx, vy);
             double phi = fabs(acos(clip(vx / nr, -1.0, 1.0)));
             c.langle[i] = phi > PI_D / 2 ? PI_D - phi : phi;
         }
@@ -551,12 +617,12 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
         const double* q = c.lp + 4 * (size_t)n;
         double lmx = 0.5 * (q[0] + q[2]), lmy = 0.5 * (q[1] + q[3]);
         double v2x = q[0] - q[2], v2y = q[1] - q[3];
-        double n2 = sqrt(v2x * v2x + v2y * v2y);
+        double n2 = norm2(v2x, v2y);
         double pl = 0.0;
         for (int m = 0; m < M; ++m) {
             double v1x = lmx - sh.vx[m], v1y = lmy - sh.vy[m];
-            double n1 = sqrt(v1x * v1x + v1y * v1y);
-            double cc = 1 - fabs((v1x * v2x + v1y * v2y) / (n1 * n2));
+            double n1 = norm2(v1x, v1y);
+            double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
             double lv = cc * cc;                             // :174
             c.lvsq[(size_t)m * c.ldn + n] = lv;
             double plv = exp(-(lv / (2 * sh.s[m]))) * sh.k2[m];   // calc_plv :137-145
@@ -755,45 +821,49 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
     for (int m = wave_id(); m < M; m += nwaves()) {
         const double* wm = c.w + (size_t)m * c.ldn;
         double wmax = -1e300;
-        int nsel = 0;
+        int nsel = 0, selidx = -1;
         for (int n = lane(); n < N; n += WAVE) {
             if (mode == 1 && c.assoc[n] != m) continue;
             wmax = nanmax(wmax, wm[n]);
             ++nsel;
+            selidx = n;
         }
         wmax = wave_max(wmax);
         nsel = wave_sum_int(nsel);
+        selidx = wave_max_int(selidx);
         if (mode == 1 && nsel == 0) {                         // :355-356 `continue`
             if (lane() == 0) { sh.removed[m] = 0; sh.err[m] = -1.0; }
             continue;
         }
         bool valid = nsel > 0 && (wmax > 0 || wmax < 0);      // :456-460; NaN -> LinAlgError -> None
-        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, sv = 0, sp = 0;
+        double sv = 0, sp = 0;
         const double* lvs = c.lvsq + (size_t)m * c.ldn;
         const double* pvl = c.pvl + (size_t)m * c.ldn;
         for (int n = lane(); n < N; n += WAVE) {
             double pq = pvl[n];
             sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
             sp += pq;
-            if (mode == 1 && c.assoc[n] != m) continue;
-            double r = wm[n] / wmax;                          // :462 (hard mode: :358, then /1 at :462)
-            const double* ln = c.l + 3 * (size_t)n;
-            double x = r * ln[0], y = r * ln[1], z = r * ln[2];
-            a00 += x * x; a01 += x * y; a02 += x * z;
-            a11 += y * y; a12 += y * z; a22 += z * z;
         }
-        a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
-        a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
         sv = wave_sum(sv);
         sp = wave_sum(sp);
+        double vp[3] = {0, 0, 0};
+        if (valid && nsel > 1) {
+            const int* assoc = c.assoc;
+            // row weight w / max w (:462; hard mode: :358 then / 1 at :462)
+            wave_null_vector(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
+        }
         if (lane() == 0) {
             int rem = 0;
             double err = -1.0;
             if (!valid) {
                 rem = 1;                                      // newVP is None (:294-296)
             } else {
-                double vp[3];
-                eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
+                if (nsel == 1) {                              // one row: LAPACK's reflector decides
+                    const double* ln = c.l + 3 * (size_t)selidx;
+                    lapack_null_1row(ln[0], ln[1], ln[2], vp);    // the row is (w/max w) * l = 1 * l
+                    double nr = norm3(vp[0], vp[1], vp[2]);
+                    vp[0] /= nr; vp[1] /= nr; vp[2] /= nr;    // :472
+                }
                 double sg = sign_np(vp[2]);                   // :474
                 vp[0] *= sg; vp[1] *= sg; vp[2] *= sg;
                 sh.nxt[3 * m] = vp[0]; sh.nxt[3 * m + 1] = vp[1]; sh.nxt[3 * m + 2] = vp[2];
@@ -805,7 +875,7 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
                 if (is_nan(sm) || (mode == 1 && sm < c.prm.s_thresh)) {
                     rem = 1;                                  // :309-310 / :379-380
                 } else {
-                    double d = fabs(sh.cur[3 * m] * vp[0] + sh.cur[3 * m + 1] * vp[1] + sh.cur[3 * m + 2] * vp[2]);
+                    double d = fabs(dot3(sh.cur[3 * m], sh.cur[3 * m + 1], sh.cur[3 * m + 2], vp[0], vp[1], vp[2]));
                     err = acos(d < 1.0 ? d : 1.0);            // :312
                     if (err > 1.5) rem = 1;                   // :316-317
                 }
@@ -858,7 +928,7 @@ VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
             for (int n = lane(); n < N; n += WAVE) wmax = nanmax(wmax, wj[n] + wk[n]);
             wmax = wave_max(wmax);
             bool valid = N > 0 && (wmax > 0 || wmax < 0);
-            double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, sv = 0, sp = 0;
+            double sv = 0, sp = 0;
             const double* lj = c.lvsq + (size_t)j * c.ldn;
             const double* lk = c.lvsq + (size_t)k * c.ldn;
             const double* pj = c.pvl + (size_t)j * c.ldn;
@@ -867,23 +937,16 @@ VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
                 double pq = pk[n] + pj[n];
                 sv += 0.5 * (lj[n] + lk[n]) * pq;             // :664
                 sp += pq;                                     // :663
-                double r = (wj[n] + wk[n]) / wmax;
-                const double* ln = c.l + 3 * (size_t)n;
-                double x = r * ln[0], y = r * ln[1], z = r * ln[2];
-                a00 += x * x; a01 += x * y; a02 += x * z;
-                a11 += y * y; a12 += y * z; a22 += z * z;
             }
-            a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
-            a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
             sv = wave_sum(sv);
             sp = wave_sum(sp);
+            double vp[3] = {0, 0, 0};
+            if (valid) wave_null_vector(c.l, N, [=](int n) { return (wj[n] + wk[n]) / wmax; }, vp);
             if (lane() == 0) {
                 double sk = exp(log(sv) - log(sp));
                 sh.s[k] = sk;                                 // :666 written BEFORE the abort test
                 int ok = valid && !(sk > 0.01);               // :668 (max_stdd = 0.01)
                 if (ok) {
-                    double vp[3];
-                    eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
                     double sg = sign_np(vp[2]);
                     X[3 * k] = vp[0] * sg; X[3 * k + 1] = vp[1] * sg; X[3 * k + 2] = vp[2] * sg;   // :672
                     for (int m = 0; m < M; ++m) sh.removed[m] = (m == j);                            // :674-675
@@ -1059,28 +1122,27 @@ VPK_DEVFN void split_vp(EmCtx& c) {
     int* csize = c.idx + 2 * N;
     cluster2(sh, nw, c.cl, member, csize);
     // per cluster: smallest right singular vector of the lweight-scaled lines (:580-602)
+    // cluster label per line (-1 = not in the set), in the assoc scratch (recomputed before next use)
+    int* lab = c.assoc;
+    for (int n = tid(); n < N; n += nthreads()) lab[n] = -1;
+    block_sync();
+    for (int q = tid(); q < nw; q += nthreads()) lab[c.idx[q]] = member[q];
+    block_sync();
     for (int cidx = wave_id(); cidx < 2; cidx += nwaves()) {
-        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
         int cnt = 0;
-        for (int q = lane(); q < nw; q += WAVE) {
-            if (member[q] != cidx) continue;
-            ++cnt;
-            int n = c.idx[q];
-            double lw = c.lweight[n];
-            const double* ln = c.l + 3 * (size_t)n;
-            double x = ln[0] * lw, y = ln[1] * lw, z = ln[2] * lw;
-            a00 += x * x; a01 += x * y; a02 += x * z;
-            a11 += y * y; a12 += y * z; a22 += z * z;
-        }
+        for (int q = lane(); q < nw; q += WAVE) cnt += (member[q] == cidx);
         cnt = wave_sum_int(cnt);
-        a00 = wave_sum(a00); a01 = wave_sum(a01); a02 = wave_sum(a02);
-        a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
+        double vp[3] = {0, 0, 0};
+        if (cnt >= 3) {                                       // :592-593
+            // rows = lweight * l over the lines of this cluster (:580-595); evaluated over all N lines
+            // with weight 0 outside the cluster, so the gather order does not matter
+            const double* lwt = c.lweight;
+            wave_null_vector(c.l, N, [=](int n) { return lab[n] == cidx ? lwt[n] : 0.0; }, vp);
+        }
         if (lane() == 0) {
             double* o = sh.dbuf + 4 * cidx;
             o[3] = 0.0;
-            if (cnt >= 3) {                                   // :592-593
-                double vp[3];
-                eig3_smallest(a00, a01, a02, a11, a12, a22, vp);
+            if (cnt >= 3) {
                 if (vp[2] < 0) { vp[0] = -vp[0]; vp[1] = -vp[1]; vp[2] = -vp[2]; }   // :599-600
                 o[0] = vp[0]; o[1] = vp[1]; o[2] = vp[2]; o[3] = 1.0;
             }
@@ -1092,7 +1154,7 @@ VPK_DEVFN void split_vp(EmCtx& c) {
         double* v1 = sh.dbuf + 4;
         bool too_similar = true;                              // :604-615
         if (v0[3] != 0.0 && v1[3] != 0.0) {
-            double cphi = clip(v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2], -1.0, 1.0);
+            double cphi = clip(dot3(v0[0], v0[1], v0[2], v1[0], v1[1], v1[2]), -1.0, 1.0);
             double ang = fabs(acos(clip(fabs(cphi), -1.0, 1.0)));
             if (ang > c.prm.merge_thresh) too_similar = false;
         }
@@ -1127,8 +1189,9 @@ struct EmOut {
     int* status;
     unsigned* flags;
     double* metric;   // N x max_vp or null
-    double* trace;    // num_iter x 4 or null
+    double* trace;    // (num_iter + 1) x TRACE_COLS or null
     int max_vp;
+    double* dbg = nullptr;   // test hook: per iteration [M, s[0..MAXM), cur[0..3 MAXM)] before the E-step
 };
 
 VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
@@ -1207,7 +1270,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             int m = c.n_init < MAXM ? c.n_init : MAXM;
             for (int k = 0; k < m; ++k) {
                 const double* q = c.init_vp + 3 * (size_t)k;
-                double nr = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                double nr = norm3(q[0], q[1], q[2]);
                 sh.cur[3 * k] = q[0] / nr; sh.cur[3 * k + 1] = q[1] / nr; sh.cur[3 * k + 2] = q[2] / nr;
             }
             sh.M = m;
@@ -1241,6 +1304,12 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             split_vp(c);
             if (sh.M != mb) events += 1;
         }
+        if (o.dbg && tid() == 0) {
+            double* q = o.dbg + (size_t)i * (1 + 4 * MAXM);
+            q[0] = sh.M;
+            for (int m = 0; m < MAXM; ++m) q[1 + m] = sh.s[m];
+            for (int m = 0; m < 3 * MAXM; ++m) q[1 + MAXM + m] = sh.cur[m];
+        }
         lap(tk);
         estep(c, sh.cur);                                     // :273
         trace_put(o, i, 4, lap(tk));
@@ -1264,12 +1333,14 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
 
         if (max_err < P.final_convergence || i == P.num_iter - 1 || !P.do_iterations) {   // :335
             if (P.do_merge) merge_vps(c, true, merge_thresh_final);                       // :339
+            trace_put(o, P.num_iter, 3, (double)sh.M);        // finalisation audit trail: M after merge
             if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, i); return; }   // reference: argmax of empty (:349)
             estep(c, sh.cur);                                 // :344 (stale index i)
             smooth(c);                                        // :346
             assign_lines(c, false);                           // :349
             mstep(c, 1, max_stdd);                            // :353-392
             compact_vps(c);                                   // :394-396
+            trace_put(o, P.num_iter, 4, (double)sh.M);        // ... after the hard-assignment M-step
             estep(c, sh.cur);                                 // :398 (still index i)
             smooth(c);                                        // :400
             if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }               // :402-404
@@ -1281,6 +1352,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = !sh.icnt[m];
             block_sync();
             compact_vps(c);                                   // :412-413
+            trace_put(o, P.num_iter, 5, (double)sh.M);        // ... after keeping the VPs that win a line
             estep(c, sh.nxt);                                 // :415 (index i+1 at last)
             smooth(c);                                        // :417
             assign_lines(c, true);                            // :418
