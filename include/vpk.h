@@ -130,7 +130,8 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
  *   (decision_metric, [line][vp]), trace_out NULL or B x (num_iter+1) x 8 fp64
  *   (row i: M after the M-step, max_err, M at the end of the iteration, event bits, then device
  *   microseconds spent in E-step / smoothing / M-step / whole iteration; row num_iter: microseconds
- *   of pairwise setup, remaining setup, whole image). */
+ *   of pairwise setup, remaining setup, whole image, M after the final merge / hard M-step / winner
+ *   selection, then microseconds inside the single-pass smoother: staging + reduction, main loop). */
 int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
                  const float* cnn, const uint8_t* sphere, int sphere_size, const double* init_vp,
                  int n_init, const vpk_em_params* p, int max_vp, double* vp_out, double* sigma_out,

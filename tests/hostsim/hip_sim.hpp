@@ -15,12 +15,21 @@
 
 namespace vpk {
 
+#define VPK_GLOBAL
+typedef double* gdp;
+typedef const double* cgdp;
+typedef int* gip;
+typedef const float* cgfp;
+typedef const unsigned char* cgbp;
+
 constexpr int WAVE = 1;
 
 #define VPK_DEV static inline
 #define VPK_DEVFN static
 #define VPK_LDS static
 
+alignas(16) static unsigned char g_sim_lds[163840];
+VPK_DEV unsigned char* lds_base() { return g_sim_lds; }
 VPK_DEV int tid() { return 0; }
 VPK_DEV int nthreads() { return 1; }
 VPK_DEV int lane() { return 0; }
@@ -38,9 +47,11 @@ VPK_DEV int wave_max_int(int v) { return v; }
 VPK_DEV void wave_argmin(double&, int&) {}
 VPK_DEV double wave_bcast(double v, int) { return v; }
 VPK_DEV int wave_bcast_int(int v, int) { return v; }
-template <int C> VPK_DEV void load_cols(const double* p, double (&out)[C]) {
+template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]) {
     for (int q = 0; q < C; ++q) out[q] = p[q];
 }
+VPK_DEV void sched_fence() {}
+VPK_DEV void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
 VPK_DEV long long clock_ticks() { return 0; }
 constexpr double CLOCK_US = 0.01;
 VPK_DEV int atomic_add_int(int* p, int v) { int o = *p; *p += v; return o; }

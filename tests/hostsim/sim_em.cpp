@@ -7,8 +7,7 @@
 
 using namespace vpk;
 
-static Shared g_sh;
-static double g_wt[WT_DOUBLES];
+#define g_sh (SH())
 static std::vector<double> g_dbg;
 
 static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_params& p, bool has_init,
@@ -19,8 +18,7 @@ static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_par
     memset(&c, 0, sizeof(c));
     c.N = n;
     c.prm = p;
-    c.sh = &g_sh;
-    c.wt = g_wt;
+    c.wt_doubles = WT_DOUBLES;
     bind_scratch(c, buf.data(), L, p.do_split != 0);
 }
 

@@ -60,48 +60,55 @@ struct Shared {
     double part[PART_DOUBLES];
 };
 
+constexpr size_t SH_BYTES = (sizeof(Shared) + 15) / 16 * 16;
+// LDS layout of every EM kernel: [Shared | smoother operand panel]
+VPK_DEV Shared& SH() { return *reinterpret_cast<Shared*>(lds_base()); }
+VPK_DEV double* WT() { return reinterpret_cast<double*>(lds_base() + SH_BYTES); }
+
 struct EmCtx {
     int N;
     int ldn;   // row stride of the [m][n] arrays (N rounded up to 8)
     int ld;    // row stride of lsim
     int mcap;  // row stride of wsrc ([n][m]); multiple of MT
-    double* l;
-    const double* lp;
-    const float* cnn;
-    const unsigned char* sphere;
+    gdp l;
+    cgdp lp;
+    cgfp cnn;
+    cgbp sphere;
     int ssize;
-    const double* init_vp;
+    cgdp init_vp;
     int n_init;
     vpk_em_params prm;
     // per-slot global scratch
-    double* lsim;     // N x ld
-    double* den;      // N   : 1 + bias * lweight[k] * sum_j lsim[j][k]
-    double* lweight;  // N
-    double* langle;   // N
-    double* lscore;   // N
-    double* lvsq;     // [m][n]
-    double* pvl;      // [m][n]
-    double* w;        // [m][n]
-    double* wsrc;     // [n][mcap] : p_vl * lweight, VP index contiguous (broadcast reads)
-    double* drow;     // nwaves x ldn closest-distance rows (kNN selection)
-    double* cl;       // split: Nw x Nw cluster distances (NULL when do_split == 0)
-    int* assoc;       // N
-    int* idx;         // N (split: gathered line indices, cluster membership)
-    double* rowsum;   // N : sum_j lsim[j][k]
-    Shared* sh;
-    double* wt;       // LDS, WT_DOUBLES: operand tile of the smoother
+    gdp lsim;     // N x ld
+    gdp den;      // N   : 1 + bias * lweight[k] * sum_j lsim[j][k]
+    gdp lweight;  // N
+    gdp langle;   // N
+    gdp lscore;   // N
+    gdp lvsq;     // [m][n]
+    gdp pvl;      // [m][n]
+    gdp w;        // [m][n]
+    gdp wsrc;     // [n][mcap] : p_vl * lweight, VP index contiguous (broadcast reads)
+    gdp drow;     // nwaves x ldn closest-distance rows (kNN selection)
+    gdp cl;       // split: Nw x Nw cluster distances (NULL when do_split == 0)
+    gip assoc;    // N
+    gip idx;      // 3N (split: gathered line indices, cluster membership)
+    gdp rowsum;   // N : sum_j lsim[j][k]
+    int wt_doubles;   // its capacity (WT_DOUBLES, or more when the launch gives the workgroup a whole CU)
+    gdp part;     // global: nwaves x mcap x ldn row-slice partial sums of the smoother
 };
 
 // point the context's scratch pointers into one slot
-VPK_DEV void bind_scratch(EmCtx& c, double* base, const EmLayout& L, bool do_split) {
+VPK_DEV void bind_scratch(EmCtx& c, double* base_, const EmLayout& L, bool do_split) {
+    gdp base = (gdp)base_;
     c.ldn = L.ldn; c.ld = L.ld; c.mcap = L.mcap;
     c.lsim = base + L.lsim; c.den = base + L.den; c.lweight = base + L.lweight;
     c.langle = base + L.langle; c.lscore = base + L.lscore; c.lvsq = base + L.lvsq;
     c.pvl = base + L.pvl; c.w = base + L.w; c.wsrc = base + L.wsrc; c.drow = base + L.drow;
-    c.cl = do_split ? base + L.cl : nullptr;
+    c.cl = do_split ? base + L.cl : (gdp) nullptr;
     c.rowsum = base + L.rowsum;
-    c.assoc = (int*)(base + L.assoc);
-    c.idx = (int*)(base + L.idx);
+    c.part = base + L.part;
+    c.assoc = (gip)(base + L.assoc);
+    c.idx = (gip)(base + L.idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -109,6 +116,13 @@ VPK_DEV void bind_scratch(EmCtx& c, double* base, const EmLayout& L, bool do_spl
 // ---------------------------------------------------------------------------------------------
 VPK_DEV double clip(double x, double lo, double hi) {  // np.clip (NaN passes through)
     return x < lo ? lo : (x > hi ? hi : x);
+}
+// phase stopwatch (thread 0, after a barrier): returns microseconds since the previous call
+VPK_DEV double lap(long long& t) {
+    long long now = clock_ticks();
+    double us = (double)(now - t) * CLOCK_US;
+    t = now;
+    return us;
 }
 VPK_DEV bool is_nan(double x) { return x != x; }
 // The reference's scalar code calls np.dot / np.linalg.norm on 2- and 3-vectors; NumPy's BLAS
@@ -124,7 +138,8 @@ VPK_DEV double norm3(double x, double y, double z) { return sqrt(dot3(x, y, z, x
 VPK_DEV double sign_np(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : (x == 0 ? 0.0 : x)); }
 
 // workgroup-wide lexicographic (value, index) minimum; result to every thread
-VPK_DEVFN void block_argmin(Shared& sh, double& v, int& idx) {
+VPK_DEVFN void block_argmin(Shared&, double& v, int& idx) {
+    Shared& sh = SH();
     wave_argmin(v, idx);
     if (lane() == 0) {
         sh.red_v[wave_id()] = v;
@@ -144,7 +159,8 @@ VPK_DEVFN void block_argmin(Shared& sh, double& v, int& idx) {
     v = bv;
     idx = bi;
 }
-VPK_DEVFN double block_max(Shared& sh, double v) {
+VPK_DEVFN double block_max(Shared&, double v) {
+    Shared& sh = SH();
     v = wave_max(v);
     if (lane() == 0) sh.red_v[wave_id()] = v;
     block_sync();
@@ -160,7 +176,7 @@ VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a1
     double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
     for (int i = 0; i < 3; ++i)
         for (int k = 0; k < 3; ++k) J[i][k] = (i == k) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 32; ++sweep) {
+    for (int sweep = 0; sweep < 12; ++sweep) {
         double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
         if (!(off > 0)) break;
         for (int p = 0; p < 2; ++p) {
@@ -168,7 +184,7 @@ VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a1
                 double apq = A[p][q];
                 if (apq == 0) continue;
                 double g = 100.0 * fabs(apq);
-                if (sweep > 2 && fabs(A[p][p]) + g == fabs(A[p][p]) && fabs(A[q][q]) + g == fabs(A[q][q])) {
+                if (fabs(A[p][p]) + g == fabs(A[p][p]) && fabs(A[q][q]) + g == fabs(A[q][q])) {
                     A[p][q] = 0; A[q][p] = 0;                 // negligible against both diagonals
                     continue;
                 }
@@ -205,7 +221,7 @@ VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a1
 // direction are sums of small numbers (no cancellation against the large ones), and applies the
 // Jacobi correction -- an implicit one-sided Jacobi SVD, accurate like LAPACK's after 2-3 passes.
 template <class RowWeight>
-VPK_DEV void wave_null_vector(const double* l, int N, RowWeight rw, double out[3]) {
+VPK_DEV void wave_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     double ev[3] = {0, 0, 0};
     for (int pass = 0; pass < 5; ++pass) {
@@ -213,7 +229,7 @@ VPK_DEV void wave_null_vector(const double* l, int N, RowWeight rw, double out[3
         for (int n = lane(); n < N; n += WAVE) {
             const double r = rw(n);
             if (r == 0) continue;
-            const double* ln = l + 3 * (size_t)n;
+            cgdp ln = l + 3 * (size_t)n;
             double y0, y1, y2;
             if (pass == 0) {
                 y0 = r * ln[0]; y1 = r * ln[1]; y2 = r * ln[2];
@@ -238,6 +254,14 @@ VPK_DEV void wave_null_vector(const double* l, int N, RowWeight rw, double out[3
         for (int i = 0; i < 3; ++i)
             for (int k = 0; k < 3; ++k) V[i][k] = Vn[i][k];
         if (conv) break;
+        if (pass == 0) {
+            // normal-equations error of the bottom eigenvector ~ eps * ev_max / (ev_mid - ev_min):
+            // below 1e-13 when the two larger eigenvalues are within 1e3 -> no refinement needed
+            double lo = ev[0] < ev[1] ? ev[0] : ev[1]; lo = lo < ev[2] ? lo : ev[2];
+            double hi = ev[0] > ev[1] ? ev[0] : ev[1]; hi = hi > ev[2] ? hi : ev[2];
+            double mid = ev[0] + ev[1] + ev[2] - lo - hi;
+            if (mid - lo > 1e-3 * hi) break;
+        }
     }
     int b = 0;
     if (ev[1] < ev[b]) b = 1;
@@ -316,7 +340,7 @@ VPK_DEV double proximity(double d, double len_a, double len_b, double sigma) {
 // vp_localisation.py:185-186 and again :226 (the second pass divides by ~1)
 VPK_DEVFN void normalise_lines(EmCtx& c) {
     for (int n = tid(); n < c.N; n += nthreads()) {
-        double* r = c.l + 3 * (size_t)n;
+        gdp r = c.l + 3 * (size_t)n;
         for (int pass = 0; pass < 2; ++pass) {
             double nr = norm3(r[0], r[1], r[2]);
             r[0] /= nr; r[1] /= nr; r[2] /= nr;
@@ -329,9 +353,9 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 // :230) in ONE pass over the pairs: the closest distance is shared by both.  One wave per row,
 // lanes over columns (coalesced lsim stores).  Also lines_angles (:765-776).
 VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int N = c.N;
-    double* drow = c.drow + (size_t)wave_id() * c.ldn;
+    gdp drow = c.drow + (size_t)wave_id() * c.ldn;
     // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
     double* ks = sh.part + wave_id() * (4 * KNN1);
     const int k1 = N < KNN1 ? N : KNN1;
@@ -455,7 +479,7 @@ VPK_DEV double grid_centre(int i) {
 
 // pdf_params (probability_functions.py:62-96): keep the 100 strongest cells, normalise in f32.
 VPK_DEVFN void prior_setup(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     for (int i = tid(); i < NCELL; i += nthreads()) sh.wts[i] = c.cnn[i];
     block_sync();
     float* keep = (float*)sh.part;  // 400 floats
@@ -493,8 +517,8 @@ VPK_DEVFN void prior_setup(EmCtx& c) {
 // find_maxima (vp_localisation.py:13-31) + find_initial_vps (:111-165).  Leaves the VPs in
 // sh.cur (row-major cell order), sh.M = count.  Uses sh.part as scratch.
 VPK_DEVFN void initial_vps(EmCtx& c) {
-    Shared& sh = *c.sh;
-    const float* r = c.cnn;
+    Shared& sh = SH();
+    cgfp r = c.cnn;
     for (int i = tid(); i < NCELL; i += nthreads()) {
         int b = i / GRIDN, a = i % GRIDN;
         float vm = r[i];
@@ -579,7 +603,7 @@ VPK_DEVFN void initial_vps(EmCtx& c) {
 // ---------------------------------------------------------------------------------------------
 // X points at sh.cur or sh.nxt.  Writes lvsq[m][n], pvl[m][n], wsrc[n][m]; floors sh.s (:139).
 VPK_DEVFN void estep(EmCtx& c, const double* X) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     const double kk = -0.5 / (sh.sigma_prior * sh.sigma_prior);
     // prior p(v): one wave per VP, lanes over mixture components (calc_angles :252-259, calc_pdf :8-40)
@@ -614,7 +638,7 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     }
     block_sync();
     for (int n = tid(); n < N; n += nthreads()) {
-        const double* q = c.lp + 4 * (size_t)n;
+        cgdp q = c.lp + 4 * (size_t)n;
         double lmx = 0.5 * (q[0] + q[2]), lmy = 0.5 * (q[1] + q[3]);
         double v2x = q[0] - q[2], v2y = q[1] - q[3];
         double n2 = norm2(v2x, v2y);
@@ -632,7 +656,7 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
         }
         pl = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;        // :117
         double lw = c.lweight[n];
-        double* ws = c.wsrc + (size_t)n * c.mcap;
+        gdp ws = c.wsrc + (size_t)n * c.mcap;
         for (int m = 0; m < M; ++m) {
             double pvl = c.pvl[(size_t)m * c.ldn + n] / pl;  // calc_pvl :128
             c.pvl[(size_t)m * c.ldn + n] = pvl;
@@ -656,17 +680,17 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
 // wave-uniform broadcast.
 template <int C, int UNR>
 VPK_DEVFN void smooth_blocks(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     const int colw = WAVE * C;
     const int ncg = (N + colw - 1) / colw;
     const int ntile = (M + MT - 1) / MT;
     const int W = ntile * MT;                       // staged VPs per row (<= mcap)
     const int nblk = ncg * ntile;
-    int JC = WT_DOUBLES / W;                        // rows per LDS chunk
+    int JC = c.wt_doubles / W;                      // rows per LDS chunk
     if (JC > N) JC = N;
     const double bias = c.prm.wbias;
-    double* wt = c.wt;
+    double* wt = WT();
     for (int b0 = 0; b0 < nblk; b0 += nwaves()) {
         const int b = b0 + wave_id();
         const bool have = b < nblk;
@@ -687,7 +711,7 @@ VPK_DEVFN void smooth_blocks(EmCtx& c) {
             }
             block_sync();
             if (live) {
-                const double* lrow = c.lsim + (size_t)jc * c.ld + k;
+                cgdp lrow = c.lsim + (size_t)jc * c.ld + k;
                 const double* wrow = wt + tile * MT;
                 int j = 0;
                 for (; j + UNR <= jn; j += UNR) {
@@ -735,8 +759,144 @@ VPK_DEVFN void smooth_blocks(EmCtx& c) {
     block_sync();
 }
 
+// Single-pass smoother for images whose whole operand panel fits in LDS (N x W doubles).
+// lsim is read exactly ONCE per call: every lane keeps NT*8 VP accumulators for its C columns.
+// Work split: wave w owns row slice w (all waves equally loaded for any N) and walks every
+// column group; the row-slice partials go through an L2-resident scratch and are summed in a fixed
+// order (deterministic).  When the column groups divide evenly among the waves (ncg % nwaves == 0,
+// e.g. N = 1000 with C = 2) each wave instead owns whole column groups and writes results directly.
+// Loads are software-pipelined two batches deep so the L2/HBM latency of batch b+1 hides under the
+// FMAs of batch b.
+template <int NT, int C>
+VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
+    Shared& sh = SH();
+    constexpr int W = NT * MT;
+    // rows per prefetch batch: two batches are in flight per lane (16 rows x 16 B at C = 2 -- the bytes
+    // in flight, not occupancy, are what hides the ~1.5 us loaded memory latency), fewer when the
+    // accumulators already take most of the register file
+    constexpr int UNR = (NT * C >= 8) ? 4 : 8;
+    const int N = c.N;
+    const int M = sh.M - m0 < W ? sh.M - m0 : W;    // VPs handled by this call: [m0, m0 + M)
+    const double bias = c.prm.wbias;
+    double* wt = WT();
+    long long tq_ = clock_ticks();
+    for (int p = tid(); p < N * W; p += nthreads()) {
+        const int j = p / W, m = p - j * W;
+        wt[p] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m0 + m] : 0.0;
+    }
+    block_sync();
+    if (tid() == 0) sh.dbuf[8] += lap(tq_);
+    const int colw = WAVE * C;
+    const int ncg = (N + colw - 1) / colw;
+    const int nw = nwaves();
+    const bool direct = (ncg % nw) == 0;            // whole column groups per wave, no row slicing
+    const int R = direct ? 1 : nw;
+    const int slice = direct ? 0 : wave_id();
+    const int jchunk = (N + R - 1) / R;
+    const int j0 = slice * jchunk;
+    const int j1 = (j0 + jchunk) < N ? (j0 + jchunk) : N;
+    for (int cg = direct ? wave_id() : 0; cg < ncg; cg += direct ? nw : 1) {
+        const int k = cg * colw + lane() * C;
+        const bool live = k < N;
+        double acc[W][C];
+#pragma unroll
+        for (int t = 0; t < W; ++t)
+#pragma unroll
+            for (int q = 0; q < C; ++q) acc[t][q] = 0.0;
+        if (live) {
+            cgdp lcol = c.lsim + k;
+            double a0[UNR][C], a1[UNR][C];
+            double wb[2][MT];                       // operand double buffer: one 8-VP group ahead
+            int j = j0;
+            const int nfull = (j1 - j0) / UNR;      // full batches
+            if (nfull > 0) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) load_cols<C>(lcol + (size_t)(j + u) * c.ld, a0[u]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) wb[0][t] = wt[(size_t)j * W + t];
+            }
+            for (int b = 0; b < nfull; ++b) {
+                const bool more = b + 1 < nfull;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) load_cols<C>(lcol + (size_t)(j + UNR + u) * c.ld, a1[u]);
+                }
+                // UNR * NT steps, each: prefetch the next step's 8 operands, then 8*C FMAs on the current
+                // ones.  pin8 keeps the steps in order (registers stay bounded), the prefetch hides the
+                // LDS latency under the FMAs.
+#pragma unroll
+                for (int st = 0; st < UNR * NT; ++st) {
+                    const int u = st / NT, g = st % NT;
+                    const int nu = (st + 1) / NT, ng = (st + 1) % NT;
+                    int nrow = j + nu;                          // row of the next step
+                    if (st + 1 == UNR * NT) nrow = more ? j + UNR : j;   // last step: next batch (or a harmless re-read)
+                    const double* nw = wt + (size_t)nrow * W + ng * MT;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) wb[(st + 1) & 1][t] = nw[t];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int q = 0; q < C; ++q)
+                            acc[g * MT + t][q] = fma(wb[st & 1][t], a0[u][q], acc[g * MT + t][q]);
+#pragma unroll
+                    for (int q = 0; q < C; ++q)
+                        pin8(acc[g * MT][q], acc[g * MT + 1][q], acc[g * MT + 2][q], acc[g * MT + 3][q],
+                             acc[g * MT + 4][q], acc[g * MT + 5][q], acc[g * MT + 6][q], acc[g * MT + 7][q]);
+                }
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int q = 0; q < C; ++q) a0[u][q] = a1[u][q];
+                }
+                j += UNR;
+            }
+            for (; j < j1; ++j) {
+                double a[C];
+                load_cols<C>(lcol + (size_t)j * c.ld, a);
+                const double* wr = wt + (size_t)j * W;
+#pragma unroll
+                for (int t = 0; t < W; ++t) {
+                    const double wv = wr[t];
+#pragma unroll
+                    for (int q = 0; q < C; ++q) acc[t][q] = fma(wv, a[q], acc[t][q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int kk = k + q;
+                if (kk >= N) continue;
+                if (direct) {
+                    const double lw = c.lweight[kk], dn = c.den[kk];
+#pragma unroll
+                    for (int t = 0; t < W; ++t)
+                        if (t < M)
+                            c.w[(size_t)(m0 + t) * c.ldn + kk] =
+                                (wt[(size_t)kk * W + t] + bias * lw * acc[t][q]) / dn;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < W; ++t)
+                        if (t < M) c.part[((size_t)slice * c.mcap + t) * c.ldn + kk] = acc[t][q];
+                }
+            }
+        }
+    }
+    if (!direct) {
+        block_sync();
+        if (tid() == 0) sh.dbuf[9] += lap(tq_);
+        for (int p = tid(); p < M * N; p += nthreads()) {
+            const int t = p / N, kk = p - t * N;
+            double sum = 0.0;
+            for (int r = 0; r < R; ++r) sum += c.part[((size_t)r * c.mcap + t) * c.ldn + kk];   // fixed order
+            c.w[(size_t)(m0 + t) * c.ldn + kk] = (wt[(size_t)kk * W + t] + bias * c.lweight[kk] * sum) / c.den[kk];
+        }
+    }
+    block_sync();
+    if (tid() == 0) sh.dbuf[10] += lap(tq_);
+}
+
 VPK_DEVFN void smooth(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl
         for (int m = 0; m < M; ++m)
@@ -745,6 +905,25 @@ VPK_DEVFN void smooth(EmCtx& c) {
         return;
     }
     if (M == 0) return;
+    // one pass over lsim when the N x W operand panel fits in LDS; VPs beyond 32 take another pass
+    const int wneed = M > 32 ? 32 : ((M + MT - 1) / MT) * MT;
+    if ((long long)N * wneed <= c.wt_doubles) {
+        for (int m0 = 0; m0 < M; m0 += 32) {
+            const int mm = M - m0;
+            if (N > WAVE) {
+                if (mm <= 8) smooth_full<1, 2>(c, m0);
+                else if (mm <= 16) smooth_full<2, 2>(c, m0);
+                else if (mm <= 24) smooth_full<3, 2>(c, m0);
+                else smooth_full<4, 2>(c, m0);
+            } else {
+                if (mm <= 8) smooth_full<1, 1>(c, m0);
+                else if (mm <= 16) smooth_full<2, 1>(c, m0);
+                else if (mm <= 24) smooth_full<3, 1>(c, m0);
+                else smooth_full<4, 1>(c, m0);
+            }
+        }
+        return;
+    }
     if (N > WAVE) smooth_blocks<2, 8>(c);
     else smooth_blocks<1, 4>(c);
 }
@@ -754,7 +933,7 @@ VPK_DEVFN void smooth(EmCtx& c) {
 // ---------------------------------------------------------------------------------------------
 // np.argmax over VPs (first maximum; a NaN counts as the maximum).  hard = apply the outlier test.
 VPK_DEVFN void assign_lines(EmCtx& c, bool hard) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     for (int n = tid(); n < N; n += nthreads()) {
         int best = 0;
@@ -775,7 +954,7 @@ VPK_DEVFN void assign_lines(EmCtx& c, bool hard) {
     block_sync();
 }
 VPK_DEVFN void count_lines(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     for (int m = wave_id(); m < M; m += nwaves()) {
         int cnt = 0;
@@ -791,7 +970,7 @@ VPK_DEVFN void count_lines(EmCtx& c) {
 
 // remove the VPs flagged in sh.removed from cur / nxt / s (np.delete along the VP axis)
 VPK_DEVFN void compact_vps(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     if (tid() == 0) {
         int k = 0;
         for (int m = 0; m < sh.M; ++m) {
@@ -816,13 +995,19 @@ VPK_DEVFN void compact_vps(EmCtx& c) {
 // One wave per VP.  mode 0: soft (all lines, weights w[m]); mode 1: hard (lines with
 // assoc == m, :353-392).  On return sh.removed[] / sh.err[] are set; nxt and s updated.
 VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     for (int m = wave_id(); m < M; m += nwaves()) {
-        const double* wm = c.w + (size_t)m * c.ldn;
+        cgdp wm = c.w + (size_t)m * c.ldn;
         double wmax = -1e300;
         int nsel = 0, selidx = -1;
+        double sv = 0, sp = 0;
+        cgdp lvs = c.lvsq + (size_t)m * c.ldn;
+        cgdp pvl = c.pvl + (size_t)m * c.ldn;
         for (int n = lane(); n < N; n += WAVE) {
+            double pq = pvl[n];
+            sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
+            sp += pq;
             if (mode == 1 && c.assoc[n] != m) continue;
             wmax = nanmax(wmax, wm[n]);
             ++nsel;
@@ -831,24 +1016,16 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         wmax = wave_max(wmax);
         nsel = wave_sum_int(nsel);
         selidx = wave_max_int(selidx);
+        sv = wave_sum(sv);
+        sp = wave_sum(sp);
         if (mode == 1 && nsel == 0) {                         // :355-356 `continue`
             if (lane() == 0) { sh.removed[m] = 0; sh.err[m] = -1.0; }
             continue;
         }
         bool valid = nsel > 0 && (wmax > 0 || wmax < 0);      // :456-460; NaN -> LinAlgError -> None
-        double sv = 0, sp = 0;
-        const double* lvs = c.lvsq + (size_t)m * c.ldn;
-        const double* pvl = c.pvl + (size_t)m * c.ldn;
-        for (int n = lane(); n < N; n += WAVE) {
-            double pq = pvl[n];
-            sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
-            sp += pq;
-        }
-        sv = wave_sum(sv);
-        sp = wave_sum(sp);
         double vp[3] = {0, 0, 0};
         if (valid && nsel > 1) {
-            const int* assoc = c.assoc;
+            const VPK_GLOBAL int* assoc = c.assoc;
             // row weight w / max w (:462; hard mode: :358 then / 1 at :462)
             wave_null_vector(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
         }
@@ -859,7 +1036,7 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
                 rem = 1;                                      // newVP is None (:294-296)
             } else {
                 if (nsel == 1) {                              // one row: LAPACK's reflector decides
-                    const double* ln = c.l + 3 * (size_t)selidx;
+                    cgdp ln = c.l + 3 * (size_t)selidx;
                     lapack_null_1row(ln[0], ln[1], ln[2], vp);    // the row is (w/max w) * l = 1 * l
                     double nr = norm3(vp[0], vp[1], vp[2]);
                     vp[0] /= nr; vp[1] /= nr; vp[2] /= nr;    // :472
@@ -902,7 +1079,7 @@ VPK_DEV double max_err_of(const Shared& sh, int M) {
 // merge_vps (vp_localisation.py:633-697)
 // ---------------------------------------------------------------------------------------------
 VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int N = c.N;
     for (int guard = 0; guard < 4 * MAXM; ++guard) {
         const int M = sh.M;
@@ -922,17 +1099,17 @@ VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
         estep(c, X);                                          // :658 (at the caller's index)
         smooth(c);
         if (wave_id() == 0) {                                 // newVP from w[j] + w[k] (:661)
-            const double* wj = c.w + (size_t)j * c.ldn;
-            const double* wk = c.w + (size_t)k * c.ldn;
+            cgdp wj = c.w + (size_t)j * c.ldn;
+            cgdp wk = c.w + (size_t)k * c.ldn;
             double wmax = -1e300;
             for (int n = lane(); n < N; n += WAVE) wmax = nanmax(wmax, wj[n] + wk[n]);
             wmax = wave_max(wmax);
             bool valid = N > 0 && (wmax > 0 || wmax < 0);
             double sv = 0, sp = 0;
-            const double* lj = c.lvsq + (size_t)j * c.ldn;
-            const double* lk = c.lvsq + (size_t)k * c.ldn;
-            const double* pj = c.pvl + (size_t)j * c.ldn;
-            const double* pk = c.pvl + (size_t)k * c.ldn;
+            cgdp lj = c.lvsq + (size_t)j * c.ldn;
+            cgdp lk = c.lvsq + (size_t)k * c.ldn;
+            cgdp pj = c.pvl + (size_t)j * c.ldn;
+            cgdp pk = c.pvl + (size_t)k * c.ldn;
             for (int n = lane(); n < N; n += WAVE) {
                 double pq = pk[n] + pj[n];
                 sv += 0.5 * (lj[n] + lk[n]) * pq;             // :664
@@ -972,7 +1149,8 @@ VPK_DEVFN void merge_vps(EmCtx& c, bool use_next, double thresh) {
 // smallest matrix position, and VPK_EM_FLAG_SPLIT_TIE is raised.
 // D: n x n working copy in global memory (destroyed); member: n ints; labels -> member (0/1).
 // ---------------------------------------------------------------------------------------------
-VPK_DEVFN void cluster2(Shared& sh, int n, double* D, int* member, int* csize) {
+VPK_DEVFN void cluster2(Shared&, int n, gdp D, gip member, gip csize) {
+    Shared& sh = SH();
     for (int p = tid(); p < n * n; p += nthreads()) {
         int a = p / n, b = p % n;
         double v = D[p];
@@ -1037,7 +1215,7 @@ VPK_DEVFN void cluster2(Shared& sh, int n, double* D, int* member, int* csize) {
 // split_best_vp (vp_localisation.py:527-630).  Expects w = weight matrix of sh.cur.
 // ---------------------------------------------------------------------------------------------
 VPK_DEVFN void split_vp(EmCtx& c) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int M = sh.M, N = c.N;
     if (M == 0 || c.cl == nullptr) return;
     assign_lines(c, false);                                   // weightIndices (:536) == vpAssoc (:551)
@@ -1110,20 +1288,20 @@ VPK_DEVFN void split_vp(EmCtx& c) {
         int a = p / nw, b = p % nw;
         double v = 0.0;
         if (a != b) {
-            const double* qa = c.lp + 4 * (size_t)c.idx[a];
-            const double* qb = c.lp + 4 * (size_t)c.idx[b];
+            cgdp qa = c.lp + 4 * (size_t)c.idx[a];
+            cgdp qb = c.lp + 4 * (size_t)c.idx[b];
             double la[4] = {qa[0], qa[1], qa[2], qa[3]}, lb[4] = {qb[0], qb[1], qb[2], qb[3]};
             v = 1 - lines_cosangle(la, lb, 2.0);
         }
         c.cl[p] = v;
     }
     block_sync();
-    int* member = c.idx + N;          // idx has room for 3N ints
-    int* csize = c.idx + 2 * N;
+    gip member = c.idx + N;          // idx has room for 3N ints
+    gip csize = c.idx + 2 * N;
     cluster2(sh, nw, c.cl, member, csize);
     // per cluster: smallest right singular vector of the lweight-scaled lines (:580-602)
     // cluster label per line (-1 = not in the set), in the assoc scratch (recomputed before next use)
-    int* lab = c.assoc;
+    gip lab = c.assoc;
     for (int n = tid(); n < N; n += nthreads()) lab[n] = -1;
     block_sync();
     for (int q = tid(); q < nw; q += nthreads()) lab[c.idx[q]] = member[q];
@@ -1136,7 +1314,7 @@ VPK_DEVFN void split_vp(EmCtx& c) {
         if (cnt >= 3) {                                       // :592-593
             // rows = lweight * l over the lines of this cluster (:580-595); evaluated over all N lines
             // with weight 0 outside the cluster, so the gather order does not matter
-            const double* lwt = c.lweight;
+            cgdp lwt = c.lweight;
             wave_null_vector(c.l, N, [=](int n) { return lab[n] == cidx ? lwt[n] : 0.0; }, vp);
         }
         if (lane() == 0) {
@@ -1195,7 +1373,7 @@ struct EmOut {
 };
 
 VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const int N = c.N;
     int M = status == VPK_EM_OK ? sh.M : 0;
     if (M > o.max_vp) {
@@ -1232,24 +1410,18 @@ VPK_DEV void trace_put(EmOut& o, int i, int slot, double v) {
 VPK_DEV void trace_add(EmOut& o, int i, int slot, double v) {
     if (o.trace && tid() == 0) o.trace[TRACE_COLS * i + slot] += v;
 }
-// phase stopwatch (thread 0, after a barrier): returns microseconds since the previous call
-VPK_DEV double lap(long long& t) {
-    long long now = clock_ticks();
-    double us = (double)(now - t) * CLOCK_US;
-    t = now;
-    return us;
-}
+
 
 // ---------------------------------------------------------------------------------------------
 // the driver: expectation_maximisation (vp_localisation.py:168-450)
 // ---------------------------------------------------------------------------------------------
 VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
-    Shared& sh = *c.sh;
+    Shared& sh = SH();
     const vpk_em_params& P = c.prm;
     const double max_stdd = 1e-6;                             // :196-198 ("angle")
     const double merge_thresh_final = P.merge_thresh * 10;    // :190
     const int split_merge_it = 100;                           // :193
-    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; }
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.dbuf[8] = 0; sh.dbuf[9] = 0; sh.dbuf[10] = 0; }
     block_sync();
     if (o.trace)
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;
@@ -1269,7 +1441,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         if (tid() == 0) {
             int m = c.n_init < MAXM ? c.n_init : MAXM;
             for (int k = 0; k < m; ++k) {
-                const double* q = c.init_vp + 3 * (size_t)k;
+                cgdp q = c.init_vp + 3 * (size_t)k;
                 double nr = norm3(q[0], q[1], q[2]);
                 sh.cur[3 * k] = q[0] / nr; sh.cur[3 * k + 1] = q[1] / nr; sh.cur[3 * k + 2] = q[2] / nr;
             }
@@ -1375,6 +1547,8 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             trace_put(o, i, 3, events + 2);
             trace_put(o, i, 7, (double)(clock_ticks() - t_iter) * CLOCK_US);
             trace_put(o, P.num_iter, 2, (double)(clock_ticks() - t_begin) * CLOCK_US);
+            trace_put(o, P.num_iter, 6, sh.dbuf[8] + sh.dbuf[10]);   // smoother: operand staging + partial reduction
+            trace_put(o, P.num_iter, 7, sh.dbuf[9]);                  // smoother: main loop (wave 0)
             write_result(c, o, VPK_EM_OK, i);                 // :439-442
             return;
         }

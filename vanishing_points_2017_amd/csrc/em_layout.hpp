@@ -14,7 +14,7 @@ namespace vpk {
 
 struct EmLayout {
     int ldn, ld, mcap, nwaves;
-    size_t lsim, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, cl, assoc, idx;
+    size_t lsim, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, part, cl, assoc, idx;
     size_t total_doubles;
 };
 
@@ -54,6 +54,7 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.w = o;       o += (size_t)mcap * n;
     L.wsrc = o;    o += n * (size_t)mcap;
     L.drow = o;    o += (size_t)nwaves * n;
+    L.part = o;    o += (size_t)nwaves * mcap * n;   // row-slice partials of the smoother
     L.cl = o;      o += do_split ? n * n : 8;
     L.assoc = o;   o += em_align(n, 2) / 2;            // n ints
     L.idx = o;     o += em_align(3 * n, 2) / 2;        // 3n ints

@@ -14,14 +14,16 @@ using namespace vpk;
 
 namespace {
 
-constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD, up to 3 workgroups per CU by LDS
+constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD, up to 2 workgroups per CU by LDS
 constexpr int EM_WAVES = EM_THREADS / 64;
 // dynamic LDS: [Shared | smoother operand tile]; ~77 KiB -> two workgroups per CU (160 KiB)
-constexpr size_t SH_BYTES = (sizeof(Shared) + 15) / 16 * 16;
 constexpr size_t EM_LDS_BYTES = SH_BYTES + WT_DOUBLES * sizeof(double);
-extern __shared__ __attribute__((aligned(16))) unsigned char vpk_smem[];
-#define VPK_SHARED_DECL Shared& sh = *reinterpret_cast<Shared*>(vpk_smem)
-#define VPK_WT (reinterpret_cast<double*>(vpk_smem + SH_BYTES))
+// when a batch leaves at most one workgroup per CU, the workgroup takes (almost) the whole 160 KiB so
+// that the smoother's operand panel of any YUD/ECD-sized image fits and lsim is read once per E-step
+constexpr int WT_DOUBLES_BIG = 16384;   // 128 KiB
+constexpr size_t EM_LDS_BYTES_BIG = SH_BYTES + WT_DOUBLES_BIG * sizeof(double);
+static_assert(EM_LDS_BYTES_BIG <= 163840, "LDS per CU");
+#define VPK_SHARED_DECL Shared& sh = SH()
 
 struct EmBatchArgs {
     int B;
@@ -50,6 +52,7 @@ struct EmBatchArgs {
     unsigned* flags_out;
     double* metric_out;
     double* trace_out;
+    int wt_doubles;
 };
 
 __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
@@ -64,15 +67,15 @@ __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
         const long long off = a.offsets[img];
         EmCtx c;
         c.N = (int)(a.offsets[img + 1] - off);
-        c.l = a.l + 3 * off;
-        c.lp = a.lp + 4 * off;
-        c.cnn = a.cnn + (size_t)img * NCELL;
-        c.sphere = a.sphere + (size_t)img * a.ssize * a.ssize;
+        c.l = (gdp)(a.l + 3 * off);
+        c.lp = (cgdp)(a.lp + 4 * off);
+        c.cnn = (cgfp)(a.cnn + (size_t)img * NCELL);
+        c.sphere = (cgbp)(a.sphere + (size_t)img * a.ssize * a.ssize);
         c.ssize = a.ssize;
-        c.init_vp = a.init_vp ? a.init_vp + (size_t)img * a.n_init * 3 : nullptr;
+        c.init_vp = a.init_vp ? (cgdp)(a.init_vp + (size_t)img * a.n_init * 3) : (cgdp) nullptr;
         c.n_init = a.n_init;
         c.prm = a.prm;
-        c.sh = &sh; c.wt = VPK_WT;
+        c.wt_doubles = a.wt_doubles;
         bind_scratch(c, a.scratch + (size_t)block_id() * a.L.total_doubles, a.L, a.prm.do_split != 0);
         EmOut o;
         o.max_vp = a.max_vp;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const doubl
                                                               double* langle_out) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.lp = lp; c.sh = &sh; c.wt = VPK_WT;
+    c.N = n; c.lp = (cgdp)lp; c.wt_doubles = WT_DOUBLES;
     c.prm.use_weights = 1;
     bind_scratch(c, ws, L, false);
     pairwise_setup(c, true);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(EM_THREADS) void init_vps_kernel(const float* cnn, 
                                                               int* m0_out, float* weights_out) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = 0; c.cnn = cnn; c.sphere = sphere; c.ssize = ssize; c.sh = &sh; c.wt = VPK_WT;
+    c.N = 0; c.cnn = (cgfp)cnn; c.sphere = (cgbp)sphere; c.ssize = ssize; c.wt_doubles = WT_DOUBLES;
     c.prm.num_init_vp = num_max;
     initial_vps(c);
     for (int k = tid(); k < 3 * sh.M; k += nthreads()) v0_out[k] = sh.cur[k];
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const d
                                                            double* p_l_out) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.lp = lp; c.cnn = cnn; c.sh = &sh; c.wt = VPK_WT;
+    c.N = n; c.lp = (cgdp)lp; c.cnn = (cgfp)cnn; c.wt_doubles = WT_DOUBLES;
     c.prm.use_weights = 1;
     bind_scratch(c, ws, L, false);
     prior_setup(c);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m,
                                                                    double* w_out) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.sh = &sh; c.wt = VPK_WT;
+    c.N = n; c.wt_doubles = WT_DOUBLES;
     c.prm.use_weights = 1;
     c.prm.wbias = bias;
     bind_scratch(c, ws, L, false);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const d
                                                            int* valid_out) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.l = const_cast<double*>(l); c.sh = &sh; c.wt = VPK_WT;
+    c.N = n; c.l = (gdp) const_cast<double*>(l); c.wt_doubles = WT_DOUBLES;
     c.prm.s_thresh = 1e-200;
     bind_scratch(c, ws, L, false);
     if (tid() == 0) sh.M = m;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, 
     VPK_SHARED_DECL;
     if (tid() == 0) sh.flags = 0;
     block_sync();
-    cluster2(sh, n, D, member, csize);
+    cluster2(sh, n, (gdp)D, (gip)member, (gip)csize);
     for (int q = tid(); q < n; q += nthreads()) labels_out[q] = member[q];
     if (tid() == 0) *flags_out = sh.flags;
 }
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, 
 template <typename K>
 int allow_lds(vpk_handle* h, K kernel) {
     VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EM_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EM_LDS_BYTES_BIG));
     return VPK_OK;
 }
 int em_prepare(vpk_handle* h) {
@@ -339,7 +342,9 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.vp_out = vp_out; a.sigma_out = sigma_out; a.counts_out = counts_out; a.counts_w_out = counts_w_out;
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, a);
+    const bool big = slots <= h->num_cu;             // one workgroup per CU at most
+    a.wt_doubles = big ? WT_DOUBLES_BIG : WT_DOUBLES;
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), big ? EM_LDS_BYTES_BIG : EM_LDS_BYTES, h->stream, a);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }

@@ -10,14 +10,30 @@
 #include <math.h>
 #include <stdint.h>
 
+// The one dynamic-LDS symbol of every EM kernel.  Device functions derive their LDS pointers from
+// this symbol (not from pointers stored in structs) so the compiler can prove address space 3 and
+// emit ds_read/ds_write instead of flat accesses, also in non-inlined functions.
+extern __shared__ __attribute__((aligned(16))) unsigned char vpk_smem[];
+
 namespace vpk {
+
+// HBM pointers carry the global address space explicitly: device functions that are not inlined into
+// the kernel would otherwise see generic pointers and emit flat_* accesses, which also count on
+// lgkmcnt and so serialise against the LDS operand reads of the smoother.
+#define VPK_GLOBAL __attribute__((address_space(1)))
+typedef VPK_GLOBAL double* gdp;
+typedef const VPK_GLOBAL double* cgdp;
+typedef VPK_GLOBAL int* gip;
+typedef const VPK_GLOBAL float* cgfp;
+typedef const VPK_GLOBAL unsigned char* cgbp;
 
 constexpr int WAVE = 64;  // CDNA4 wavefront width (hard-coded on purpose)
 
 #define VPK_DEV __device__ __forceinline__
-#define VPK_DEVFN __device__
+#define VPK_DEVFN __device__ __attribute__((noinline))
 #define VPK_LDS __shared__
 
+VPK_DEV unsigned char* lds_base() { return vpk_smem; }
 VPK_DEV int tid() { return (int)threadIdx.x; }
 VPK_DEV int nthreads() { return (int)blockDim.x; }
 VPK_DEV int lane() { return (int)(threadIdx.x & 63u); }
@@ -76,12 +92,26 @@ VPK_DEV double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane); 
 VPK_DEV int wave_bcast_int(int v, int src_lane) { return __shfl(v, src_lane); }
 
 // C adjacent doubles as one load: 16-byte global_load_dwordx4 when C == 2 (p must be 16-byte aligned)
-template <int C> VPK_DEV void load_cols(const double* p, double (&out)[C]);
-template <> VPK_DEV void load_cols<1>(const double* p, double (&out)[1]) { out[0] = p[0]; }
-template <> VPK_DEV void load_cols<2>(const double* p, double (&out)[2]) {
-    const double2 v = *reinterpret_cast<const double2*>(p);
+template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]);
+template <> VPK_DEV void load_cols<1>(cgdp p, double (&out)[1]) { out[0] = p[0]; }
+template <> VPK_DEV void load_cols<2>(cgdp p, double (&out)[2]) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t v = *reinterpret_cast<const VPK_GLOBAL d2_t*>(p);   // one global_load_dwordx4
     out[0] = v.x;
     out[1] = v.y;
+}
+
+// scheduling fence: the compiler may not move instructions across it (keeps the unrolled rows of the
+// smoother from hoisting all their LDS operand reads to the top and spilling)
+VPK_DEV void sched_fence() {
+    asm volatile("" ::: "memory");          // IR level: no load/store motion across this point
+    __builtin_amdgcn_sched_barrier(0);     // machine scheduler: nothing moves across
+}
+
+// pin eight accumulators: everything that produces them is complete before this point and no memory
+// access moves across it (an empty asm the optimiser must treat as reading+writing the values)
+VPK_DEV void pin8(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7) {
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "memory");
 }
 
 // constant-rate (100 MHz) device clock for the optional phase timing in the EM trace
