@@ -46,6 +46,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ wp,
                                                                  const float* __restrict__ bias,
+                                                                 const int2* __restrict__ ktab,
                                                                  float* __restrict__ out) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
@@ -91,6 +92,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
     const size_t in_base = ((size_t)b * d.groups * d.IC + (size_t)g * d.IC) * d.H * d.W;
     const float* inf = reinterpret_cast<const float*>(in_);
     const unsigned char* inu = reinterpret_cast<const unsigned char*>(in_);
+    // im2col addressing: element (k, n) sits at patch origin + ktab[k].x, where the per-layer table
+    // holds x = ic*H*W + kh*W + kw and y = kh << 16 | kw (built once at load time).  k is uniform per
+    // wave, so the table reads are scalar loads; per element only two adds and two unsigned compares
+    // remain on the vector ALU.
+    const float* inf_n = inf + in_base;
+    const unsigned char* inu_n = inu + in_base;
+    const int patch0 = ih0 * d.W + iw0;                    // may be negative (padding)
+    const int kset_u = __builtin_amdgcn_readfirstlane(kset);
 
     float4 a_reg[(BK * BM) / (CONV_THREADS * 4) + 1];
     float b_reg[8];
@@ -120,20 +129,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
                 for (int q = 0; q < 8; ++q) b_reg[q] = (n_ok && k0 + kset * 8 + q < d.K) ? row[q] : 0.f;
             }
         } else {
+            const int2* tab = ktab + k0 + kset_u * 8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                int k = k0 + kset * 8 + q;
-                int ic = k / (KH * KW);
-                int rem = k - ic * (KH * KW);
-                int kh = rem / KW, kw = rem - kh * KW;
-                int ih = ih0 + kh, iw = iw0 + kw;
-                float v = 0.f;
-                if (n_ok && k < d.K && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
-                    size_t off = in_base + ((size_t)ic * d.H + ih) * d.W + iw;
-                    if (U8IN) v = (float)inu[off] - mean[(size_t)ih * d.W + iw];   // evaluation.py:35
-                    else v = inf[off];
-                }
-                b_reg[q] = v;
+                const int2 e = tab[q];
+                const int ih = ih0 + (e.y >> 16), iw = iw0 + (e.y & 0xffff);
+                const bool ok = n_ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+                // unconditional load from a clamped (always valid) address + select: a load under a
+                // branch has to be waited for at the merge, which would serialise the 8 gathers
+                const int rel = ok ? patch0 + e.x : 0;
+                float v;
+                if (U8IN) v = (float)inu_n[rel] - mean[rel];       // evaluation.py:35 (IC = 1: same offset)
+                else v = inf_n[rel];
+                b_reg[q] = ok ? v : 0.f;
             }
         }
     };
@@ -283,6 +291,7 @@ struct Layer {
     ConvDims d;
     float* wp = nullptr;     // packed weights
     float* bias = nullptr;
+    int2* ktab = nullptr;    // im2col table (conv layers)
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -309,6 +318,7 @@ void vpk_cnn_free(vpk_handle* h) {
     for (auto& l : h->cnn->L) {
         if (l.wp) (void)hipFree(l.wp);
         if (l.bias) (void)hipFree(l.bias);
+        if (l.ktab) (void)hipFree(l.ktab);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
@@ -347,7 +357,7 @@ void launch_conv(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const
                  const Layer& l, float* out) {
     long long ntiles = (d.N + 127) / 128;
     long long blocks = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, mean, l.wp, l.bias, out);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, mean, l.wp, l.bias, l.ktab, out);
 }
 
 int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
@@ -488,6 +498,21 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                            l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
         VPK_HIP(h, hipStreamSynchronize(h->stream));
         VPK_HIP(h, hipFree(raw));
+        if (li < 5) {   // convolution: im2col table, padded entries fail the bounds test
+            std::vector<int2> tab(d.Kp);
+            for (int k = 0; k < d.Kp; ++k) {
+                if (k < d.K) {
+                    int ic = k / (t.KH * t.KH), r = k % (t.KH * t.KH), kh = r / t.KH, kw = r % t.KH;
+                    tab[k].x = ic * t.H * t.W + kh * t.W + kw;
+                    tab[k].y = (kh << 16) | kw;
+                } else {
+                    tab[k].x = 0;
+                    tab[k].y = (0x4000 << 16) | 0x4000;
+                }
+            }
+            VPK_HIP(h, hipMalloc((void**)&l.ktab, tab.size() * sizeof(int2)));
+            VPK_HIP(h, hipMemcpy(l.ktab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
         VPK_HIP(h, hipMalloc((void**)&l.bias, (size_t)t.G * t.OC * sizeof(float)));
         VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
     }
