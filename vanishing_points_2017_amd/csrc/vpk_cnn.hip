@@ -41,43 +41,54 @@ struct ConvDims {
 //   C[m][n] = sum_k Wp[k][m] * X[k][n],  m = output channel, n = (b, oh, ow), k = (ic, kh, kw)
 // WAVES_M x WAVES_N waves, each owning TM x TN MFMA tiles of 32 x 32.
 // --------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int TM, int TN, int KH, int KW, int STRIDE, int PAD, bool U8IN, bool DENSE>
-__global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, const void* __restrict__ in_,
-                                                                 const float* __restrict__ mean,
-                                                                 const float* __restrict__ wp,
-                                                                 const float* __restrict__ bias,
-                                                                 const int2* __restrict__ ktab,
-                                                                 float* __restrict__ out) {
+// LDS-DMA implicit GEMM (every conv / dense layer; conv1's input is pre-converted to fp32):
+// both operand tiles go HBM -> LDS with global_load_lds (no staging VGPRs, no ds_write), three LDS
+// stages, raw s_barrier + counted s_waitcnt vmcnt(N) so that the DMA of stage t+2 stays in flight
+// across the barrier that publishes stage t+1 (cdna_hip_programming.md T3/T4).  The weights panel is
+// lane-linear 16-byte pieces; the im2col panel is one 4-byte gather per lane, lanes = 64 consecutive
+// output positions of one k row, so the LDS image Bs[k][n] is lane-linear too; out-of-range taps
+// read a zero word.
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE>
+__global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
+                                                                     const float* __restrict__ wp,
+                                                                     const float* __restrict__ bias,
+                                                                     const int2* __restrict__ ktab,
+                                                                     const float* __restrict__ zero,
+                                                                     float* __restrict__ out, int stride,
+                                                                     int pad) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
-    static_assert(WAVES_M * WAVES_N * 64 == CONV_THREADS, "4 waves");
     static_assert(BN == 128, "the B-tile loader assumes 128 columns");
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) float As[NST][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[NST][BK][BN];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int mtiles = d.Mp / BM;
-    // blockIdx.x = ((g * ksplit + ks) * ntiles + nt) * mtiles + mt : m-tile fastest so that the
-    // blocks sharing one im2col panel are launched together
     int bid = blockIdx.x;
     const int mt = bid % mtiles; bid /= mtiles;
     const long long ntiles = (d.N + BN - 1) / BN;
     const int nt = (int)(bid % ntiles); bid = (int)(bid / ntiles);
     const int ks = bid % d.ksplit;
     const int g = bid / d.ksplit;
-
     const int ksteps_total = d.Kp / BK;
     const int ksteps_per = (ksteps_total + d.ksplit - 1) / d.ksplit;
     const int kt0 = ks * ksteps_per;
     const int kt1 = (kt0 + ksteps_per) < ksteps_total ? (kt0 + ksteps_per) : ksteps_total;
+    const float* wpan = wp + (size_t)g * d.Kp * d.Mp + (size_t)mt * BM;
 
-    const float* wpan = wp + (size_t)g * d.Kp * d.Mp + (size_t)mt * BM;   // [Kp][Mp] panel of this group
-
-    // ---- B-tile loader state: this thread always serves column n_local and 8 consecutive k ----
     const int n_local = tid & 127;
-    const int kset = tid >> 7;                       // 0/1 -> k offsets 0..7 / 8..15 of the stage
+    const int kset = wave >> 1;                       // waves 0,1 -> k 0..7 ; waves 2,3 -> k 8..15
     const long long n = (long long)nt * BN + n_local;
     const bool n_ok = n < d.N;
     const int ohw = d.OH * d.OW;
@@ -88,76 +99,57 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
         oh = r / d.OW;
         ow = r - oh * d.OW;
     }
-    const int ih0 = oh * STRIDE - PAD, iw0 = ow * STRIDE - PAD;
-    const size_t in_base = ((size_t)b * d.groups * d.IC + (size_t)g * d.IC) * d.H * d.W;
-    const float* inf = reinterpret_cast<const float*>(in_);
-    const unsigned char* inu = reinterpret_cast<const unsigned char*>(in_);
-    // im2col addressing: element (k, n) sits at patch origin + ktab[k].x, where the per-layer table
-    // holds x = ic*H*W + kh*W + kw and y = kh << 16 | kw (built once at load time).  k is uniform per
-    // wave, so the table reads are scalar loads; per element only two adds and two unsigned compares
-    // remain on the vector ALU.
-    const float* inf_n = inf + in_base;
-    const unsigned char* inu_n = inu + in_base;
-    const int patch0 = ih0 * d.W + iw0;                    // may be negative (padding)
-    const int kset_u = __builtin_amdgcn_readfirstlane(kset);
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    const float* in_n = DENSE ? in + (size_t)(n_ok ? n : 0) * d.K
+                              : in + ((size_t)b * d.groups * d.IC + (size_t)g * d.IC) * d.H * d.W;
+    const int patch0 = ih0 * d.W + iw0;
 
-    float4 a_reg[(BK * BM) / (CONV_THREADS * 4) + 1];
-    float b_reg[8];
-    constexpr int A_F4 = (BK * BM) / 4;              // float4 per A stage
-
-    auto load_tile = [&](int kt) {
+    constexpr int A_F4 = (BK * BM) / 4;
+    constexpr int A_IT = (A_F4 + CONV_THREADS - 1) / CONV_THREADS;
+    auto issue = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        // A: k-major panel rows are contiguous in m -> coalesced float4
 #pragma unroll
-        for (int r = 0; r * CONV_THREADS < A_F4; ++r) {
-            int idx = tid + r * CONV_THREADS;
-            if (idx < A_F4) {
-                int kk = (idx * 4) / BM, m = (idx * 4) % BM;
-                a_reg[r] = *reinterpret_cast<const float4*>(wpan + (size_t)(k0 + kk) * d.Mp + m);
+        for (int r = 0; r < A_IT; ++r) {
+            const int idx0 = r * CONV_THREADS + wave * 64;         // wave-uniform first float4 of this piece
+            if (idx0 < A_F4) {
+                const int idx = idx0 + lane;
+                const int kk = (idx * 4) / BM, m = (idx * 4) % BM;
+                const float* src = wpan + (size_t)(k0 + kk) * d.Mp + m;
+                float* dst = &As[buf][0][0] + (size_t)idx0 * 4;    // hardware adds lane * 16
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
             }
         }
-        // B: gather
-        if (DENSE) {
-            const float* row = inf + (size_t)n * d.K + k0 + kset * 8;
-            if (n_ok && k0 + kset * 8 + 8 <= d.K) {
-                float4 v0 = *reinterpret_cast<const float4*>(row);
-                float4 v1 = *reinterpret_cast<const float4*>(row + 4);
-                b_reg[0] = v0.x; b_reg[1] = v0.y; b_reg[2] = v0.z; b_reg[3] = v0.w;
-                b_reg[4] = v1.x; b_reg[5] = v1.y; b_reg[6] = v1.z; b_reg[7] = v1.w;
+        const int2* tab = ktab + k0 + kset * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float* src;
+            if (DENSE) {
+                const int k = k0 + kset * 8 + q;
+                src = (n_ok && k < d.K) ? in_n + k : zero;
             } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) b_reg[q] = (n_ok && k0 + kset * 8 + q < d.K) ? row[q] : 0.f;
-            }
-        } else {
-            const int2* tab = ktab + k0 + kset_u * 8;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
                 const int2 e = tab[q];
                 const int ih = ih0 + (e.y >> 16), iw = iw0 + (e.y & 0xffff);
                 const bool ok = n_ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-                // unconditional load from a clamped (always valid) address + select: a load under a
-                // branch has to be waited for at the merge, which would serialise the 8 gathers
-                const int rel = ok ? patch0 + e.x : 0;
-                float v;
-                if (U8IN) v = (float)inu_n[rel] - mean[rel];       // evaluation.py:35 (IC = 1: same offset)
-                else v = inf_n[rel];
-                b_reg[q] = ok ? v : 0.f;
+                src = ok ? in_n + (patch0 + e.x) : zero;
             }
+            float* dst = &Bs[buf][kset * 8 + q][(wave & 1) * 64];  // hardware adds lane * 4
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 4, 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r * CONV_THREADS < A_F4; ++r) {
-            int idx = tid + r * CONV_THREADS;
-            if (idx < A_F4) {
-                int kk = (idx * 4) / BM, m = (idx * 4) % BM;
-                *reinterpret_cast<float4*>(&As[buf][kk][m]) = a_reg[r];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) Bs[buf][kset * 8 + q][n_local] = b_reg[q];
+    // DMA instructions one thread issues per stage (waves whose A piece falls outside issue one less)
+    constexpr int A_FULL = A_F4 / CONV_THREADS;                    // pieces every wave issues
+    constexpr bool A_PARTIAL = (A_F4 % CONV_THREADS) != 0;         // extra piece for the first waves only
+    auto wait_stage = [&](bool keep_one_in_flight) {
+        // wait until only the newest stage's DMA (if any) is still outstanding for this wave
+        const bool extra = A_PARTIAL && (A_FULL * CONV_THREADS + wave * 64 < A_F4);
+        if (!keep_one_in_flight) wait_vmcnt<0>();
+        else if (extra) wait_vmcnt<A_FULL + 1 + 8>();
+        else wait_vmcnt<A_FULL + 8>();
     };
 
+    const int arow = wm * TM * 32 + (lane & 31);
+    const int bcol = wn * TN * 32 + (lane & 31);
+    const int khalf = lane >> 5;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -166,17 +158,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
-    __syncthreads();
-    const int arow = wm * TM * 32 + (lane & 31);
-    const int bcol = wn * TN * 32 + (lane & 31);
-    const int khalf = lane >> 5;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1);         // global loads in flight under the MFMAs
+    const int nk = kt1 - kt0;
+    if (nk > 0) issue(kt0, 0);
+    if (nk > 1) issue(kt0 + 1, 1);
+    wait_stage(nk > 1);
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t % NST;
+        if (t + 2 < nk) issue(kt0 + t + 2, (t + 2) % NST);
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
             float af[TM], bf[TN];
@@ -190,11 +179,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < kt1) store_tile(buf ^ 1);
-        __syncthreads();
+        wait_stage(t + 2 < nk);                         // stage t+1 has landed (own pieces) ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // ... for every wave; stage t's buffer is free again
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long long nn = (long long)nt * BN + wn * TN * 32 + j * 32 + (lane & 31);
@@ -213,12 +202,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_kernel(ConvDims d, con
                     if (d.relu) v = v > 0.f ? v : 0.f;
                     out[((size_t)bb * d.groups * d.OC + (size_t)g * d.OC + m) * ohw + rr] = v;
                 } else {
-                    // split-K partial: [ks][n][m] (deterministic two-pass reduction)
                     out[((size_t)ks * d.N + nn) * d.OC + m] = v;
                 }
             }
         }
     }
+}
+
+// conv1 input: float(uint8 raster) - mean (evaluation.py:35), so that conv1 can use the DMA kernel
+__global__ void prep_input_kernel(const unsigned char* __restrict__ sphere, const float* __restrict__ mean,
+                                  float* __restrict__ out, long long total, int plane) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    out[idx] = (float)sphere[idx] - mean[idx % plane];
 }
 
 // sum the split-K partials, add bias, activation: act 0 = none, 1 = ReLU, 2 = sigmoid
@@ -236,26 +232,62 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
     out[idx] = v;
 }
 
-// LRN across channels, local_size 5 (deploy.prototxt:34-44,82-92): one thread per (b, h, w) walks
-// the channels with a 5-deep register window, so every input element is read exactly once and the
-// window sum is a fresh 5-term sum (no running add/subtract drift).
-__global__ void lrn5_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW,
-                            float alpha, float beta) {
+
+// Fused LRN (across channels, local_size 5) + MAX pool 3x3 stride 2 (deploy.prototxt:34-55, 82-103):
+// one thread per pooled output (b, ph, pw) walks the channels keeping a 5-deep register window for
+// each of the 9 taps of its pooling footprint, so the normalised map (0.6 GB at B = 102 for norm1)
+// is never written to or re-read from HBM: traffic = conv output once (L1/L2 absorb the 2.25x
+// footprint overlap) + the pooled output.
+constexpr int LRN_CCH = 16;   // channels per thread (plus a 2-channel halo on each side)
+__global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                           int C, int H, int W, int PH, int PW, float alpha,
+                                                           float beta) {
+    const int nch = (C + LRN_CCH - 1) / LRN_CCH;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * HW) return;
-    int b = (int)(idx / HW), p = (int)(idx % HW);
-    const float* x = in + (size_t)b * C * HW + p;
-    float* y = out + (size_t)b * C * HW + p;
+    if (idx >= (long long)B * nch * PH * PW) return;
+    const int pw = (int)(idx % PW);
+    const int ph = (int)((idx / PW) % PH);
+    const int ch = (int)((idx / ((long long)PW * PH)) % nch);
+    const int b = (int)(idx / ((long long)PW * PH * nch));
+    const int c0 = ch * LRN_CCH;
+    const int c1 = (c0 + LRN_CCH) < C ? (c0 + LRN_CCH) : C;
+    const int HW = H * W;
+    const float* x = in + (size_t)b * C * HW;
+    float* y = out + (size_t)b * C * PH * PW + (size_t)ph * PW + pw;
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int h = ph * 2 + t / 3, w = pw * 2 + t % 3;
+        ok[t] = h < H && w < W;                         // Caffe clips the window at the border
+        off[t] = ok[t] ? h * W + w : 0;
+    }
     const float an = alpha / 5.f;
-    float v0 = 0.f, v1 = 0.f;                       // x[c-2], x[c-1]
-    float v2 = x[0];                                // x[c]
-    float v3 = C > 1 ? x[(size_t)HW] : 0.f;         // x[c+1]
-    for (int c = 0; c < C; ++c) {
-        float v4 = (c + 2 < C) ? x[(size_t)(c + 2) * HW] : 0.f;
-        float sum = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4;
-        float scale = 1.f + an * sum;
-        y[(size_t)c * HW] = v2 * powf(scale, -beta);
-        v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+    float v0[9], v1[9], v2[9], v3[9];                   // x[c-2], x[c-1], x[c], x[c+1] per tap
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        v0[t] = (c0 - 2 >= 0) ? x[(size_t)(c0 - 2) * HW + off[t]] : 0.f;
+        v1[t] = (c0 - 1 >= 0) ? x[(size_t)(c0 - 1) * HW + off[t]] : 0.f;
+        v2[t] = x[(size_t)c0 * HW + off[t]];
+        v3[t] = (c0 + 1 < C) ? x[(size_t)(c0 + 1) * HW + off[t]] : 0.f;
+    }
+    for (int c = c0; c < c1; ++c) {
+        float m = -3.402823466e38f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v4 = (c + 2 < C) ? x[(size_t)(c + 2) * HW + off[t]] : 0.f;
+            const float sum = v0[t] * v0[t] + v1[t] * v1[t] + v2[t] * v2[t] + v3[t] * v3[t] + v4 * v4;
+            // scale^-beta: beta = 0.75 in this net -> rsqrt(s) * sqrt(rsqrt(s)) (two hardware
+            // transcendentals, ~1 ulp) instead of a ~80-instruction powf per tap
+            const float sc = 1.f + an * sum;
+            float pw_;
+            if (beta == 0.75f) { const float r = rsqrtf(sc); pw_ = r * sqrtf(r); }
+            else pw_ = powf(sc, -beta);
+            const float val = v2[t] * pw_;
+            if (ok[t]) m = val > m ? val : m;
+            v0[t] = v1[t]; v1[t] = v2[t]; v2[t] = v3[t]; v3[t] = v4;
+        }
+        y[(size_t)c * PH * PW] = m;
     }
 }
 
@@ -301,6 +333,7 @@ int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
 struct vpk_cnn_state {
     Layer L[8];              // conv1..5, fc6..8
     float* mean = nullptr;
+    float* zero = nullptr;   // 64 B of zeros: DMA source for out-of-range im2col taps
     bool loaded = false;
     // activations (grown on demand)
     float* act = nullptr;
@@ -321,6 +354,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.ktab) (void)hipFree(l.ktab);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
+    if (h->cnn->zero) (void)hipFree(h->cnn->zero);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
     if (h->cnn->ev_ready)
         for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
@@ -353,11 +387,12 @@ constexpr size_t A_FC6 = 4096, A_FC7 = 4096, A_FC8 = 400;
 constexpr size_t A_BIG = A_CONV1;     // 1.45M floats: the largest blob per image
 
 template <typename KernelT>
-void launch_conv(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const void* in, const float* mean,
-                 const Layer& l, float* out) {
+void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const float* in, const Layer& l,
+                const float* zero, float* out, int stride, int pad) {
     long long ntiles = (d.N + 127) / 128;
     long long blocks = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, mean, l.wp, l.bias, l.ktab, out);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, l.wp, l.bias, l.ktab,
+                       zero, out, stride, pad);
 }
 
 int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
@@ -391,32 +426,35 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
 
     // conv1 + relu1 (fused uint8 - mean load)
-    launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 11, 11, 4, 0, true, false>, dims(0), 96, sphere, S->mean, S->L[0], bufA);
+    {   // uint8 raster - mean -> fp32 (fused pre-pass), then conv1 through the DMA kernel
+        const long long tot = (long long)batch * 500 * 500;
+        hipLaunchKernelGGL(prep_input_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, sphere, S->mean, bufB, tot, 500 * 500);
+    }
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, bufB, S->L[0], S->zero, bufA, 4, 0);
     mark();
     if ((rc = tapcopy(0, bufA, A_CONV1))) return rc;
-    // norm1, pool1
-    hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 123 * 123)), dim3(256), 0, st, bufA, bufB, batch, 96, 123 * 123, 1e-4f, 0.75f);
+    // norm1 + pool1 (fused)
+    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 61 * 61 * ((96 + LRN_CCH - 1) / LRN_CCH))), dim3(256), 0, st, bufA, bufB, batch, 96, 123, 123, 61, 61, 1e-4f, 0.75f);
     mark();
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 96 * 61 * 61)), dim3(256), 0, st, bufB, bufA, (long long)batch * 96, 123, 123, 61, 61, 3, 2);
     mark();
-    if ((rc = tapcopy(1, bufA, A_POOL1))) return rc;
+    if ((rc = tapcopy(1, bufB, A_POOL1))) return rc;
     // conv2 + relu2
-    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 5, 5, 1, 2, false, false>, dims(1), 128, bufA, nullptr, S->L[1], bufB);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, bufB, S->L[1], S->zero, bufA, 1, 2);
     mark();
-    if ((rc = tapcopy(2, bufB, A_CONV2))) return rc;
-    hipLaunchKernelGGL(lrn5_kernel, dim3(ew_blocks((long long)batch * 61 * 61)), dim3(256), 0, st, bufB, bufA, batch, 256, 61 * 61, 1e-4f, 0.75f);
+    if ((rc = tapcopy(2, bufA, A_CONV2))) return rc;
+    // norm2 + pool2 (fused)
+    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 30 * 30 * ((256 + LRN_CCH - 1) / LRN_CCH))), dim3(256), 0, st, bufA, bufB, batch, 256, 61, 61, 30, 30, 1e-4f, 0.75f);
     mark();
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 900)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 61, 61, 30, 30, 3, 2);
     mark();
     if ((rc = tapcopy(3, bufB, A_POOL2))) return rc;
     // conv3..5
-    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(2), 128, bufB, nullptr, S->L[2], bufA);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, bufB, S->L[2], S->zero, bufA, 1, 1);
     mark();
     if ((rc = tapcopy(4, bufA, A_CONV3))) return rc;
-    launch_conv(h, conv_gemm_kernel<1, 4, 3, 1, 3, 3, 1, 1, false, false>, dims(3), 96, bufA, nullptr, S->L[3], bufB);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, bufA, S->L[3], S->zero, bufB, 1, 1);
     mark();
     if ((rc = tapcopy(5, bufB, A_CONV4))) return rc;
-    launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 3, 3, 1, 1, false, false>, dims(4), 128, bufB, nullptr, S->L[4], bufA);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, bufB, S->L[4], S->zero, bufA, 1, 1);
     mark();
     if ((rc = tapcopy(6, bufA, A_CONV5))) return rc;
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 30, 30, 15, 15, 3, 2);
@@ -427,7 +465,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     float* fc_out = bufA;
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
-        launch_conv(h, conv_gemm_kernel<2, 2, 2, 2, 1, 1, 1, 0, false, true>, d, 128, fc_in, nullptr, S->L[li], part);
+        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], S->zero, part, 1, 0);
         const long long tot = d.N * d.OC;
         float* dst = li == 7 ? out : fc_out;
         float* pre = (li == 7 && tap == 10) ? tap_out : nullptr;
@@ -477,6 +515,8 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
     vpk_cnn_state* S = h->cnn;
     VPK_HIP(h, hipMalloc((void**)&S->mean, 500 * 500 * sizeof(float)));
     VPK_HIP(h, hipMemcpy(S->mean, mean, 500 * 500 * sizeof(float), hipMemcpyHostToDevice));
+    VPK_HIP(h, hipMalloc((void**)&S->zero, 64));
+    VPK_HIP(h, hipMemset(S->zero, 0, 64));
     for (int li = 0; li < 8; ++li) {
         const Topo& t = TOPO[li];
         Layer& l = S->L[li];
