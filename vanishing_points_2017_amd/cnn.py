@@ -43,8 +43,8 @@ def synthetic_mean(seed=0):
 class Net(object):
     """Counterpart of caffe.Net(model_def, model_weights, caffe.TEST) for this one topology."""
 
-    def __init__(self, weights, mean, device=0):
-        self.rt = get_runtime(device)
+    def __init__(self, weights, mean, device=0, runtime=None):
+        self.rt = runtime if runtime is not None else get_runtime(device)
         blobs = []
         keep = []
         for name, shape in LAYER_SHAPES:

@@ -36,8 +36,10 @@ class Runtime(object):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def get_runtime(device=0):
-    key = int(device)
+def get_runtime(device=0, lane="main"):
+    """Process-wide runtime of ``device``.  ``lane`` names an independent (handle, stream) pair on the
+    same GPU, e.g. one for the CNN and one for the EM so that consecutive batches overlap."""
+    key = (int(device), lane)
     if key not in _runtimes:
-        _runtimes[key] = Runtime(key)
+        _runtimes[key] = Runtime(int(device))
     return _runtimes[key]
