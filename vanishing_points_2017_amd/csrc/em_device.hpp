@@ -306,6 +306,70 @@ VPK_DEV double seg_point_dist(double ax, double ay, double bx, double by, double
     double ex = cx - px, ey = cy - py;
     return norm2(ex, ey);
 }
+// Per-line quantities reused by every pair this line takes part in (all as the reference rounds them)
+struct LineGeom {
+    double x1, y1, x2, y2;   // end points
+    double dx, dy;           // (x2 - x1, y2 - y1): segment vector used by line_segment_point_distance
+    double nn;               // np.square(norm(d)) (:747)
+    double vx, vy;           // (x1 - x2, y1 - y2): direction used by lines_points_cosangle (:716)
+    double nv;               // norm(v)
+};
+VPK_DEV LineGeom line_geom(const double a[4]) {
+    LineGeom g;
+    g.x1 = a[0]; g.y1 = a[1]; g.x2 = a[2]; g.y2 = a[3];
+    g.dx = a[2] - a[0]; g.dy = a[3] - a[1];
+    const double nrm = norm2(g.dx, g.dy);
+    g.nn = nrm * nrm;
+    g.vx = a[0] - a[2]; g.vy = a[1] - a[3];
+    g.nv = norm2(g.vx, g.vy);
+    return g;
+}
+// squared distance from point p to segment s (vp_localisation.py:743-758 before the final sqrt)
+VPK_DEV double seg_point_dist_sq(const LineGeom& s, double px, double py) {
+    const double param = dot2(px - s.x1, py - s.y1, s.dx, s.dy) / s.nn;
+    double cx, cy;
+    if (param < 0) {
+        cx = s.x1; cy = s.y1;
+    } else if (param > 1) {
+        cx = s.x2; cy = s.y2;
+    } else {
+        cx = s.x1 + param * s.dx; cy = s.y1 + param * s.dy;
+    }
+    const double ex = cx - px, ey = cy - py;
+    return dot2(ex, ey, ex, ey);
+}
+// vp_localisation.py:727-740.  sqrt is monotonic and correctly rounded, so min(sqrt(a..d)) ==
+// sqrt(min(a..d)) bit for bit: one square root per pair instead of four.
+VPK_DEV double line_distance_closest(const LineGeom& a, const LineGeom& b) {
+    const double d1 = seg_point_dist_sq(a, b.x1, b.y1);
+    const double d2 = seg_point_dist_sq(a, b.x2, b.y2);
+    const double d4 = seg_point_dist_sq(b, a.x1, a.y1);
+    const double d5 = seg_point_dist_sq(b, a.x2, a.y2);
+    const double m = d1 < d2 ? d1 : d2;
+    const double q = d4 < d5 ? d4 : d5;
+    return sqrt(m < q ? m : q);
+}
+// cos(clip(9 * acos(c), -pi/2, pi/2)) for c in [0, 1] without acos/cos (vp_localisation.py:721-722 with
+// f = 9): with s = sin(phi) = sqrt((1 - c)(1 + c)), cos(9 phi) = Re((c + i s)^9), evaluated by repeated
+// squaring (unit-modulus products: ~1e-15 absolute error, the same order as libm's last-ulp noise through
+// the ill-conditioned acos near c = 1).  9 phi >= pi/2  <=>  c <= cos(pi/18): the clipped branch returns
+// numpy's cos(pi/2) = 6.123233995736766e-17.
+VPK_DEV double cos9_of_cos(double c) {
+    const double COS_PI_18 = 0.98480775301220802;     // cos(pi / 18)
+    if (!(c > COS_PI_18)) return (c != c) ? c : 6.123233995736766e-17;
+    if (c > 1.0) c = 1.0;                             // np.clip(cosdphi, -1, 1)
+    const double s = sqrt((1.0 - c) * (1.0 + c));
+    double re = c, im = s;                            // z
+    double r2 = re * re - im * im, i2 = 2 * re * im;  // z^2
+    double r4 = r2 * r2 - i2 * i2, i4 = 2 * r2 * i2;  // z^4
+    double r8 = r4 * r4 - i4 * i4, i8 = 2 * r4 * i4;  // z^8
+    return r8 * re - i8 * im;                         // Re(z^9)
+}
+VPK_DEV double lines_cosangle(const LineGeom& a, const LineGeom& b, double f) {   // :715-724, f = 9 only
+    const double c = fabs(dot2(a.vx, a.vy, b.vx, b.vy) / (a.nv * b.nv));
+    (void)f;
+    return cos9_of_cos(c);
+}
 // vp_localisation.py:727-740
 VPK_DEV double line_distance_closest(const double a[4], const double b[4]) {
     double d1 = seg_point_dist(a[0], a[1], a[2], a[3], b[0], b[1]);
@@ -355,46 +419,74 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
     Shared& sh = SH();
     const int N = c.N;
-    gdp drow = c.drow + (size_t)wave_id() * c.ldn;
     // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
-    double* ks = sh.part + wave_id() * (4 * KNN1);
+    double* ks = sh.part + wave_id() * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank
     const int k1 = N < KNN1 ? N : KNN1;
     const int k2 = N < KNN2 ? N : KNN2;
     for (int i = wave_id(); i < N; i += nwaves()) {
         double a[4] = {c.lp[4 * (size_t)i], c.lp[4 * (size_t)i + 1], c.lp[4 * (size_t)i + 2],
                        c.lp[4 * (size_t)i + 3]};
-        const double len_a = line_length(a);
+        const LineGeom ga = line_geom(a);
+        const double len_a = ga.nv;               // line_length == norm of the direction (:761-762)
         double rsum = 0.0;
-        for (int j = lane(); j < N; j += WAVE) {
-            double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2],
-                           c.lp[4 * (size_t)j + 3]};
-            double d = line_distance_closest(a, b);
+        // per-lane sorted list of this lane's KNN1 nearest columns, by (distance, index): filled by a
+        // branch-free insertion during the pair loop, merged across the wave afterwards -- the distance
+        // row never goes to memory
+        double td[KNN1];
+        int tj[KNN1];
+#pragma unroll
+        for (int q = 0; q < KNN1; ++q) { td[q] = 1e300; tj[q] = 0x7fffffff; }
+        // two independent pairs per lane per trip: the per-pair arithmetic is one long dependent fp64
+        // chain (divisions, square roots, exp), so the second pair fills its issue bubbles
+        auto pair_eval = [&](int j, double& d, double& sim) {
+            const int jj = j < N ? j : i;          // clamp: lanes past the end recompute the diagonal
+            double b[4] = {c.lp[4 * (size_t)jj], c.lp[4 * (size_t)jj + 1], c.lp[4 * (size_t)jj + 2],
+                           c.lp[4 * (size_t)jj + 3]};
+            const LineGeom gb = line_geom(b);
+            d = line_distance_closest(ga, gb);
+            sim = want_lsim ? lines_cosangle(ga, gb, 9.0) * proximity(d, len_a, gb.nv, 1.0) : 0.0;
+        };
+        auto pair_commit = [&](int j, double d, double sim) {
+            if (j >= N) return;
             if (want_lsim) {
-                double sim = lines_cosangle(a, b, 9.0) * proximity(d, len_a, line_length(b), 1.0);
                 sim = (i == j) ? 0.0 : sim;
                 c.lsim[(size_t)i * c.ld + j] = sim;
                 rsum += sim;
             }
-            drow[j] = (i == j) ? 4.0 : d;  // :82
+            double nd = (i == j) ? 4.0 : d;       // :82
+            int nj = j;
+#pragma unroll
+            for (int q = 0; q < KNN1; ++q) {
+                const bool lt = (nd < td[q]) || (nd == td[q] && nj < tj[q]);
+                const double od = td[q];
+                const int oj = tj[q];
+                td[q] = lt ? nd : od;
+                tj[q] = lt ? nj : oj;
+                nd = lt ? od : nd;
+                nj = lt ? oj : nj;
+            }
+        };
+        for (int j = lane(); j < N; j += 2 * WAVE) {
+            double d0, s0, d1, s1;
+            pair_eval(j, d0, s0);
+            pair_eval(j + WAVE, d1, s1);
+            pair_commit(j, d0, s0);
+            pair_commit(j + WAVE, d1, s1);
         }
         rsum = wave_sum(rsum);                    // lsim is symmetric: row sum == column sum (:522)
         if (lane() == 0) c.rowsum[i] = rsum;
-        wave_sync();
-        // k1 nearest by k1 rounds of lexicographic (distance, index) selection
-        double last_d = -1.0;
-        int last_j = -1;
+        // k1 nearest overall: k1 rounds of lexicographic (distance, index) minimum over the lane heads
         for (int r = 0; r < k1; ++r) {
-            double bd = 1e300;
-            int bj = 0x7fffffff;
-            for (int j = lane(); j < N; j += WAVE) {
-                double d = drow[j];
-                bool after = (d > last_d) || (d == last_d && j > last_j);
-                if (after && ((d < bd) || (d == bd && j < bj))) { bd = d; bj = j; }
-            }
+            double bd = td[0];
+            int bj = tj[0];
             wave_argmin(bd, bj);
+            if (tj[0] == bj && td[0] == bd) {     // the winning lane pops its head
+#pragma unroll
+                for (int q = 0; q + 1 < KNN1; ++q) { td[q] = td[q + 1]; tj[q] = tj[q + 1]; }
+                td[KNN1 - 1] = 1e300;
+                tj[KNN1 - 1] = 0x7fffffff;
+            }
             if (lane() == 0) { ks[r] = (double)bj; ks[KNN1 + r] = bd; }
-            last_d = bd;
-            last_j = bj;
         }
         wave_sync();
         for (int q = lane(); q < k1; q += WAVE) {
@@ -405,20 +497,21 @@ VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
             ks[3 * KNN1 + q] = proximity(ks[KNN1 + q], len_a, line_length(b), 1.0);  // :65
         }
         wave_sync();
-        if (lane() == 0) {
-            // np.argsort(cosphi)[::-1][0:k2] (:57-59): descending, ties -> later position first
-            double sum = 0.0;
-            for (int r = 0; r < k2; ++r) {
-                for (int q = 0; q < k1; ++q) {
-                    double cq = ks[2 * KNN1 + q];
-                    int rank = 0;
-                    for (int p = 0; p < k1; ++p) {
-                        double cp = ks[2 * KNN1 + p];
-                        rank += (cp > cq) || (cp == cq && p > q);
-                    }
-                    if (rank == r) sum += ks[3 * KNN1 + q] * cq;                     // :66-68
-                }
+        // np.argsort(cosphi)[::-1][0:k2] (:57-59): descending, ties -> later position first.  Each of the
+        // k1 neighbour lanes computes its own rank; the k2 best publish prox * cos under their rank.
+        for (int q = lane(); q < k1; q += WAVE) {
+            const double cq = ks[2 * KNN1 + q];
+            int rank = 0;
+            for (int p = 0; p < k1; ++p) {
+                const double cp = ks[2 * KNN1 + p];
+                rank += (cp > cq) || (cp == cq && p > q);
             }
+            if (rank < k2) ks[4 * KNN1 + rank] = ks[3 * KNN1 + q] * cq;                 // :66
+        }
+        wave_sync();
+        if (lane() == 0) {
+            double sum = 0.0;
+            for (int r = 0; r < k2; ++r) sum += ks[4 * KNN1 + r];                       // :68, in rank order
             c.lscore[i] = sum / k2;                                                 // :70
             // lines_angles (:765-776)
             double vx = a[0] - a[2], vy = a[1] - a[3];
@@ -1421,7 +1514,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
     const double max_stdd = 1e-6;                             // :196-198 ("angle")
     const double merge_thresh_final = P.merge_thresh * 10;    // :190
     const int split_merge_it = 100;                           // :193
-    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.dbuf[8] = 0; sh.dbuf[9] = 0; sh.dbuf[10] = 0; }
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
     block_sync();
     if (o.trace)
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;

@@ -241,8 +241,27 @@ int em_prepare(vpk_handle* h) {
     return VPK_OK;
 }
 
-int em_slots(const vpk_handle* h, int batch, size_t slot_bytes) {
-    int slots = h->num_cu * 2;                       // 2 workgroups of 512 threads per CU
+// How many workgroups share a CU, and how much LDS each gets for the smoother's operand panel.
+//   1 per CU, 128 KiB panel : small batches, and big batches whose N x W panel needs it (single pass over lsim)
+//   2 per CU,  48 KiB panel : big batches whose panel fits 48 KiB
+//   3 per CU,  16 KiB panel : big batches of large images with few VPs (the HBM-streaming stress shape):
+//                             the panel is chunked anyway, so more workgroups per CU = more overlap
+struct EmMode { int per_cu; int wt_doubles; size_t lds_bytes; };
+constexpr int WT_DOUBLES_SMALL = 2048;
+EmMode em_mode(const vpk_handle* h, int batch, int nmax, int mcap) {
+    const size_t panel = (size_t)nmax * (size_t)(mcap > 32 ? 32 : mcap) * sizeof(double);
+    EmMode big{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
+    EmMode mid{2, WT_DOUBLES, EM_LDS_BYTES};
+    EmMode small{3, WT_DOUBLES_SMALL, SH_BYTES + WT_DOUBLES_SMALL * sizeof(double)};
+    if (batch <= h->num_cu) return big;
+    if (panel <= WT_DOUBLES * sizeof(double)) return mid;
+    if (mcap <= MT) return small;
+    if (panel <= WT_DOUBLES_BIG * sizeof(double)) return big;
+    return mid;
+}
+
+int em_slots(const vpk_handle* h, int batch, size_t slot_bytes, int per_cu) {
+    int slots = h->num_cu * per_cu;
     if (slots > batch) slots = batch;
     size_t budget = h->total_mem / 2;                // never claim more than half of HBM
     while (slots > 1 && (size_t)slots * slot_bytes > budget) slots /= 2;
@@ -271,7 +290,7 @@ size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const v
     int mcap = em_mcap(p->num_init_vp, n_init, n_init > 0, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
     EmLayout L = em_layout(n_max, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
     size_t slot = L.total_doubles * sizeof(double);
-    return (size_t)em_slots(h, batch, slot) * slot;
+    return (size_t)em_slots(h, batch, slot, em_mode(h, batch, n_max, mcap).per_cu) * slot;
 }
 
 int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
@@ -300,7 +319,8 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     int mcap = em_mcap(p->num_init_vp, n_init, has_init, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
     EmLayout L = em_layout((int)nmax, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
     const size_t slot_bytes = L.total_doubles * sizeof(double);
-    const int slots = em_slots(h, batch, slot_bytes);
+    const EmMode mode = em_mode(h, batch, (int)nmax, mcap);
+    const int slots = em_slots(h, batch, slot_bytes, mode.per_cu);
     rc = vpk_reserve(h, &h->em_ws, &h->em_ws_bytes, (size_t)slots * slot_bytes, "hipMalloc(EM workspace)");
     if (rc) return rc;
     // header: offsets (B+1 i64) | order (B i32) | queue counter
@@ -342,9 +362,8 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.vp_out = vp_out; a.sigma_out = sigma_out; a.counts_out = counts_out; a.counts_w_out = counts_w_out;
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
-    const bool big = slots <= h->num_cu;             // one workgroup per CU at most
-    a.wt_doubles = big ? WT_DOUBLES_BIG : WT_DOUBLES;
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), big ? EM_LDS_BYTES_BIG : EM_LDS_BYTES, h->stream, a);
+    a.wt_doubles = mode.wt_doubles;
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), mode.lds_bytes, h->stream, a);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
