@@ -173,23 +173,34 @@ def main():
         total_images = count * world * args.steps
         value = total_images / elapsed
         # ---- roofline of the dominant kernel (live HIP-event timings from this run) ----
-        if em_ms >= cnn_ms or args.workload == "stress":
-            # EM batch kernel (one launch per step): algorithmic bytes B_EM of SURVEY 8d,
-            # 8 N^2 (I+1) + I (64 N + 16 M N) per image with I = E-step evaluations
-            m_avg = np.maximum(nvp, 1)
-            evals = iters + 1 + 5                       # loop E-steps + initial + finalisation (>= 4) + slack 1
-            b_em = float(np.sum(8.0 * n_lines ** 2 * (evals + 1) + evals * (64.0 * n_lines + 16.0 * m_avg * n_lines)))
-            roof = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
-        else:
-            name = max(cnn.Net.LAYER_FLOP, key=lambda k: layer_ms[k])
-            flop = cnn.Net.LAYER_FLOP[name] * count
-            roof = {"kernel": "conv_gemm_kernel(%s)" % name, "bound": "mfma",
+        traffic = {}
+        try:   # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)
+        except (OSError, ValueError):
+            pass
+        m_avg = np.maximum(nvp, 1)
+        evals = iters + 1 + 5                            # loop E-steps + initial + finalisation (>= 4) + 1
+        # EM batch kernel (one launch per step): algorithmic bytes B_EM of SURVEY 8d,
+        # 8 N^2 (I+1) + I (64 N + 16 M N) per image with I = E-step evaluations
+        b_em = float(np.sum(8.0 * n_lines ** 2 * (evals + 1) + evals * (64.0 * n_lines + 16.0 * m_avg * n_lines)))
+        key = "yud_102" if (args.workload == "yud" and count == 102) else (
+            "stress_512x1000x8x50" if (args.workload == "stress" and count == 512) else None)
+        t = traffic.get(key) if key else None
+        roof_em = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None}
+        name = max(cnn.Net.LAYER_FLOP, key=lambda k: layer_ms[k])
+        flop = cnn.Net.LAYER_FLOP[name] * count
+        roof_cnn = {"kernel": "conv_gemm_dma_kernel(%s)" % name, "bound": "mfma",
                     "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "traffic": None}
+        roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
+        roof = roof_em if (em_ms >= cnn_ms or args.workload == "stress") else roof_cnn
         roof["frac"] = roof["achieved"] / roof["peak"]
         line = {
-            "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU",
+            "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU" if args.workload == "yud"
+                      else "images/sec (CNN->EM), synthetic stress, 1->8 GPU roofline scan",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (CNN, MFMA) + f64 (EM)",
@@ -203,6 +214,7 @@ def main():
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
                          "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},
             "roofline": roof,
+            "roofline_secondary": roof_cnn if roof is roof_em else roof_em,
         }
         if not args.no_cpu_baseline:
             sample = args.cpu_sample or (6 if args.workload == "yud" else 1)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 passes for profiles/: kernel trace (+stats db) and HBM traffic counters, separate passes
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=gpurun_out/prof
+rm -rf $R; mkdir -p $R
+rocprofv3 --kernel-trace --stats -d $R/yud_trace -o t -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/yud_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/stress_trace -o t -- python3 bench.py --workload stress --steps 3 --warmup 1 --no-cpu-baseline > $R/stress_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/yud_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/yud_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/stress_fetch -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/stress_write -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_write.log 2>&1
+grep -h '"metric"' $R/yud_trace.log $R/stress_trace.log | cut -c1-400
+du -sh $R

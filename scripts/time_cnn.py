@@ -1,0 +1,17 @@
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch
+from vanishing_points_2017_amd import cnn
+from vanishing_points_2017_amd.runtime import get_runtime
+rt = get_runtime(0)
+net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
+net.set_profiling(True)
+for B in (102, 512):
+    x = torch.randint(0, 60, (B, 500, 500), dtype=torch.uint8, device=rt.tdev)
+    for _ in range(3):
+        net.forward_device(x)
+    rt.synchronize()
+    ms = net.last_layer_ms()
+    tot = sum(ms.values())
+    print("B=%d total %.2f ms (%.0f img/s) " % (B, tot, B / tot * 1e3), {k: round(v, 3) for k, v in ms.items()})
+    print("   TF:", {k: round(cnn.Net.LAYER_FLOP[k] * B / (ms[k] * 1e-3) / 1e12, 1) for k in cnn.Net.LAYER_FLOP})

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
 
 // conv1 input: float(uint8 raster) - mean (evaluation.py:35), so that conv1 can use the DMA kernel
 __global__ void prep_input_kernel(const unsigned char* __restrict__ sphere, const float* __restrict__ mean,
-                                  float* __restrict__ out, long long total, int plane) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    out[idx] = (float)sphere[idx] - mean[idx % plane];
+                                  float* __restrict__ out, int plane) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;       // pixel within the image
+    if (p >= plane) return;
+    const size_t idx = (size_t)blockIdx.y * plane + p;         // blockIdx.y = image
+    out[idx] = (float)sphere[idx] - mean[p];
 }
 
 // sum the split-K partials, add bias, activation: act 0 = none, 1 = ReLU, 2 = sigmoid
@@ -427,8 +428,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
 
     // conv1 + relu1 (fused uint8 - mean load)
     {   // uint8 raster - mean -> fp32 (fused pre-pass), then conv1 through the DMA kernel
-        const long long tot = (long long)batch * 500 * 500;
-        hipLaunchKernelGGL(prep_input_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, sphere, S->mean, bufB, tot, 500 * 500);
+        hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, bufB,
+                           500 * 500);
     }
     launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, bufB, S->L[0], S->zero, bufA, 4, 0);
     mark();
