@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
+    ap.add_argument("--em-lanes", type=int, default=3,
+                    help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images timed on the CPU (default 6 yud / 1 stress)")
     return ap.parse_args()
@@ -100,9 +102,13 @@ def main():
 
     from vanishing_points_2017_amd import cnn, em as gem
     from vanishing_points_2017_amd.runtime import get_runtime
-    # two lanes (library handle + HIP stream each) on the same GPU: the EM of step k overlaps the CNN of
-    # step k+1 -- the EM's tail (a few images still iterating) leaves most CUs idle otherwise
-    rt = get_runtime(local_rank, "em")
+    # lanes (library handle + HIP stream each) on the same GPU: one for the CNN, --em-lanes for the EM,
+    # used round-robin.  Steps are software-pipelined: the EM of step k (one persistent workgroup per
+    # image: 102 of 256 CUs, and a tail of a few images still iterating) overlaps the CNN of step k+1 and
+    # the EM of steps k+1, k+2.  All K steps complete inside the timed region.
+    n_lanes = max(1, args.em_lanes)
+    lanes = [get_runtime(local_rank, "em%d" % i) for i in range(n_lanes)]
+    rt = lanes[0]
     rt_cnn = get_runtime(local_rank, "cnn")
     count = args.images or (102 if args.workload == "yud" else 512)
     scenes, kw = make_workload(args.workload, rank, count)
@@ -113,12 +119,16 @@ def main():
     params = gem._params(kw)
     d = gem.upload_batch(rt, scenes)                     # inputs resident in HBM before the timed region
     l_pristine = d["l"].clone()
+    l_lane = [d["l"]] + [d["l"].clone() for _ in range(n_lanes - 1)]   # EM normalises l in place
+    rt.synchronize()
     n_lines = np.diff(d["offsets"])
     max_vp = 64
 
     sphere_cnn = d["sphere"]
 
-    def step():
+    def step(k):
+        rt = lanes[k % n_lanes]
+        l_buf = l_lane[k % n_lanes]
         with rt_cnn.on_stream():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
@@ -127,9 +137,9 @@ def main():
         resp.record_stream(rt.stream)
         with rt.on_stream():
             rt.stream.wait_event(e[1])                   # EM(k) needs CNN(k)
-            d["l"].copy_(l_pristine)                     # EM normalises l in place; restore the input
+            l_buf.copy_(l_pristine)                      # restore the input
             e[2].record()
-            out = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], resp.reshape(-1, 400), d["sphere"],
+            out = gem.em_batch_device(rt, d["offsets"], l_buf, d["lp"], resp.reshape(-1, 400), d["sphere"],
                                       d["init_vp"], params, max_vp=max_vp)
             e[3].record()
             if dist is not None:                         # the one collective: gather the result records
@@ -144,16 +154,20 @@ def main():
             with rt.on_stream():
                 dist.barrier()
         rt_cnn.synchronize()
-        rt.synchronize()
+        for r in lanes:
+            r.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(n_lanes):                             # setup: every lane allocates its workspace once
+        step(k)
+    sync_all()
+    for k in range(args.warmup):
+        step(k)
     sync_all()
     t0 = time.perf_counter()
     evs = []
-    for _ in range(args.steps):
-        e, out = step()
+    for k in range(args.steps):
+        e, out = step(args.warmup + k)
         evs.append(e)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -209,7 +223,8 @@ def main():
                                    % count if args.workload == "yud" else
                                    "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
                        "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
-            "stage_ms": {"cnn": cnn_ms, "em": em_ms, "note": "stages of consecutive steps overlap on two HIP streams"},
+            "stage_ms": {"cnn": cnn_ms, "em": em_ms, "em_lanes": n_lanes,
+                         "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"},
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
                          "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},
