@@ -6,7 +6,7 @@ from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 net.set_profiling(True)
-for B in (102, 512):
+for B in ([int(a) for a in sys.argv[1:]] or [102, 512]):
     x = torch.randint(0, 60, (B, 500, 500), dtype=torch.uint8, device=rt.tdev)
     for _ in range(3):
         net.forward_device(x)

@@ -25,15 +25,16 @@ constexpr int BK = 16;          // K depth of one LDS stage
 constexpr int CONV_THREADS = 256;
 
 struct ConvDims {
-    int B, IC, H, W;            // input  (IC = channels per group)
+    int B, IC, Hp, Wp;          // input: IC = channels per group; Hp x Wp = PADDED plane (zero border = conv padding)
     int OC, OH, OW;             // output (OC = channels per group)
     int groups;
     int K;                      // IC*KH*KW (unpadded)
     int Kp;                     // K padded to a multiple of BK
     int Mp;                     // OC padded to a multiple of BM
-    long long N;                // B*OH*OW
+    int N;                      // B*OH*OW
     int ksplit;                 // split-K factor (dense layers); 1 = fused epilogue
     int relu;
+    int OHp, OWp, opad;         // output plane layout: (oh, ow) is stored at (oh + opad, ow + opad) of an OHp x OWp plane
 };
 
 // --------------------------------------------------------------------------------------------
@@ -46,23 +47,43 @@ struct ConvDims {
 // stages, raw s_barrier + counted s_waitcnt vmcnt(N) so that the DMA of stage t+2 stays in flight
 // across the barrier that publishes stage t+1 (cdna_hip_programming.md T3/T4).  The weights panel is
 // lane-linear 16-byte pieces; the im2col panel is one 4-byte gather per lane, lanes = 64 consecutive
-// output positions of one k row, so the LDS image Bs[k][n] is lane-linear too; out-of-range taps
-// read a zero word.
+// output positions of one k row, so the LDS image Bs[k][n] is lane-linear too.
+//
+// Addressing costs no vector instructions inside the K loop: activations are stored in planes that
+// already carry the convolution's zero border (the producer writes the interior, the border is zeroed
+// when the workspace is allocated), so every tap of every output position is an in-range load and
+// address = (scalar: tile base + table[k]) + (per-lane constant: position of the patch origin).  The
+// DMA uses the saddr form (64-bit SGPR base + 32-bit VGPR offset); the lane offsets are computed once
+// per workgroup.  Columns beyond N (last tile) re-read column N-1 and are not stored.
 // --------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS-DMA issued from inline asm: hipcc knows that the global_load_lds builtin writes LDS and puts an
+// s_waitcnt vmcnt(0) in front of the next ds_read, which drains the stage that was just issued and
+// defeats the pipeline.  An asm statement is outside its bookkeeping; completion is counted by hand
+// (wait_stage below).  M0 = wave-uniform LDS byte address of the destination (the hardware adds
+// lane * size); M0 is compiler-reserved, so it is saved and restored inside the statement.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+__device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE>
 __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
-                                                                     const int2* __restrict__ ktab,
-                                                                     const float* __restrict__ zero,
-                                                                     float* __restrict__ out, int stride,
-                                                                     int pad) {
+                                                                     const unsigned* __restrict__ ktab,
+                                                                     float* __restrict__ out, int stride) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(BN == 128, "the B-tile loader assumes 128 columns");
@@ -77,8 +98,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
     const int mtiles = d.Mp / BM;
     int bid = blockIdx.x;
     const int mt = bid % mtiles; bid /= mtiles;
-    const long long ntiles = (d.N + BN - 1) / BN;
-    const int nt = (int)(bid % ntiles); bid = (int)(bid / ntiles);
+    const int ntiles = (d.N + BN - 1) / BN;
+    const int nt = bid % ntiles; bid /= ntiles;
     const int ks = bid % d.ksplit;
     const int g = bid / d.ksplit;
     const int ksteps_total = d.Kp / BK;
@@ -87,53 +108,56 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
     const int kt1 = (kt0 + ksteps_per) < ksteps_total ? (kt0 + ksteps_per) : ksteps_total;
     const float* wpan = wp + (size_t)g * d.Kp * d.Mp + (size_t)mt * BM;
 
-    const int n_local = tid & 127;
+    // ---- per-lane constants of the B (im2col / dense) gather -------------------------------------
     const int kset = wave >> 1;                       // waves 0,1 -> k 0..7 ; waves 2,3 -> k 8..15
-    const long long n = (long long)nt * BN + n_local;
-    const bool n_ok = n < d.N;
     const int ohw = d.OH * d.OW;
-    int b = 0, oh = 0, ow = 0;
-    if (n_ok) {
-        b = (int)(n / ohw);
-        int r = (int)(n - (long long)b * ohw);
-        oh = r / d.OW;
-        ow = r - oh * d.OW;
+    int n = nt * BN + (tid & 127);
+    n = n < d.N ? n : d.N - 1;                        // tail columns re-read the last valid one
+    const float* bbase;                               // wave-uniform base of this tile's gather
+    unsigned boff;                                    // this lane's byte offset from it
+    if (DENSE) {
+        bbase = in;
+        boff = (unsigned)n * (unsigned)d.K * 4u;
+    } else {
+        const int b_first = (nt * BN) / ohw;          // first image of the tile (scalar)
+        const int b = n / ohw;
+        const int r = n - b * ohw;
+        const int oh = r / d.OW, ow = r - oh * d.OW;
+        const int plane = d.Hp * d.Wp;
+        bbase = in + ((size_t)b_first * d.groups + g) * d.IC * plane;
+        boff = (unsigned)((b - b_first) * d.groups * d.IC * plane + oh * stride * d.Wp + ow * stride) * 4u;
     }
-    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
-    const float* in_n = DENSE ? in + (size_t)(n_ok ? n : 0) * d.K
-                              : in + ((size_t)b * d.groups * d.IC + (size_t)g * d.IC) * d.H * d.W;
-    const int patch0 = ih0 * d.W + iw0;
-
+    // ---- per-lane constants of the A (weights) pieces --------------------------------------------
     constexpr int A_F4 = (BK * BM) / 4;
     constexpr int A_IT = (A_F4 + CONV_THREADS - 1) / CONV_THREADS;
+    unsigned aoff[A_IT];
+#pragma unroll
+    for (int r = 0; r < A_IT; ++r) {
+        const int idx = r * CONV_THREADS + wave * 64 + lane;
+        const int kk = (idx * 4) / BM, m = (idx * 4) % BM;
+        aoff[r] = (unsigned)(kk * d.Mp + m) * 4u;
+    }
+    const unsigned as_base = lds_addr(&As[0][0][0]), bs_base = lds_addr(&Bs[0][0][0]);
     auto issue = [&](int kt, int buf) {
         const int k0 = kt * BK;
+        const float* abase = wpan + (size_t)k0 * d.Mp;
 #pragma unroll
         for (int r = 0; r < A_IT; ++r) {
             const int idx0 = r * CONV_THREADS + wave * 64;         // wave-uniform first float4 of this piece
-            if (idx0 < A_F4) {
-                const int idx = idx0 + lane;
-                const int kk = (idx * 4) / BM, m = (idx * 4) % BM;
-                const float* src = wpan + (size_t)(k0 + kk) * d.Mp + m;
-                float* dst = &As[buf][0][0] + (size_t)idx0 * 4;    // hardware adds lane * 16
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
-            }
+            if (idx0 < A_F4)
+                dma16(aoff[r], abase, __builtin_amdgcn_readfirstlane(as_base + (unsigned)((buf * BK * BM + idx0 * 4) * 4)));
         }
-        const int2* tab = ktab + k0 + kset * 8;
+        const int kb = k0 + kset * 8;
+        unsigned e[8];
+        if (!DENSE) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = ktab[kb + q];        // wave-uniform byte offsets: scalar loads
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float* src;
-            if (DENSE) {
-                const int k = k0 + kset * 8 + q;
-                src = (n_ok && k < d.K) ? in_n + k : zero;
-            } else {
-                const int2 e = tab[q];
-                const int ih = ih0 + (e.y >> 16), iw = iw0 + (e.y & 0xffff);
-                const bool ok = n_ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-                src = ok ? in_n + (patch0 + e.x) : zero;
-            }
-            float* dst = &Bs[buf][kset * 8 + q][(wave & 1) * 64];  // hardware adds lane * 4
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 4, 0, 0);
+            const char* src = DENSE ? (const char*)(bbase + kb + q) : (const char*)bbase + e[q];
+            dma4(boff, src, __builtin_amdgcn_readfirstlane(
+                                bs_base + (unsigned)(((buf * BK + kset * 8 + q) * BN + (wave & 1) * 64) * 4)));
         }
     };
     // DMA instructions one thread issues per stage (waves whose A piece falls outside issue one less)
@@ -184,12 +208,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
         __builtin_amdgcn_s_barrier();                   // ... for every wave; stage t's buffer is free again
     }
 
+    const int oplane = d.OHp * d.OWp;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const long long nn = (long long)nt * BN + wn * TN * 32 + j * 32 + (lane & 31);
+        const int nn = nt * BN + wn * TN * 32 + j * 32 + (lane & 31);
         if (nn >= d.N) continue;
-        const int bb = (int)(nn / ohw);
-        const int rr = (int)(nn - (long long)bb * ohw);
+        const int bb = nn / ohw;
+        const int rr = nn - bb * ohw;
+        const int oh = rr / d.OW, ow = rr - oh * d.OW;
+        const size_t opos = (size_t)(oh + d.opad) * d.OWp + ow + d.opad;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
                 if (d.ksplit == 1) {
                     v += bias[g * d.OC + m];
                     if (d.relu) v = v > 0.f ? v : 0.f;
-                    out[((size_t)bb * d.groups * d.OC + (size_t)g * d.OC + m) * ohw + rr] = v;
+                    out[((size_t)bb * d.groups * d.OC + (size_t)g * d.OC + m) * oplane + opos] = v;
                 } else {
                     out[((size_t)ks * d.N + nn) * d.OC + m] = v;
                 }
@@ -240,9 +267,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
 // is never written to or re-read from HBM: traffic = conv output once (L1/L2 absorb the 2.25x
 // footprint overlap) + the pooled output.
 constexpr int LRN_CCH = 16;   // channels per thread (plus a 2-channel halo on each side)
+// The pooled map is written into planes of PHp x PWp at offset opad (the next convolution's zero border).
 __global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
                                                            int C, int H, int W, int PH, int PW, float alpha,
-                                                           float beta) {
+                                                           float beta, int PHp, int PWp, int opad) {
     const int nch = (C + LRN_CCH - 1) / LRN_CCH;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * nch * PH * PW) return;
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restri
     const int c1 = (c0 + LRN_CCH) < C ? (c0 + LRN_CCH) : C;
     const int HW = H * W;
     const float* x = in + (size_t)b * C * HW;
-    float* y = out + (size_t)b * C * PH * PW + (size_t)ph * PW + pw;
+    float* y = out + (size_t)b * C * PHp * PWp + (size_t)(ph + opad) * PWp + pw + opad;
     int off[9];
     bool ok[9];
 #pragma unroll
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restri
             if (ok[t]) m = val > m ? val : m;
             v0[t] = v1[t]; v1[t] = v2[t]; v2[t] = v3[t]; v3[t] = v4;
         }
-        y[(size_t)c * PH * PW] = m;
+        y[(size_t)c * PHp * PWp] = m;
     }
 }
 
@@ -324,7 +352,7 @@ struct Layer {
     ConvDims d;
     float* wp = nullptr;     // packed weights
     float* bias = nullptr;
-    int2* ktab = nullptr;    // im2col table (conv layers)
+    unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -334,7 +362,6 @@ int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
 struct vpk_cnn_state {
     Layer L[8];              // conv1..5, fc6..8
     float* mean = nullptr;
-    float* zero = nullptr;   // 64 B of zeros: DMA source for out-of-range im2col taps
     bool loaded = false;
     // activations (grown on demand)
     float* act = nullptr;
@@ -355,7 +382,6 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.ktab) (void)hipFree(l.ktab);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
-    if (h->cnn->zero) (void)hipFree(h->cnn->zero);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
     if (h->cnn->ev_ready)
         for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
@@ -365,117 +391,164 @@ void vpk_cnn_free(vpk_handle* h) {
 
 namespace {
 
-// static topology of cnn/deploy.prototxt (per-group channel counts)
-struct Topo { int IC, H, W, OC, OH, OW, G, KH, S, P, BM; };
+// static topology of cnn/deploy.prototxt (per-group channel counts).  H, W = unpadded input plane,
+// P = convolution padding (the input planes are stored with that zero border), OP = border of the
+// OUTPUT planes (= padding of the layer that consumes them; 0 = dense).
+struct Topo { int IC, H, W, OC, OH, OW, G, KH, S, P, BM, OP; };
 const Topo TOPO[8] = {
-    {1, 500, 500, 96, 123, 123, 1, 11, 4, 0, 96},     // conv1 (:9-27)
-    {48, 61, 61, 128, 61, 61, 2, 5, 1, 2, 128},       // conv2 (:56-75) group 2
-    {256, 30, 30, 384, 30, 30, 1, 3, 1, 1, 128},      // conv3 (:104-122)
-    {192, 30, 30, 192, 30, 30, 2, 3, 1, 1, 96},       // conv4 (:129-148) group 2
-    {192, 30, 30, 128, 30, 30, 2, 3, 1, 1, 128},      // conv5 (:155-174) group 2
-    {57600, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128},       // fc6 (:192-210)
-    {4096, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128},        // fc7 (:224-242)
-    {4096, 1, 1, 400, 1, 1, 1, 1, 1, 0, 128},         // fc8_20x20 (:257-275)
+    {1, 500, 500, 96, 123, 123, 1, 11, 4, 0, 96, 0},     // conv1 (:9-27)      -> LRN/pool (dense)
+    {48, 61, 61, 128, 61, 61, 2, 5, 1, 2, 128, 0},       // conv2 (:56-75) g2  -> LRN/pool (dense)
+    {256, 30, 30, 384, 30, 30, 1, 3, 1, 1, 128, 1},      // conv3 (:104-122)   -> conv4 (pad 1)
+    {192, 30, 30, 192, 30, 30, 2, 3, 1, 1, 96, 1},       // conv4 (:129-148) g2 -> conv5 (pad 1)
+    {192, 30, 30, 128, 30, 30, 2, 3, 1, 1, 128, 0},      // conv5 (:155-174) g2 -> pool5 (dense)
+    {57600, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128, 0},       // fc6 (:192-210)
+    {4096, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128, 0},        // fc7 (:224-242)
+    {4096, 1, 1, 400, 1, 1, 1, 1, 1, 0, 128, 0},         // fc8_20x20 (:257-275)
 };
-const int KSPLIT[8] = {1, 1, 1, 1, 1, 8, 8, 8};
+// split-K of the dense layers: enough workgroups for ~3 per CU at the default batch (fc6: 32 m-tiles x 24)
+const int KSPLIT[8] = {1, 1, 1, 1, 1, 24, 16, 32};
 
-// activation buffer layout (floats per image)
+// Activation arena: one region per blob, floats per image.  Regions are carved by the CAPACITY batch,
+// so an image's planes sit at the same address for every batch size <= capacity and the zero borders
+// written at allocation time stay valid.  Nothing is reused between layers (17.6 MB per image; 288 GB
+// of HBM3E makes ping-pong buffers unnecessary, and the borders must not be overwritten).
+enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_COUNT };
+constexpr size_t REGION_FLOATS[R_COUNT] = {
+    500ull * 500,            // fp32 input (raster - mean)
+    96ull * 123 * 123,       // conv1, dense
+    96ull * 65 * 65,         // pool1 with conv2's border of 2
+    256ull * 61 * 61,        // conv2, dense
+    256ull * 32 * 32,        // pool2 with conv3's border of 1
+    384ull * 32 * 32,        // conv3 with conv4's border
+    384ull * 32 * 32,        // conv4 with conv5's border
+    256ull * 900,            // conv5, dense
+    256ull * 225,            // pool5 = fc6 input
+    4096, 4096,              // fc6 / fc7 outputs
+    24ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
+};
+constexpr size_t arena_floats_per_image() {
+    size_t t = 0;
+    for (int i = 0; i < R_COUNT; ++i) t += REGION_FLOATS[i];
+    return t;
+}
+// dense sizes of the blobs a tap can return
 constexpr size_t A_CONV1 = 96ull * 123 * 123, A_POOL1 = 96ull * 61 * 61;
 constexpr size_t A_CONV2 = 256ull * 61 * 61, A_POOL2 = 256ull * 30 * 30;
 constexpr size_t A_CONV3 = 384ull * 900, A_CONV4 = 384ull * 900, A_CONV5 = 256ull * 900, A_POOL5 = 256ull * 225;
 constexpr size_t A_FC6 = 4096, A_FC7 = 4096, A_FC8 = 400;
-// two ping-pong regions big enough for the largest producer/consumer pair
-constexpr size_t A_BIG = A_CONV1;     // 1.45M floats: the largest blob per image
+
+// interior of bordered planes -> dense (taps only)
+__global__ void unpad_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int H, int W,
+                             int Hp, int Wp, int pad) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const int w = (int)(idx % W), hh = (int)((idx / W) % H);
+    const long long pl = idx / ((long long)W * H);
+    out[idx] = in[((size_t)pl * Hp + hh + pad) * Wp + w + pad];
+}
 
 template <typename KernelT>
-void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const float* in, const Layer& l,
-                const float* zero, float* out, int stride, int pad) {
+void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const float* in, const Layer& l, float* out,
+                int stride) {
     long long ntiles = (d.N + 127) / 128;
     long long blocks = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, l.wp, l.bias, l.ktab,
-                       zero, out, stride, pad);
+                       out, stride);
 }
 
 int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
     vpk_cnn_state* S = h->cnn;
-    // workspace: 2 big ping-pong activation regions + split-K partials
-    const size_t per_img = 2 * A_BIG;
-    const size_t part_floats = 8ull * 4096 * (size_t)batch;
-    size_t need = ((size_t)batch * per_img + part_floats) * sizeof(float);
-    int rc = vpk_reserve(h, (void**)&S->act, &S->act_bytes, need, "hipMalloc(CNN activations)");
-    if (rc) return rc;
-    float* bufA = S->act;
-    float* bufB = S->act + (size_t)batch * A_BIG;
-    float* part = S->act + (size_t)batch * per_img;
     hipStream_t st = h->stream;
+    if (batch > S->act_batch) {     // grow the arena; all borders (and everything else) start as zeros
+        const size_t need = (size_t)batch * arena_floats_per_image() * sizeof(float);
+        int rc = vpk_reserve(h, (void**)&S->act, &S->act_bytes, need, "hipMalloc(CNN activations)");
+        if (rc) return rc;
+        VPK_HIP(h, hipMemsetAsync(S->act, 0, need, st));
+        S->act_batch = batch;
+    }
+    float* R[R_COUNT];
+    {
+        size_t off = 0;
+        for (int i = 0; i < R_COUNT; ++i) { R[i] = S->act + off; off += (size_t)S->act_batch * REGION_FLOATS[i]; }
+    }
     auto tapcopy = [&](int id, const float* src, size_t per) -> int {
         if (tap == id && tap_out)
             VPK_HIP(h, hipMemcpyAsync(tap_out, src, per * batch * sizeof(float), hipMemcpyDeviceToDevice, st));
         return VPK_OK;
     };
+    auto ew_blocks = [](long long n) { return (unsigned)((n + 255) / 256); };
+    auto tapunpad = [&](int id, const float* src, int C, int H, int W, int pad) {
+        if (tap == id && tap_out) {
+            const long long planes = (long long)batch * C;
+            hipLaunchKernelGGL(unpad_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, st, src, tap_out, planes, H, W,
+                               H + 2 * pad, W + 2 * pad, pad);
+        }
+    };
     auto dims = [&](int li) {
         ConvDims d = S->L[li].d;
         d.B = batch;
-        d.N = (long long)batch * d.OH * d.OW;
+        d.N = batch * d.OH * d.OW;
         return d;
     };
-    auto ew_blocks = [](long long n) { return (unsigned)((n + 255) / 256); };
     int evi = 0;
     auto mark = [&]() {
         if (S->profiling && evi < 14) (void)hipEventRecord(S->ev[evi++], st);
     };
+    int rc;
     mark();
 
-    // conv1 + relu1 (fused uint8 - mean load)
-    {   // uint8 raster - mean -> fp32 (fused pre-pass), then conv1 through the DMA kernel
-        hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, bufB,
-                           500 * 500);
-    }
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, bufB, S->L[0], S->zero, bufA, 4, 0);
+    // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
+    hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
+                       500 * 500);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 4);
     mark();
-    if ((rc = tapcopy(0, bufA, A_CONV1))) return rc;
-    // norm1 + pool1 (fused)
-    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 61 * 61 * ((96 + LRN_CCH - 1) / LRN_CCH))), dim3(256), 0, st, bufA, bufB, batch, 96, 123, 123, 61, 61, 1e-4f, 0.75f);
+    if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
+    // norm1 + pool1 (fused), written with conv2's border
+    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 61 * 61 * ((96 + LRN_CCH - 1) / LRN_CCH))),
+                       dim3(256), 0, st, R[R_CONV1], R[R_POOL1], batch, 96, 123, 123, 61, 61, 1e-4f, 0.75f, 65, 65, 2);
     mark();
     mark();
-    if ((rc = tapcopy(1, bufB, A_POOL1))) return rc;
+    tapunpad(1, R[R_POOL1], 96, 61, 61, 2);
     // conv2 + relu2
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, bufB, S->L[1], S->zero, bufA, 1, 2);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, R[R_POOL1], S->L[1], R[R_CONV2], 1);
     mark();
-    if ((rc = tapcopy(2, bufA, A_CONV2))) return rc;
-    // norm2 + pool2 (fused)
-    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 30 * 30 * ((256 + LRN_CCH - 1) / LRN_CCH))), dim3(256), 0, st, bufA, bufB, batch, 256, 61, 61, 30, 30, 1e-4f, 0.75f);
+    if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
+    // norm2 + pool2 (fused), written with conv3's border
+    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 30 * 30 * ((256 + LRN_CCH - 1) / LRN_CCH))),
+                       dim3(256), 0, st, R[R_CONV2], R[R_POOL2], batch, 256, 61, 61, 30, 30, 1e-4f, 0.75f, 32, 32, 1);
     mark();
     mark();
-    if ((rc = tapcopy(3, bufB, A_POOL2))) return rc;
+    tapunpad(3, R[R_POOL2], 256, 30, 30, 1);
     // conv3..5
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, bufB, S->L[2], S->zero, bufA, 1, 1);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, R[R_POOL2], S->L[2], R[R_CONV3], 1);
     mark();
-    if ((rc = tapcopy(4, bufA, A_CONV3))) return rc;
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, bufA, S->L[3], S->zero, bufB, 1, 1);
+    tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1);
     mark();
-    if ((rc = tapcopy(5, bufB, A_CONV4))) return rc;
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, bufB, S->L[4], S->zero, bufA, 1, 1);
+    tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, R[R_CONV4], S->L[4], R[R_CONV5], 1);
     mark();
-    if ((rc = tapcopy(6, bufA, A_CONV5))) return rc;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, bufA, bufB, (long long)batch * 256, 30, 30, 15, 15, 3, 2);
+    if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, R[R_CONV5],
+                       R[R_POOL5], (long long)batch * 256, 30, 30, 15, 15, 3, 2);
     mark();
-    if ((rc = tapcopy(7, bufB, A_POOL5))) return rc;
+    if ((rc = tapcopy(7, R[R_POOL5], A_POOL5))) return rc;
     // fc6 / fc7 / fc8: split-K partials + deterministic reduction (+ bias, ReLU / sigmoid)
-    float* fc_in = bufB;
-    float* fc_out = bufA;
+    float* fc_in = R[R_POOL5];
+    float* fc_out = R[R_FCA];
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
-        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], S->zero, part, 1, 0);
-        const long long tot = d.N * d.OC;
+        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], R[R_PART], 1);
+        const long long tot = (long long)d.N * d.OC;
         float* dst = li == 7 ? out : fc_out;
         float* pre = (li == 7 && tap == 10) ? tap_out : nullptr;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, part, S->L[li].bias, d.ksplit,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_blocks(tot)), dim3(256), 0, st, R[R_PART], S->L[li].bias, d.ksplit,
                            d.N, d.OC, li == 7 ? 2 : 1, dst, pre);
         mark();
         if (li == 5 && (rc = tapcopy(8, fc_out, A_FC6))) return rc;
         if (li == 6 && (rc = tapcopy(9, fc_out, A_FC7))) return rc;
-        float* t = fc_in; fc_in = fc_out; fc_out = t;
+        fc_in = fc_out;
+        fc_out = (li == 5) ? R[R_FCB] : R[R_FCA];
     }
     if (S->profiling) S->ev_valid = (evi == 14);
     VPK_HIP(h, hipGetLastError());
@@ -516,13 +589,12 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
     vpk_cnn_state* S = h->cnn;
     VPK_HIP(h, hipMalloc((void**)&S->mean, 500 * 500 * sizeof(float)));
     VPK_HIP(h, hipMemcpy(S->mean, mean, 500 * 500 * sizeof(float), hipMemcpyHostToDevice));
-    VPK_HIP(h, hipMalloc((void**)&S->zero, 64));
-    VPK_HIP(h, hipMemset(S->zero, 0, 64));
     for (int li = 0; li < 8; ++li) {
         const Topo& t = TOPO[li];
         Layer& l = S->L[li];
         ConvDims& d = l.d;
-        d.B = 0; d.IC = t.IC; d.H = t.H; d.W = t.W; d.OC = t.OC; d.OH = t.OH; d.OW = t.OW; d.groups = t.G;
+        d.B = 0; d.IC = t.IC; d.Hp = t.H + 2 * t.P; d.Wp = t.W + 2 * t.P; d.OC = t.OC; d.OH = t.OH; d.OW = t.OW; d.groups = t.G;
+        d.OHp = t.OH + 2 * t.OP; d.OWp = t.OW + 2 * t.OP; d.opad = t.OP;
         d.K = t.IC * t.KH * t.KH;
         d.Kp = (d.K + BK - 1) / BK * BK;
         d.Mp = (t.OC + t.BM - 1) / t.BM * t.BM;
@@ -539,20 +611,15 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                            l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
         VPK_HIP(h, hipStreamSynchronize(h->stream));
         VPK_HIP(h, hipFree(raw));
-        if (li < 5) {   // convolution: im2col table, padded entries fail the bounds test
-            std::vector<int2> tab(d.Kp);
-            for (int k = 0; k < d.Kp; ++k) {
-                if (k < d.K) {
-                    int ic = k / (t.KH * t.KH), r = k % (t.KH * t.KH), kh = r / t.KH, kw = r % t.KH;
-                    tab[k].x = ic * t.H * t.W + kh * t.W + kw;
-                    tab[k].y = (kh << 16) | kw;
-                } else {
-                    tab[k].x = 0;
-                    tab[k].y = (0x4000 << 16) | 0x4000;
-                }
+        if (li < 5) {   // convolution: byte offset of tap k from the patch origin, in the bordered planes;
+                        // the K padding (conv1: 121 -> 128) points at offset 0 and meets zero weights
+            std::vector<unsigned> tab(d.Kp, 0u);
+            for (int k = 0; k < d.K; ++k) {
+                int ic = k / (t.KH * t.KH), r = k % (t.KH * t.KH), kh = r / t.KH, kw = r % t.KH;
+                tab[k] = (unsigned)((ic * d.Hp + kh) * d.Wp + kw) * 4u;
             }
-            VPK_HIP(h, hipMalloc((void**)&l.ktab, tab.size() * sizeof(int2)));
-            VPK_HIP(h, hipMemcpy(l.ktab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice));
+            VPK_HIP(h, hipMalloc((void**)&l.ktab, tab.size() * sizeof(unsigned)));
+            VPK_HIP(h, hipMemcpy(l.ktab, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         }
         VPK_HIP(h, hipMalloc((void**)&l.bias, (size_t)t.G * t.OC * sizeof(float)));
         VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
@@ -566,8 +633,10 @@ int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* 
     if (!h->cnn || !h->cnn->loaded) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_forward before vpk_cnn_load");
     VPK_HIP(h, hipSetDevice(h->device));
     // activations for the whole batch stay in HBM; chunk only if they would exceed a third of it
-    const size_t per_img = (2 * A_BIG + 8ull * 4096) * sizeof(float);
-    int chunk = (int)std::min<size_t>((size_t)batch, std::max<size_t>(1, (h->total_mem / 3) / per_img));
+    // (and at 4096 images: positions and dense-layer byte offsets are 32-bit inside one launch)
+    const size_t per_img = arena_floats_per_image() * sizeof(float);
+    int chunk = (int)std::min<size_t>(std::min<size_t>((size_t)batch, 4096),
+                                      std::max<size_t>(1, (h->total_mem / 3) / per_img));
     static const size_t tap_size[11] = {A_CONV1, A_POOL1, A_CONV2, A_POOL2, A_CONV3, A_CONV4, A_CONV5, A_POOL5,
                                         A_FC6, A_FC7, A_FC8};
     for (int b0 = 0; b0 < batch; b0 += chunk) {
