@@ -127,7 +127,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
  * outputs (device): vp_out B x max_vp x 3, sigma_out / counts_out / counts_w_out B x max_vp,
  *   num_vp_out B, assoc_out sum(N) int64 (-1 = outlier), iterations_out B, status_out B
  *   (vpk_em_status), flags_out B (VPK_EM_FLAG_*), metric_out NULL or sum(N) x max_vp fp64
- *   (decision_metric, [line][vp]), trace_out NULL or B x (num_iter+1) x 8 fp64
+ *   (decision_metric, [line][vp]), trace_out NULL or B x (num_iter+1) x 12 fp64
  *   (row i: M after the M-step, max_err, M at the end of the iteration, event bits, then device
  *   microseconds spent in E-step / smoothing / M-step / whole iteration; row num_iter: microseconds
  *   of pairwise setup, remaining setup, whole image, M after the final merge / hard M-step / winner

@@ -44,7 +44,15 @@ VPK_DEV int wave_sum_int(int v) { return v; }
 VPK_DEV double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 VPK_DEV double wave_max(double v) { return v; }
 VPK_DEV int wave_max_int(int v) { return v; }
+constexpr int VPG = 1;
+template <int G> VPK_DEV double group_sum(double v) { return v; }
+template <int G> VPK_DEV int group_sum_int(int v) { return v; }
+template <int G> VPK_DEV double group_max(double v) { return v; }
+template <int G> VPK_DEV int group_max_int(int v) { return v; }
 VPK_DEV void wave_argmin(double&, int&) {}
+VPK_DEV unsigned long long wave_ballot(bool pred) { return pred ? 1ull : 0ull; }
+VPK_DEV unsigned long long lanes_below() { return 0ull; }
+VPK_DEV int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
 VPK_DEV double wave_bcast(double v, int) { return v; }
 VPK_DEV int wave_bcast_int(int v, int) { return v; }
 template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]) {

@@ -126,6 +126,7 @@ int sim_weight_matrix(int n, int m, const double* p_vl, const double* lweight, c
         c.den[k] = 1 + bias * c.lweight[k] * sum;
         for (int q = m; q < c.mcap; ++q) c.wsrc[(size_t)k * c.mcap + q] = 0.0;
     }
+    g_sh.ibuf[5] = 0;
     smooth(c);
     for (int k = 0; k < m; ++k)
         for (int q = 0; q < n; ++q) w_out[(size_t)k * n + q] = c.w[(size_t)k * c.ldn + q];
@@ -157,7 +158,20 @@ int sim_cluster2(int n, const double* ldist, int* labels_out, unsigned* flags_ou
     std::vector<double> D(ldist, ldist + (size_t)n * n);
     std::vector<int> member(n), csize(n);
     g_sh.flags = 0;
-    cluster2(g_sh, n, D.data(), member.data(), csize.data());
+    const int ld = n | 1;
+    if (n <= CLUSTER_LDS_MAX && (long long)n * ld + n <= WT_DOUBLES) {   // same choice as the kernel
+        double* DL = WT();
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                const double v = D[(size_t)a * n + b];
+                DL[a * ld + b] = (a == b || !(v + D[(size_t)b * n + a] != 0.0)) ? -1.0 : v;
+            }
+        int* lmember = reinterpret_cast<int*>(DL + (size_t)n * ld);
+        cluster2_lds(n, ld, DL, lmember, lmember + n);
+        for (int q = 0; q < n; ++q) member[q] = lmember[q];
+    } else {
+        cluster2(g_sh, n, D.data(), member.data(), csize.data());
+    }
     for (int i = 0; i < n; ++i) labels_out[i] = member[i];
     *flags_out = g_sh.flags;
     return 0;

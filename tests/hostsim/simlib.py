@@ -67,7 +67,7 @@ def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, **
     num = np.zeros(1, np.int32); assoc = np.zeros(n, np.int64); it = np.zeros(1, np.int32)
     st = np.zeros(1, np.int32); fl = np.zeros(1, np.uint32)
     metric = np.zeros((n, max_vp)) if want_metric else None
-    trace = np.zeros((p.num_iter + 1, 8))
+    trace = np.zeros((p.num_iter + 1, 12))
     D, I, L, U = ctypes.c_double, ctypes.c_int32, ctypes.c_longlong, ctypes.c_uint32
     lib().sim_em_single(n, _p(l, D), _p(lp, D), _p(cnn, ctypes.c_float), _p(sphere, ctypes.c_ubyte),
                         sphere.shape[0], _p(iv, D), 0 if iv is None else iv.shape[0], ctypes.byref(p),

@@ -31,7 +31,8 @@ constexpr int MT = 8;               // VP tile of the smoothing kernel (accumula
 constexpr int PART_DOUBLES = 2048;  // LDS scratch for the setup phases (16 KiB)
 constexpr int WT_DOUBLES = 6144;    // LDS operand tile of the smoother (48 KiB)
 constexpr int KNN1 = 10;            // line_rating_knn k1 (vp_localisation.py:34,230)
-constexpr int TRACE_COLS = 8;        // trace row: M, max_err, M_end, events, us_estep, us_smooth, us_mstep, us_total
+constexpr int TRACE_COLS = 12;       // trace row: M, max_err, M_end, events, us_estep, us_smooth, us_mstep, us_total,
+                                     //            us_split_select, us_split_cluster, us_split_fit, us_merge
 constexpr int KNN2 = 4;             // k2=4 at the call site (:230)
 constexpr double PI_D = 3.141592653589793238462643383279502884;
 
@@ -214,19 +215,20 @@ VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a1
 }
 
 // Smallest right singular vector of the row-weighted line matrix diag(r) * L (N x 3), cooperatively
-// by ONE wave -- stands in for V[:,2] of numpy.linalg.svd (vp_localisation.py:466,595).
+// by one aligned group of G lanes (G = WAVE: the whole wave) -- stands in for V[:,2] of
+// numpy.linalg.svd (vp_localisation.py:466,595).  All lanes of the group must call it together.
 // rw(n) returns the row weight r_n (0 = row not selected).  Pass 0 diagonalises the 3x3 scatter
 // sum r^2 l l^T (normal equations: error ~ eps * cond^2 in the small direction); every further pass
 // re-accumulates the scatter IN THE ROTATED BASIS V^T l, where the entries that couple to the small
 // direction are sums of small numbers (no cancellation against the large ones), and applies the
 // Jacobi correction -- an implicit one-sided Jacobi SVD, accurate like LAPACK's after 2-3 passes.
-template <class RowWeight>
-VPK_DEV void wave_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
+template <int G, class RowWeight>
+VPK_DEV void group_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     double ev[3] = {0, 0, 0};
     for (int pass = 0; pass < 5; ++pass) {
         double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
-        for (int n = lane(); n < N; n += WAVE) {
+        for (int n = lane() % G; n < N; n += G) {
             const double r = rw(n);
             if (r == 0) continue;
             cgdp ln = l + 3 * (size_t)n;
@@ -241,8 +243,8 @@ VPK_DEV void wave_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
             g00 += y0 * y0; g01 += y0 * y1; g02 += y0 * y2;
             g11 += y1 * y1; g12 += y1 * y2; g22 += y2 * y2;
         }
-        g00 = wave_sum(g00); g01 = wave_sum(g01); g02 = wave_sum(g02);
-        g11 = wave_sum(g11); g12 = wave_sum(g12); g22 = wave_sum(g22);
+        g00 = group_sum<G>(g00); g01 = group_sum<G>(g01); g02 = group_sum<G>(g02);
+        g11 = group_sum<G>(g11); g12 = group_sum<G>(g12); g22 = group_sum<G>(g22);
         const double tol = 4e-16;
         const bool conv = pass > 0 && fabs(g01) <= tol * sqrt(g00 * g11) && fabs(g02) <= tol * sqrt(g00 * g22) &&
                           fabs(g12) <= tol * sqrt(g11 * g22);
@@ -269,6 +271,11 @@ VPK_DEV void wave_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
     double x = V[0][b], y = V[1][b], z = V[2][b];
     double nrm = norm3(x, y, z);                              // vp /= np.linalg.norm(vp) (:472)
     out[0] = x / nrm; out[1] = y / nrm; out[2] = z / nrm;
+}
+
+template <class RowWeight>
+VPK_DEV void wave_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
+    group_null_vector<WAVE>(l, N, rw, out);
 }
 
 // Third right singular vector of a 1 x 3 matrix [a b c] as LAPACK returns it (numpy.linalg.svd with
@@ -730,6 +737,11 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
         }
     }
     block_sync();
+    // When the smoother's whole operand panel fits in LDS the weights go there directly ([line][vp],
+    // Wp = M rounded to the VP tile) as well as to HBM, and smooth_full skips its staging pass.
+    const int Wp = ((M + MT - 1) / MT) * MT;
+    const bool panel = c.prm.use_weights && M > 0 && M <= 32 && (long long)N * Wp <= c.wt_doubles;
+    double* wt = WT();
     for (int n = tid(); n < N; n += nthreads()) {
         cgdp q = c.lp + 4 * (size_t)n;
         double lmx = 0.5 * (q[0] + q[2]), lmy = 0.5 * (q[1] + q[3]);
@@ -750,13 +762,19 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
         pl = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;        // :117
         double lw = c.lweight[n];
         gdp ws = c.wsrc + (size_t)n * c.mcap;
+        double* wl = wt + (size_t)n * Wp;
         for (int m = 0; m < M; ++m) {
             double pvl = c.pvl[(size_t)m * c.ldn + n] / pl;  // calc_pvl :128
             c.pvl[(size_t)m * c.ldn + n] = pvl;
             ws[m] = pvl * lw;                                // weight_matrix :519
+            if (panel) wl[m] = pvl * lw;
         }
-        for (int m = M; m < ((M + MT - 1) / MT) * MT; ++m) ws[m] = 0.0;   // padding of the last VP tile
+        for (int m = M; m < Wp; ++m) {                       // padding of the last VP tile
+            ws[m] = 0.0;
+            if (panel) wl[m] = 0.0;
+        }
     }
+    if (tid() == 0) sh.ibuf[5] = panel ? Wp : 0;             // consumed (and cleared) by smooth()
     block_sync();
 }
 
@@ -873,17 +891,19 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
     const double bias = c.prm.wbias;
     double* wt = WT();
     long long tq_ = clock_ticks();
-    for (int p = tid(); p < N * W; p += nthreads()) {
-        const int j = p / W, m = p - j * W;
-        wt[p] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m0 + m] : 0.0;
+    if (!(m0 == 0 && sh.ibuf[5] == W)) {            // not left in place by the E-step
+        for (int p = tid(); p < N * W; p += nthreads()) {
+            const int j = p / W, m = p - j * W;
+            wt[p] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m0 + m] : 0.0;
+        }
+        block_sync();
     }
-    block_sync();
     if (tid() == 0) sh.dbuf[8] += lap(tq_);
     const int colw = WAVE * C;
     const int ncg = (N + colw - 1) / colw;
     const int nw = nwaves();
     const bool direct = (ncg % nw) == 0;            // whole column groups per wave, no row slicing
-    const int R = direct ? 1 : nw;
+    const int R = direct ? 1 : nw;                  // (the reduction below handles up to 8 row slices)
     const int slice = direct ? 0 : wave_id();
     const int jchunk = (N + R - 1) / R;
     const int j0 = slice * jchunk;
@@ -977,18 +997,41 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
     if (!direct) {
         block_sync();
         if (tid() == 0) sh.dbuf[9] += lap(tq_);
-        for (int p = tid(); p < M * N; p += nthreads()) {
-            const int t = p / N, kk = p - t * N;
-            double sum = 0.0;
-            for (int r = 0; r < R; ++r) sum += c.part[((size_t)r * c.mcap + t) * c.ldn + kk];   // fixed order
-            c.w[(size_t)(m0 + t) * c.ldn + kk] = (wt[(size_t)kk * W + t] + bias * c.lweight[kk] * sum) / c.den[kk];
+        // one column per thread, VPs in batches of RB: all the partials of a batch are loaded before any is
+        // used (the loop is latency-bound otherwise: the stores to w keep the compiler from hoisting loads)
+        constexpr int RB = 4;
+        for (int kk = tid(); kk < N; kk += nthreads()) {
+            const double blw = bias * c.lweight[kk], dn = c.den[kk];
+            cgdp pcol = c.part + kk;
+            for (int t0 = 0; t0 < M; t0 += RB) {
+                double v[RB][8];
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        v[u][r] = (t0 + u < M && r < R) ? pcol[((size_t)r * c.mcap + t0 + u) * c.ldn] : 0.0;
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (t0 + u >= M) break;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sum += v[u][r];                                   // fixed order
+                    c.w[(size_t)(m0 + t0 + u) * c.ldn + kk] = (wt[(size_t)kk * W + t0 + u] + blw * sum) / dn;
+                }
+            }
         }
     }
     block_sync();
     if (tid() == 0) sh.dbuf[10] += lap(tq_);
 }
 
+VPK_DEVFN void smooth_dispatch(EmCtx& c);
 VPK_DEVFN void smooth(EmCtx& c) {
+    smooth_dispatch(c);
+    if (tid() == 0) SH().ibuf[5] = 0;               // the E-step's panel is valid for one smoothing only
+    block_sync();
+}
+VPK_DEVFN void smooth_dispatch(EmCtx& c) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
     if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl
@@ -1085,19 +1128,23 @@ VPK_DEVFN void compact_vps(EmCtx& c) {
 // ---------------------------------------------------------------------------------------------
 // M-step: calc_new_vanishing_point (vp_localisation.py:453-479) + variance (:301-307)
 // ---------------------------------------------------------------------------------------------
-// One wave per VP.  mode 0: soft (all lines, weights w[m]); mode 1: hard (lines with
+// One group of VPG lanes per VP (four VPs per wave: the serial 3x3 eigen-solves of four VPs then run in
+// the lanes of one wave instead of four waves' worth of rounds).  mode 0: soft (all lines, weights w[m]); mode 1: hard (lines with
 // assoc == m, :353-392).  On return sh.removed[] / sh.err[] are set; nxt and s updated.
 VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
-    for (int m = wave_id(); m < M; m += nwaves()) {
+    constexpr int G = VPG;
+    const int gl = lane() % G;
+    const int per_round = nwaves() * (WAVE / G);
+    for (int m = wave_id() * (WAVE / G) + lane() / G; m < M; m += per_round) {
         cgdp wm = c.w + (size_t)m * c.ldn;
         double wmax = -1e300;
         int nsel = 0, selidx = -1;
         double sv = 0, sp = 0;
         cgdp lvs = c.lvsq + (size_t)m * c.ldn;
         cgdp pvl = c.pvl + (size_t)m * c.ldn;
-        for (int n = lane(); n < N; n += WAVE) {
+        for (int n = gl; n < N; n += G) {
             double pq = pvl[n];
             sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
             sp += pq;
@@ -1106,13 +1153,13 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
             ++nsel;
             selidx = n;
         }
-        wmax = wave_max(wmax);
-        nsel = wave_sum_int(nsel);
-        selidx = wave_max_int(selidx);
-        sv = wave_sum(sv);
-        sp = wave_sum(sp);
+        wmax = group_max<G>(wmax);
+        nsel = group_sum_int<G>(nsel);
+        selidx = group_max_int<G>(selidx);
+        sv = group_sum<G>(sv);
+        sp = group_sum<G>(sp);
         if (mode == 1 && nsel == 0) {                         // :355-356 `continue`
-            if (lane() == 0) { sh.removed[m] = 0; sh.err[m] = -1.0; }
+            if (gl == 0) { sh.removed[m] = 0; sh.err[m] = -1.0; }
             continue;
         }
         bool valid = nsel > 0 && (wmax > 0 || wmax < 0);      // :456-460; NaN -> LinAlgError -> None
@@ -1120,9 +1167,9 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         if (valid && nsel > 1) {
             const VPK_GLOBAL int* assoc = c.assoc;
             // row weight w / max w (:462; hard mode: :358 then / 1 at :462)
-            wave_null_vector(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
+            group_null_vector<G>(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
         }
-        if (lane() == 0) {
+        if (gl == 0) {
             int rem = 0;
             double err = -1.0;
             if (!valid) {
@@ -1304,6 +1351,80 @@ VPK_DEVFN void cluster2(Shared&, int n, gdp D, gip member, gip csize) {
     block_sync();
 }
 
+// Same algorithm for small sets (the usual case: the lines of one VP), run by ONE wave out of LDS so
+// that a merge costs no workgroup barrier: D is an n x ld matrix in LDS (ld odd), the candidate pairs
+// (a > b, row-major) are dealt to the lanes, the active set is a 128-bit mask in registers.
+// Caller: all threads, D already holds the distances with -1 for "no edge"; member/csize in LDS.
+constexpr int CLUSTER_LDS_MAX = 128;
+VPK_DEV void tri_decode(int idx, int& a, int& b) {            // idx = a (a - 1) / 2 + b, 0 <= b < a
+    a = (int)((1.0 + sqrt(1.0 + 8.0 * (double)idx)) * 0.5);
+    while (a > 1 && a * (a - 1) / 2 > idx) --a;
+    while ((a + 1) * a / 2 <= idx) ++a;
+    b = idx - a * (a - 1) / 2;
+}
+VPK_DEVFN void cluster2_lds(int n, int ld, double* D, int* member, int* csize) {
+    Shared& sh = SH();
+    for (int a = tid(); a < n; a += nthreads()) { member[a] = a; csize[a] = 1; }
+    block_sync();
+    if (wave_id() == 0) {
+        unsigned long long act[2];
+        act[0] = n >= 64 ? ~0ull : ((1ull << n) - 1);
+        act[1] = n > 64 ? (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1)) : 0ull;
+        const int npairs = n * (n - 1) / 2;
+        int last_slot = -1;
+        bool tie_seen = false, disconnected = false;
+        for (int t = 0; t < n - 2; ++t) {
+            double bv = 1e300;
+            int bi = 0x7fffffff;
+            int ties = 0;
+            int a, b;
+            tri_decode(lane(), a, b);
+            for (int idx = lane(); idx < npairs; idx += WAVE) {
+                const bool on = ((act[a >> 6] >> (a & 63)) & 1ull) && ((act[b >> 6] >> (b & 63)) & 1ull);
+                if (on) {
+                    const double v = D[a * ld + b];
+                    if (!(v < 0)) {
+                        if (v < bv) { bv = v; bi = a * ld + b; ties = 0; }
+                        else if (v == bv) ties = 1;
+                    }
+                }
+                b += WAVE;
+                while (b >= a) { b -= a; ++a; }
+            }
+            const double myv = bv;
+            wave_argmin(bv, bi);
+            if (bi == 0x7fffffff) { disconnected = true; break; }
+            if (wave_sum_int(myv == bv ? 1 + ties : 0) >= 2) tie_seen = true;
+            const int ma = bi / ld, mb = bi - ma * ld;         // ma > mb; the merged cluster lives in slot ma
+            const int na = csize[ma], nb = csize[mb];
+            for (int cidx = lane(); cidx < n; cidx += WAVE) {
+                if (cidx == ma || cidx == mb || !((act[cidx >> 6] >> (cidx & 63)) & 1ull)) continue;
+                const double da = D[ma * ld + cidx], db = D[mb * ld + cidx];
+                double nv;
+                if (da >= 0 && db >= 0)
+                    nv = (na * da + nb * db) / (double)(na + nb);  // average_merge
+                else
+                    nv = da >= 0 ? da : db;                        // only one side connected (or none: -1)
+                D[ma * ld + cidx] = nv;
+                D[cidx * ld + ma] = nv;
+            }
+            for (int q = lane(); q < n; q += WAVE)
+                if (member[q] == mb) member[q] = ma;
+            wave_sync();
+            if (lane() == 0) { csize[ma] = na + nb; csize[mb] = 0; }
+            wave_sync();
+            act[mb >> 6] &= ~(1ull << (mb & 63));
+            last_slot = ma;
+        }
+        for (int q = lane(); q < n; q += WAVE) member[q] = (member[q] == last_slot) ? 0 : 1;
+        if (lane() == 0) {
+            if (tie_seen) sh.flags |= VPK_EM_FLAG_SPLIT_TIE;
+            if (disconnected) sh.flags |= VPK_EM_FLAG_SPLIT_DISCONNECTED;
+        }
+    }
+    block_sync();
+}
+
 // ---------------------------------------------------------------------------------------------
 // split_best_vp (vp_localisation.py:527-630).  Expects w = weight matrix of sh.cur.
 // ---------------------------------------------------------------------------------------------
@@ -1311,6 +1432,7 @@ VPK_DEVFN void split_vp(EmCtx& c) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
     if (M == 0 || c.cl == nullptr) return;
+    long long tq_ = clock_ticks();
     assign_lines(c, false);                                   // weightIndices (:536) == vpAssoc (:551)
     double wmx = -1e300;
     for (int m = 0; m < M; ++m)
@@ -1367,16 +1489,31 @@ VPK_DEVFN void split_vp(EmCtx& c) {
             if (sh.icnt[cand] > 8 && (px > -1 && py > -1 && px < 1 && py < 1)) { worst = cand; break; }
         }
         sh.ibuf[3] = worst;
+    }
+    block_sync();
+    if (wave_id() == 0) {                                     // assocLines, ascending (:552): ordered compaction
+        const int worst = sh.ibuf[3];
         int nw = 0;
         if (worst >= 0)
-            for (int n = 0; n < N; ++n)
-                if (c.assoc[n] == worst) c.idx[nw++] = n;     // assocLines, ascending (:552)
-        sh.ibuf[4] = nw;
+            for (int n0 = 0; n0 < N; n0 += WAVE) {
+                const int n = n0 + lane();
+                const bool hit = n < N && c.assoc[n] == worst;
+                const unsigned long long mask = wave_ballot(hit);
+                if (hit) c.idx[nw + popcount64(mask & lanes_below())] = n;
+                nw += popcount64(mask);
+            }
+        if (lane() == 0) sh.ibuf[4] = nw;
     }
     block_sync();
     const int worst = sh.ibuf[3], nw = sh.ibuf[4];
+    if (tid() == 0) sh.dbuf[11] += lap(tq_);
     if (worst < 0) return;
     const double stdd = sh.s[worst] / 2;                      // :566
+    gip member = c.idx + N;          // idx has room for 3N ints
+    gip csize = c.idx + 2 * N;
+    const int ld = nw | 1;
+    const bool in_lds = nw <= CLUSTER_LDS_MAX && (long long)nw * ld + nw <= c.wt_doubles;
+    double* DL = WT();
     for (int p = tid(); p < nw * nw; p += nthreads()) {       // Ldist (:568-572)
         int a = p / nw, b = p % nw;
         double v = 0.0;
@@ -1386,12 +1523,21 @@ VPK_DEVFN void split_vp(EmCtx& c) {
             double la[4] = {qa[0], qa[1], qa[2], qa[3]}, lb[4] = {qb[0], qb[1], qb[2], qb[3]};
             v = 1 - lines_cosangle(la, lb, 2.0);
         }
-        c.cl[p] = v;
+        // (Ldist is bitwise symmetric, so sklearn's edge test D + D^T != 0 is v + v != 0)
+        if (in_lds) DL[a * ld + b] = (a == b || !(v + v != 0.0)) ? -1.0 : v;
+        else c.cl[p] = v;
     }
     block_sync();
-    gip member = c.idx + N;          // idx has room for 3N ints
-    gip csize = c.idx + 2 * N;
-    cluster2(sh, nw, c.cl, member, csize);
+    if (in_lds) {
+        int* lmember = reinterpret_cast<int*>(DL + (size_t)nw * ld);
+        int* lcsize = lmember + nw;
+        cluster2_lds(nw, ld, DL, lmember, lcsize);
+        for (int q = tid(); q < nw; q += nthreads()) member[q] = lmember[q];
+        block_sync();
+    } else {
+        cluster2(sh, nw, c.cl, member, csize);
+    }
+    if (tid() == 0) sh.dbuf[12] += lap(tq_);
     // per cluster: smallest right singular vector of the lweight-scaled lines (:580-602)
     // cluster label per line (-1 = not in the set), in the assoc scratch (recomputed before next use)
     gip lab = c.assoc;
@@ -1443,6 +1589,7 @@ VPK_DEVFN void split_vp(EmCtx& c) {
             }
         }
     }
+    if (tid() == 0) sh.dbuf[13] += lap(tq_);
     block_sync();
 }
 
@@ -1514,7 +1661,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
     const double max_stdd = 1e-6;                             // :196-198 ("angle")
     const double merge_thresh_final = P.merge_thresh * 10;    // :190
     const int split_merge_it = 100;                           // :193
-    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.ibuf[5] = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
     block_sync();
     if (o.trace)
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;
@@ -1564,10 +1711,14 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         double events = 0;
         if (i % P.split_merge_freq == 0 && i > 0 && i < split_merge_it && P.do_split) {   // :262-269
             int mb = sh.M;
+            if (tid() == 0) { sh.dbuf[11] = 0; sh.dbuf[12] = 0; sh.dbuf[13] = 0; }
             estep(c, sh.cur);
             smooth(c);
             split_vp(c);
             if (sh.M != mb) events += 1;
+            trace_put(o, i, 8, sh.dbuf[11]);
+            trace_put(o, i, 9, sh.dbuf[12]);
+            trace_put(o, i, 10, sh.dbuf[13]);
         }
         if (o.dbg && tid() == 0) {
             double* q = o.dbg + (size_t)i * (1 + 4 * MAXM);
@@ -1647,7 +1798,9 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         }
         if (i % P.split_merge_freq == 0 && i > 0 && i <= split_merge_it + P.split_merge_freq && P.do_merge) {
             int mb = sh.M;
+            lap(tk);
             merge_vps(c, true, P.merge_thresh);               // :444-448
+            trace_put(o, i, 11, lap(tk));
             if (sh.M != mb) events += 4;
         }
         trace_put(o, i, 2, (double)sh.M);

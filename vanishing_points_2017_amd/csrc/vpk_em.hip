@@ -168,7 +168,7 @@ __global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m,
     bind_scratch(c, ws, L, false);
     for (int p = tid(); p < n * n; p += nthreads())      // caller's matrix (row stride n) -> padded rows
         c.lsim[(size_t)(p / n) * c.ld + p % n] = lsim[p];
-    if (tid() == 0) sh.M = m;
+    if (tid() == 0) { sh.M = m; sh.ibuf[5] = 0; }        // no E-step ran: the operand panel is not in LDS
     for (int i = tid(); i < n; i += nthreads()) c.lweight[i] = lweight[i];
     for (int p = tid(); p < n * c.mcap; p += nthreads()) {
         int i = p / c.mcap, k = p % c.mcap;
@@ -216,7 +216,22 @@ __global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, 
     VPK_SHARED_DECL;
     if (tid() == 0) sh.flags = 0;
     block_sync();
-    cluster2(sh, n, (gdp)D, (gip)member, (gip)csize);
+    const int ld = n | 1;
+    if (n <= CLUSTER_LDS_MAX && (long long)n * ld + n <= WT_DOUBLES) {   // same choice as split_vp
+        double* DL = WT();
+        for (int p = tid(); p < n * n; p += nthreads()) {
+            const int a = p / n, b = p % n;
+            const double v = D[p];
+            DL[a * ld + b] = (a == b || !(v + D[(size_t)b * n + a] != 0.0)) ? -1.0 : v;
+        }
+        block_sync();
+        int* lmember = reinterpret_cast<int*>(DL + (size_t)n * ld);
+        cluster2_lds(n, ld, DL, lmember, lmember + n);
+        for (int q = tid(); q < n; q += nthreads()) member[q] = lmember[q];
+        block_sync();
+    } else {
+        cluster2(sh, n, (gdp)D, (gip)member, (gip)csize);
+    }
     for (int q = tid(); q < n; q += nthreads()) labels_out[q] = member[q];
     if (tid() == 0) *flags_out = sh.flags;
 }

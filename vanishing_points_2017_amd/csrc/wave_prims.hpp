@@ -77,6 +77,32 @@ VPK_DEV int wave_max_int(int v) {
     }
     return v;
 }
+// The same butterflies over aligned groups of G lanes (G = 16: four independent problems per wave, used
+// where a phase has more small problems than waves, e.g. one M-step per VP).  G = 64 == the wave forms.
+constexpr int VPG = 16;   // lanes per VP in the M-step
+template <int G> VPK_DEV double group_sum(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int G> VPK_DEV int group_sum_int(int v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int G> VPK_DEV double group_max(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = nanmax(v, __shfl_xor(v, o));
+    return v;
+}
+template <int G> VPK_DEV int group_max_int(int v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        int u = __shfl_xor(v, o);
+        v = u > v ? u : v;
+    }
+    return v;
+}
 // lexicographic (value, index) minimum; NaN values never win
 VPK_DEV void wave_argmin(double& v, int& idx) {
 #pragma unroll
@@ -88,6 +114,10 @@ VPK_DEV void wave_argmin(double& v, int& idx) {
         idx = take ? j : idx;
     }
 }
+// lanes of this wave for which pred holds (bit i = lane i), and helpers for ordered compaction
+VPK_DEV unsigned long long wave_ballot(bool pred) { return __ballot(pred); }
+VPK_DEV unsigned long long lanes_below() { return (1ull << lane()) - 1ull; }
+VPK_DEV int popcount64(unsigned long long m) { return __popcll(m); }
 VPK_DEV double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
 VPK_DEV int wave_bcast_int(int v, int src_lane) { return __shfl(v, src_lane); }
 

@@ -45,7 +45,7 @@ def em_batch_device(rt, offsets, l, lp, cnn, sphere, init_vp=None, params=None, 
             "status": torch.empty((batch,), dtype=torch.int32, device=dev),
             "flags": torch.empty((batch,), dtype=torch.int32, device=dev),
             "metric": torch.empty((max(total, 1), max_vp), dtype=torch.float64, device=dev) if want_metric else None,
-            "trace": torch.empty((batch, p.num_iter + 1, 8), dtype=torch.float64, device=dev) if want_trace else None,
+            "trace": torch.empty((batch, p.num_iter + 1, 12), dtype=torch.float64, device=dev) if want_trace else None,
         }
         n_init = 0 if init_vp is None else int(init_vp.shape[-2])
         rc = rt.lib.vpk_em_batch(
