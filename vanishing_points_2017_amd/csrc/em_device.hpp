@@ -1041,11 +1041,13 @@ VPK_DEVFN void smooth_dispatch(EmCtx& c) {
         return;
     }
     if (M == 0) return;
-    // one pass over lsim when the N x W operand panel fits in LDS; VPs beyond 32 take another pass
-    const int wneed = M > 32 ? 32 : ((M + MT - 1) / MT) * MT;
-    if ((long long)N * wneed <= c.wt_doubles) {
-        for (int m0 = 0; m0 < M; m0 += 32) {
-            const int mm = M - m0;
+    // single-pass kernel on as many VPs as the LDS panel holds (N x wfit doubles, wfit a multiple of the VP
+    // tile, at most 32 accumulator sets per lane); more VPs than that take further passes over lsim
+    int wfit = (int)((c.wt_doubles / N) / MT) * MT;
+    if (wfit > 32) wfit = 32;
+    if (wfit >= MT) {
+        for (int m0 = 0; m0 < M; m0 += wfit) {
+            const int mm = (M - m0) < wfit ? (M - m0) : wfit;
             if (N > WAVE) {
                 if (mm <= 8) smooth_full<1, 2>(c, m0);
                 else if (mm <= 16) smooth_full<2, 2>(c, m0);

@@ -15,6 +15,8 @@
 // 0.6 GB at B = 102; 288 GB of HBM3E makes chunking unnecessary up to B ~ 4000).
 #include "vpk_internal.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -65,25 +67,28 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // s_waitcnt vmcnt(0) in front of the next ds_read, which drains the stage that was just issued and
 // defeats the pipeline.  An asm statement is outside its bookkeeping; completion is counted by hand
 // (wait_stage below).  M0 = wave-uniform LDS byte address of the destination (the hardware adds
-// lane * size); M0 is compiler-reserved, so it is saved and restored inside the statement.
+// lane * size); M0 is compiler-reserved, so it is saved and restored inside the statement.  The three
+// scalar instructions in front of the load give 5 wait states: hipcc may have written the SGPR operands
+// with v_readlane / v_readfirstlane just before (VALU-writes-SGPR -> VMEM hazard it cannot see in asm).
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
 __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma4(unsigned voff, const void* sbase, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE>
-__global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
+__global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
                                                                      const unsigned* __restrict__ ktab,
-                                                                     float* __restrict__ out, int stride) {
+                                                                     float* __restrict__ out, int stride,
+                                                                     int* __restrict__ tile_counter, int total_tiles) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(BN == 128, "the B-tile loader assumes 128 columns");
@@ -95,8 +100,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // Persistent workgroups over a dynamic tile queue: the first gridDim.x tiles are taken statically, the
+    // rest from an atomic counter.  (With a static grid the workgroups are dealt round-robin to the XCDs, and
+    // CUs that another stream's kernel holds -- the EM runs beside the CNN -- make their XCD the straggler.)
+    // The next index is fetched at the start of a tile and published through LDS, so its latency is hidden.
+    __shared__ int s_next[2];
+    int parity = 0;
+    for (int tile = blockIdx.x; tile < total_tiles;) {
+    int nx = 0;
+    if (tid == 0)    // ONE lane; the oldest outstanding vector-memory op of wave 0: complete at the first wait_stage
+        // (s_nop 4: hipcc may have produced the SGPR pair with v_readlane right before this statement and
+        //  cannot see that the instruction inside reads it -- VALU-writes-SGPR -> VMEM needs 5 wait states)
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(nx) : "v"(0), "v"(1), "s"(tile_counter) : "memory");
     const int mtiles = d.Mp / BM;
-    int bid = blockIdx.x;
+    int bid = tile;
     const int mt = bid % mtiles; bid /= mtiles;
     const int ntiles = (d.N + BN - 1) / BN;
     const int nt = bid % ntiles; bid /= ntiles;
@@ -186,6 +203,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
     if (nk > 0) issue(kt0, 0);
     if (nk > 1) issue(kt0 + 1, 1);
     wait_stage(nk > 1);
+    asm volatile("" : "+v"(nx));                        // the atomic's result has landed (it is older than stage 0)
+    if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
         const int buf = t % NST;
@@ -234,6 +254,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gemm_dma_kernel(ConvDims d,
             }
         }
     }
+    tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
+    parity ^= 1;
+    }   // tile loop
 }
 
 // conv1 input: float(uint8 raster) - mean (evaluation.py:35), so that conv1 can use the DMA kernel
@@ -413,6 +436,7 @@ const int KSPLIT[8] = {1, 1, 1, 1, 1, 24, 16, 32};
 // written at allocation time stay valid.  Nothing is reused between layers (17.6 MB per image; 288 GB
 // of HBM3E makes ping-pong buffers unnecessary, and the borders must not be overwritten).
 enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_COUNT };
+constexpr size_t CTR_FLOATS = 64;   // tile-queue counters of the 8 GEMM launches, behind the regions
 constexpr size_t REGION_FLOATS[R_COUNT] = {
     500ull * 500,            // fp32 input (raster - mean)
     96ull * 123 * 123,       // conv1, dense
@@ -449,18 +473,19 @@ __global__ void unpad_kernel(const float* __restrict__ in, float* __restrict__ o
 
 template <typename KernelT>
 void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const float* in, const Layer& l, float* out,
-                int stride) {
+                int stride, int* counter) {
     long long ntiles = (d.N + 127) / 128;
-    long long blocks = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
+    long long total = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
+    long long blocks = std::min<long long>(total, (getenv("VPK_CNN_STATIC") ? 1000000ll : 3ll) * h->num_cu);     // three workgroups fit a CU (LDS)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, l.wp, l.bias, l.ktab,
-                       out, stride);
+                       out, stride, counter, (int)total);
 }
 
 int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
     vpk_cnn_state* S = h->cnn;
     hipStream_t st = h->stream;
     if (batch > S->act_batch) {     // grow the arena; all borders (and everything else) start as zeros
-        const size_t need = (size_t)batch * arena_floats_per_image() * sizeof(float);
+        const size_t need = ((size_t)batch * arena_floats_per_image() + CTR_FLOATS) * sizeof(float);
         int rc = vpk_reserve(h, (void**)&S->act, &S->act_bytes, need, "hipMalloc(CNN activations)");
         if (rc) return rc;
         VPK_HIP(h, hipMemsetAsync(S->act, 0, need, st));
@@ -471,6 +496,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         size_t off = 0;
         for (int i = 0; i < R_COUNT; ++i) { R[i] = S->act + off; off += (size_t)S->act_batch * REGION_FLOATS[i]; }
     }
+    int* ctr = reinterpret_cast<int*>(S->act + (size_t)S->act_batch * arena_floats_per_image());
+    VPK_HIP(h, hipMemsetAsync(ctr, 0, CTR_FLOATS * sizeof(float), st));
     auto tapcopy = [&](int id, const float* src, size_t per) -> int {
         if (tap == id && tap_out)
             VPK_HIP(h, hipMemcpyAsync(tap_out, src, per * batch * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -491,8 +518,10 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         return d;
     };
     int evi = 0;
+    int dbg_stop = getenv("VPK_CNN_STOP") ? atoi(getenv("VPK_CNN_STOP")) : 99, dbg_n = 0;
     auto mark = [&]() {
         if (S->profiling && evi < 14) (void)hipEventRecord(S->ev[evi++], st);
+        if (++dbg_n >= dbg_stop) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "stage %d: %s\n", dbg_n, hipGetErrorString(e)); }
     };
     int rc;
     mark();
@@ -500,7 +529,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
     hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
                        500 * 500);
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 4);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 4, ctr + 0);
     mark();
     if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
     // norm1 + pool1 (fused), written with conv2's border
@@ -510,7 +539,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     tapunpad(1, R[R_POOL1], 96, 61, 61, 2);
     // conv2 + relu2
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, R[R_POOL1], S->L[1], R[R_CONV2], 1);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, R[R_POOL1], S->L[1], R[R_CONV2], 1, ctr + 1);
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
     // norm2 + pool2 (fused), written with conv3's border
@@ -520,13 +549,13 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     tapunpad(3, R[R_POOL2], 256, 30, 30, 1);
     // conv3..5
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, R[R_POOL2], S->L[2], R[R_CONV3], 1);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, R[R_POOL2], S->L[2], R[R_CONV3], 1, ctr + 2);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, R[R_CONV4], S->L[4], R[R_CONV5], 1);
+    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, R[R_CONV4], S->L[4], R[R_CONV5], 1, ctr + 4);
     mark();
     if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, R[R_CONV5],
@@ -538,7 +567,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     float* fc_out = R[R_FCA];
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
-        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], R[R_PART], 1);
+        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], R[R_PART], 1, ctr + li);
         const long long tot = (long long)d.N * d.OC;
         float* dst = li == 7 ? out : fc_out;
         float* pre = (li == 7 && tap == 10) ? tap_out : nullptr;

@@ -71,7 +71,10 @@ int vpk_destroy(vpk_handle* h) {
     vpk_cnn_free(h);
     if (h->em_ws) (void)hipFree(h->em_ws);
     if (h->em_hdr) (void)hipFree(h->em_hdr);
-    if (h->em_hdr_host) (void)hipHostFree(h->em_hdr_host);
+    for (int i = 0; i < vpk_handle::VPK_HDR_RING; ++i) {
+        if (h->em_hdr_host[i]) (void)hipHostFree(h->em_hdr_host[i]);
+        if (h->em_hdr_ev[i]) (void)hipEventDestroy(h->em_hdr_ev[i]);
+    }
     if (h->small_ws) (void)hipFree(h->small_ws);
     if (h->raster_hdr) (void)hipFree(h->raster_hdr);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

@@ -7,6 +7,7 @@
 #include "vpk_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -268,6 +269,15 @@ EmMode em_mode(const vpk_handle* h, int batch, int nmax, int mcap) {
     EmMode big{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
     EmMode mid{2, WT_DOUBLES, EM_LDS_BYTES};
     EmMode small{3, WT_DOUBLES_SMALL, SH_BYTES + WT_DOUBLES_SMALL * sizeof(double)};
+    if (const char* f = getenv("VPK_EM_WT")) {         // development override: panel doubles
+        const int wt = atoi(f);
+        return EmMode{1, wt, SH_BYTES + (size_t)wt * sizeof(double)};
+    }
+    if (const char* f = getenv("VPK_EM_MODE")) {       // development override: 1 = big, 2 = mid, 3 = small
+        if (f[0] == '1') return big;
+        if (f[0] == '2') return mid;
+        if (f[0] == '3') return small;
+    }
     if (batch <= h->num_cu) return big;
     if (panel <= WT_DOUBLES * sizeof(double)) return mid;
     if (mcap <= MT) return small;
@@ -343,24 +353,30 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     const size_t ord_bytes = em_align((size_t)batch * 4, 256);
     rc = vpk_reserve(h, &h->em_hdr, &h->em_hdr_bytes, off_bytes + ord_bytes + 256, "hipMalloc(EM header)");
     if (rc) return rc;
-    // the previous batch on this handle may still be reading the header / staging buffers
-    VPK_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->em_hdr_host_bytes < off_bytes + ord_bytes) {
-        if (h->em_hdr_host) VPK_HIP(h, hipHostFree(h->em_hdr_host));
-        h->em_hdr_host = nullptr;
-        h->em_hdr_host_bytes = 0;
-        VPK_HIP(h, hipHostMalloc(&h->em_hdr_host, (off_bytes + ord_bytes) * 2, hipHostMallocDefault));
-        h->em_hdr_host_bytes = (off_bytes + ord_bytes) * 2;
+    // The device header is rewritten by a stream-ordered copy (after the previous batch's kernel), so only
+    // the pinned staging buffer needs care: take the next ring slot and wait for the copy that last used it.
+    const int ring = h->em_hdr_next;
+    h->em_hdr_next = (ring + 1) % vpk_handle::VPK_HDR_RING;
+    if (!h->em_hdr_ev[ring]) VPK_HIP(h, hipEventCreateWithFlags(&h->em_hdr_ev[ring], hipEventDisableTiming));
+    if (h->em_hdr_ev_valid[ring]) VPK_HIP(h, hipEventSynchronize(h->em_hdr_ev[ring]));
+    if (h->em_hdr_host_bytes[ring] < off_bytes + ord_bytes) {
+        if (h->em_hdr_host[ring]) VPK_HIP(h, hipHostFree(h->em_hdr_host[ring]));
+        h->em_hdr_host[ring] = nullptr;
+        h->em_hdr_host_bytes[ring] = 0;
+        VPK_HIP(h, hipHostMalloc(&h->em_hdr_host[ring], (off_bytes + ord_bytes) * 2, hipHostMallocDefault));
+        h->em_hdr_host_bytes[ring] = (off_bytes + ord_bytes) * 2;
     }
-    long long* st_off = (long long*)h->em_hdr_host;
-    int* order = (int*)((char*)h->em_hdr_host + off_bytes);
+    long long* st_off = (long long*)h->em_hdr_host[ring];
+    int* order = (int*)((char*)h->em_hdr_host[ring] + off_bytes);
     for (int b = 0; b <= batch; ++b) st_off[b] = offsets[b];
     std::iota(order, order + batch, 0);
     std::stable_sort(order, order + batch, [&](int x, int y) {
         return (offsets[x + 1] - offsets[x]) > (offsets[y + 1] - offsets[y]);   // largest image first
     });
     char* hdr = (char*)h->em_hdr;
-    VPK_HIP(h, hipMemcpyAsync(hdr, h->em_hdr_host, off_bytes + ord_bytes, hipMemcpyHostToDevice, h->stream));
+    VPK_HIP(h, hipMemcpyAsync(hdr, h->em_hdr_host[ring], off_bytes + ord_bytes, hipMemcpyHostToDevice, h->stream));
+    VPK_HIP(h, hipEventRecord(h->em_hdr_ev[ring], h->stream));
+    h->em_hdr_ev_valid[ring] = true;
     VPK_HIP(h, hipMemsetAsync(hdr + off_bytes + ord_bytes, 0, 256, h->stream));
 
     EmBatchArgs a;
@@ -378,7 +394,9 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
     a.wt_doubles = mode.wt_doubles;
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), mode.lds_bytes, h->stream, a);
+    int threads = EM_THREADS;
+    if (const char* f = getenv("VPK_EM_THREADS")) threads = atoi(f);   // development override
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(threads), mode.lds_bytes, h->stream, a);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }

@@ -24,8 +24,14 @@ struct vpk_handle {
     size_t em_ws_bytes = 0;
     void* em_hdr = nullptr;   // offsets + order + queue counter
     size_t em_hdr_bytes = 0;
-    void* em_hdr_host = nullptr;   // pinned staging for the header
-    size_t em_hdr_host_bytes = 0;
+    // pinned staging for the header: a ring, so that the call does not have to wait for the previous
+    // batch on this handle (only for the H2D copy issued VPK_HDR_RING calls ago)
+    static constexpr int VPK_HDR_RING = 4;
+    void* em_hdr_host[VPK_HDR_RING] = {};
+    size_t em_hdr_host_bytes[VPK_HDR_RING] = {};
+    hipEvent_t em_hdr_ev[VPK_HDR_RING] = {};
+    bool em_hdr_ev_valid[VPK_HDR_RING] = {};
+    int em_hdr_next = 0;
     void* small_ws = nullptr; // fine-grained entry points
     size_t small_ws_bytes = 0;
     bool raster_ready = false;
