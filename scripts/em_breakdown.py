@@ -44,3 +44,4 @@ for s_, r in zip(scenes, res):
     for name, col in (("estep", 4), ("smooth", 5), ("mstep", 6), ("split_select", 8), ("split_cluster", 9), ("split_fit", 10), ("merge", 11)):
         tot[name] += tr[:it + 1, col].sum()
 print("batch totals (ms):", {k: round(v / 1e3, 1) for k, v in tot.items()})
+print("E-step split over the batch (ms): prior %.1f, lines %.1f" % (sum(r["trace"][-1, 8] for r in res) / 1e3, sum(r["trace"][-1, 9] for r in res) / 1e3))

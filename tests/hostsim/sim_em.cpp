@@ -94,6 +94,7 @@ int sim_estep(int n, int m, const double* lp, const float* cnn, const double* v,
     g_sh.M = m;
     for (int k = 0; k < 3 * m; ++k) g_sh.cur[k] = v[k];
     for (int k = 0; k < m; ++k) g_sh.s[k] = s[k];
+    line_geometry_setup(c);
     estep(c, g_sh.cur);
     for (int k = 0; k < m; ++k) {
         s[k] = g_sh.s[k];

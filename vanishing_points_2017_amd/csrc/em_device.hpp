@@ -28,7 +28,7 @@ constexpr int GRIDN = 20;           // CNN output grid (cnn/deploy.prototxt:283-
 constexpr int NCELL = GRIDN * GRIDN;
 constexpr int MAXCOMP = 100;        // prior keeps the 100 strongest cells (probability_functions.py:87)
 constexpr int MT = 8;               // VP tile of the smoothing kernel (accumulators per column)
-constexpr int PART_DOUBLES = 2048;  // LDS scratch for the setup phases (16 KiB)
+constexpr int PART_DOUBLES = 2048;  // LDS scratch of the setup phases (16 KiB): the head of the smoother's panel, not yet in use then
 constexpr int WT_DOUBLES = 6144;    // LDS operand tile of the smoother (48 KiB)
 constexpr int KNN1 = 10;            // line_rating_knn k1 (vp_localisation.py:34,230)
 constexpr int TRACE_COLS = 12;       // trace row: M, max_err, M_end, events, us_estep, us_smooth, us_mstep, us_total,
@@ -58,13 +58,13 @@ struct Shared {
     int ibuf[8];
     double dbuf[16];
     double sigma_prior;
-    double part[PART_DOUBLES];
 };
 
 constexpr size_t SH_BYTES = (sizeof(Shared) + 15) / 16 * 16;
 // LDS layout of every EM kernel: [Shared | smoother operand panel]
 VPK_DEV Shared& SH() { return *reinterpret_cast<Shared*>(lds_base()); }
 VPK_DEV double* WT() { return reinterpret_cast<double*>(lds_base() + SH_BYTES); }
+VPK_DEV double* SCRATCH() { return WT(); }   // PART_DOUBLES doubles; every launch gives the panel at least that much
 
 struct EmCtx {
     int N;
@@ -89,7 +89,7 @@ struct EmCtx {
     gdp pvl;      // [m][n]
     gdp w;        // [m][n]
     gdp wsrc;     // [n][mcap] : p_vl * lweight, VP index contiguous (broadcast reads)
-    gdp drow;     // nwaves x ldn closest-distance rows (kNN selection)
+    gdp drow;     // 6 x ldn: per-line constants of the E-step (midpoint, direction, norm) and p_l
     gdp cl;       // split: Nw x Nw cluster distances (NULL when do_split == 0)
     gip assoc;    // N
     gip idx;      // 3N (split: gathered line indices, cluster membership)
@@ -170,6 +170,11 @@ VPK_DEVFN double block_max(Shared&, double v) {
     block_sync();
     return b;
 }
+
+// exp for arguments that are usually far below the underflow threshold (a VP against a distant mixture
+// component or line): exp(x) is exactly 0 for x < -745.14 in glibc and in ocml, so the ~50-instruction
+// evaluation is skipped there -- whole waves take the short path most of the time.
+VPK_DEV double exp_underflow(double x) { return x < -746.0 ? 0.0 : exp(x); }
 
 // symmetric 3x3 eigen-solver (cyclic Jacobi): A = J diag(ev) J^T, J orthogonal (columns = eigenvectors)
 VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a12, double a22,
@@ -427,7 +432,7 @@ VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
     Shared& sh = SH();
     const int N = c.N;
     // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
-    double* ks = sh.part + wave_id() * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank
+    double* ks = SCRATCH() + wave_id() * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank
     const int k1 = N < KNN1 ? N : KNN1;
     const int k2 = N < KNN2 ? N : KNN2;
     for (int i = wave_id(); i < N; i += nwaves()) {
@@ -582,7 +587,7 @@ VPK_DEVFN void prior_setup(EmCtx& c) {
     Shared& sh = SH();
     for (int i = tid(); i < NCELL; i += nthreads()) sh.wts[i] = c.cnn[i];
     block_sync();
-    float* keep = (float*)sh.part;  // 400 floats
+    float* keep = (float*)SCRATCH();  // 400 floats
     for (int i = tid(); i < NCELL; i += nthreads()) {
         float wi = sh.wts[i];
         int rank = 0;  // position in argsort(weights)[::-1]: ties -> higher index first
@@ -615,7 +620,7 @@ VPK_DEVFN void prior_setup(EmCtx& c) {
 }
 
 // find_maxima (vp_localisation.py:13-31) + find_initial_vps (:111-165).  Leaves the VPs in
-// sh.cur (row-major cell order), sh.M = count.  Uses sh.part as scratch.
+// sh.cur (row-major cell order), sh.M = count.  Uses SCRATCH().
 VPK_DEVFN void initial_vps(EmCtx& c) {
     Shared& sh = SH();
     cgfp r = c.cnn;
@@ -629,8 +634,8 @@ VPK_DEVFN void initial_vps(EmCtx& c) {
         sh.mx[i] = (vm > vu && vm > vd && vm > vl && vm > vr) ? 1 : 0;
     }
     block_sync();
-    unsigned char* keep = (unsigned char*)sh.part;          // 400 bytes
-    double* cand = sh.part + 64;                            // 400 x 4 doubles (x,y,z,valid)
+    unsigned char* keep = (unsigned char*)SCRATCH();        // 400 bytes
+    double* cand = SCRATCH() + 64;                          // 400 x 4 doubles (x,y,z,valid)
     const int num_max = c.prm.num_init_vp;
     for (int i = tid(); i < NCELL; i += nthreads()) {
         int k = 0;
@@ -698,6 +703,22 @@ VPK_DEVFN void initial_vps(EmCtx& c) {
     block_sync();
 }
 
+// Per-line constants of the E-step (calc_lvsq_angle :165-172 evaluates them again for every VP and every
+// iteration): midpoint, direction and its norm, in c.drow as [5][ldn]; the line probabilities p_l of the
+// current E-step follow at [5].
+VPK_DEVFN void line_geometry_setup(EmCtx& c) {
+    for (int n = tid(); n < c.N; n += nthreads()) {
+        cgdp q = c.lp + 4 * (size_t)n;
+        const double v2x = q[0] - q[2], v2y = q[1] - q[3];
+        c.drow[n] = 0.5 * (q[0] + q[2]);
+        c.drow[(size_t)c.ldn + n] = 0.5 * (q[1] + q[3]);
+        c.drow[2 * (size_t)c.ldn + n] = v2x;
+        c.drow[3 * (size_t)c.ldn + n] = v2y;
+        c.drow[4 * (size_t)c.ldn + n] = norm2(v2x, v2y);
+    }
+    block_sync();
+}
+
 // ---------------------------------------------------------------------------------------------
 // E-step: calc_probabilities (probability_functions.py:99-147, "angle" branch)
 // ---------------------------------------------------------------------------------------------
@@ -706,74 +727,120 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
     const double kk = -0.5 / (sh.sigma_prior * sh.sigma_prior);
-    // prior p(v): one wave per VP, lanes over mixture components (calc_angles :252-259, calc_pdf :8-40)
-    for (int m = wave_id(); m < M; m += nwaves()) {
-        double x0 = X[3 * m], x1 = X[3 * m + 1], x2 = X[3 * m + 2];
-        double beta = asin(x1);
-        double inner = x0 / cos(beta);
-        inner = inner < 1 ? inner : (is_nan(inner) ? inner : 1.0);
-        inner = inner > -1 ? inner : (is_nan(inner) ? inner : -1.0);
-        double alpha = asin(inner);
-        double acc = 0.0;
-        for (int q = lane(); q < sh.ncomp; q += WAVE) {
-            double ma = sh.pma[q], mb = sh.pmb[q];
-            double d1 = (alpha - ma) * (alpha - ma) + (beta - mb) * (beta - mb);
-            double d2 = (alpha - ma + PI_D) * (alpha - ma + PI_D) + (beta + mb) * (beta + mb);
-            double d3 = (alpha - ma - PI_D) * (alpha - ma - PI_D) + (beta + mb) * (beta + mb);
-            double d4 = (alpha + ma) * (alpha + ma) + (beta - mb - PI_D) * (beta - mb - PI_D);
-            double e4 = exp(d4 * kk);                        // the fifth term duplicates the fourth (:25-26)
-            double p = (((exp(d1 * kk) + exp(d2 * kk)) + exp(d3 * kk)) + e4) + e4;
-            acc += p * sh.pw[q];
-        }
-        acc = wave_sum(acc);
-        if (lane() == 0) {
-            sh.pv[m] = acc;
-            sh.vx[m] = x0 / x2;                              // calc_lvsq_angle :165-166
-            sh.vy[m] = x1 / x2;
-            double sm = sh.s[m];
-            sm = sm > 1e-200 ? sm : 1e-200;                  // calc_plv :139 (in place)
-            sh.s[m] = sm;
-            sh.k2[m] = 1.0 / sqrt(2 * PI_D * sm);            // :145
+    long long tq_ = clock_ticks();
+    // prior p(v): a group of VPG lanes per VP (four VPs per wave: the asin/cos chains of four VPs run in one
+    // wave's lanes), lanes over mixture components (calc_angles :252-259, calc_pdf :8-40)
+    {
+        constexpr int G = VPG;
+        const int gl = lane() % G;
+        const int per_round = nwaves() * (WAVE / G);
+        for (int m = wave_id() * (WAVE / G) + lane() / G; m < M; m += per_round) {
+            double x0 = X[3 * m], x1 = X[3 * m + 1], x2 = X[3 * m + 2];
+            double beta = asin(x1);
+            double inner = x0 / cos(beta);
+            inner = inner < 1 ? inner : (is_nan(inner) ? inner : 1.0);
+            inner = inner > -1 ? inner : (is_nan(inner) ? inner : -1.0);
+            double alpha = asin(inner);
+            double acc = 0.0;
+            for (int q = gl; q < sh.ncomp; q += G) {
+                double ma = sh.pma[q], mb = sh.pmb[q];
+                double d1 = (alpha - ma) * (alpha - ma) + (beta - mb) * (beta - mb);
+                double d2 = (alpha - ma + PI_D) * (alpha - ma + PI_D) + (beta + mb) * (beta + mb);
+                double d3 = (alpha - ma - PI_D) * (alpha - ma - PI_D) + (beta + mb) * (beta + mb);
+                double d4 = (alpha + ma) * (alpha + ma) + (beta - mb - PI_D) * (beta - mb - PI_D);
+                double e4 = exp_underflow(d4 * kk);          // the fifth term duplicates the fourth (:25-26)
+                double p = (((exp_underflow(d1 * kk) + exp_underflow(d2 * kk)) + exp_underflow(d3 * kk)) + e4) + e4;
+                acc += p * sh.pw[q];
+            }
+            acc = group_sum<G>(acc);
+            if (gl == 0) {
+                sh.pv[m] = acc;
+                sh.vx[m] = x0 / x2;                          // calc_lvsq_angle :165-166
+                sh.vy[m] = x1 / x2;
+                double sm = sh.s[m];
+                sm = sm > 1e-200 ? sm : 1e-200;              // calc_plv :139 (in place)
+                sh.s[m] = sm;
+                sh.k2[m] = 1.0 / sqrt(2 * PI_D * sm);        // :145
+            }
         }
     }
     block_sync();
+    if (tid() == 0) sh.dbuf[14] += lap(tq_);
     // When the smoother's whole operand panel fits in LDS the weights go there directly ([line][vp],
     // Wp = M rounded to the VP tile) as well as to HBM, and smooth_full skips its staging pass.
     const int Wp = ((M + MT - 1) / MT) * MT;
     const bool panel = c.prm.use_weights && M > 0 && M <= 32 && (long long)N * Wp <= c.wt_doubles;
     double* wt = WT();
+    // one thread per line; the VP loop is unrolled four deep with the four sqrt/div/exp chains written
+    // side by side (independent until the ordered sum), because a lone wave per SIMD is bound by the
+    // latency of that dependent chain, not by issue
+    cgdp gmx = c.drow, gmy = c.drow + c.ldn, gvx = c.drow + 2 * (size_t)c.ldn, gvy = c.drow + 3 * (size_t)c.ldn,
+         gn2 = c.drow + 4 * (size_t)c.ldn;
+    constexpr int EU = 4;
     for (int n = tid(); n < N; n += nthreads()) {
-        cgdp q = c.lp + 4 * (size_t)n;
-        double lmx = 0.5 * (q[0] + q[2]), lmy = 0.5 * (q[1] + q[3]);
-        double v2x = q[0] - q[2], v2y = q[1] - q[3];
-        double n2 = norm2(v2x, v2y);
+        const double lmx = gmx[n], lmy = gmy[n], v2x = gvx[n], v2y = gvy[n], n2 = gn2[n];
+        gdp lvq = c.lvsq + n, pvq = c.pvl + n;
+        double* wl = wt + (size_t)n * Wp;                    // this line's panel row; parks p_lv p_v until p_l is known
         double pl = 0.0;
-        for (int m = 0; m < M; ++m) {
-            double v1x = lmx - sh.vx[m], v1y = lmy - sh.vy[m];
-            double n1 = norm2(v1x, v1y);
-            double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
-            double lv = cc * cc;                             // :174
-            c.lvsq[(size_t)m * c.ldn + n] = lv;
-            double plv = exp(-(lv / (2 * sh.s[m]))) * sh.k2[m];   // calc_plv :137-145
-            double t = plv * sh.pv[m];
-            c.pvl[(size_t)m * c.ldn + n] = t;
-            pl += t;                                         // p_l = dot(p_lv, p_v) :116
+        int m = 0;
+        for (; m + EU <= M; m += EU) {
+            double lv[EU], tt[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const double v1x = lmx - sh.vx[m + u], v1y = lmy - sh.vy[m + u];
+                const double n1 = norm2(v1x, v1y);
+                const double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
+                lv[u] = cc * cc;                             // :174
+            }
+#pragma unroll
+            for (int u = 0; u < EU; ++u)
+                tt[u] = (exp_underflow(-(lv[u] / (2 * sh.s[m + u]))) * sh.k2[m + u]) * sh.pv[m + u];   // calc_plv :137-145
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                lvq[(size_t)(m + u) * c.ldn] = lv[u];
+                if (panel) wl[m + u] = tt[u]; else pvq[(size_t)(m + u) * c.ldn] = tt[u];
+                pl += tt[u];                                 // p_l = dot(p_lv, p_v) :116, in VP order
+            }
+        }
+        for (; m < M; ++m) {
+            const double v1x = lmx - sh.vx[m], v1y = lmy - sh.vy[m];
+            const double n1 = norm2(v1x, v1y);
+            const double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
+            const double lv1 = cc * cc;
+            lvq[(size_t)m * c.ldn] = lv1;
+            const double t1 = (exp_underflow(-(lv1 / (2 * sh.s[m]))) * sh.k2[m]) * sh.pv[m];
+            if (panel) wl[m] = t1; else pvq[(size_t)m * c.ldn] = t1;
+            pl += t1;
         }
         pl = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;        // :117
-        double lw = c.lweight[n];
+        const double lw = c.lweight[n];
         gdp ws = c.wsrc + (size_t)n * c.mcap;
-        double* wl = wt + (size_t)n * Wp;
-        for (int m = 0; m < M; ++m) {
-            double pvl = c.pvl[(size_t)m * c.ldn + n] / pl;  // calc_pvl :128
-            c.pvl[(size_t)m * c.ldn + n] = pvl;
-            ws[m] = pvl * lw;                                // weight_matrix :519
-            if (panel) wl[m] = pvl * lw;
+        m = 0;
+        for (; m + EU <= M; m += EU) {
+            double q[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) q[u] = panel ? wl[m + u] : pvq[(size_t)(m + u) * c.ldn];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) q[u] = q[u] / pl;   // calc_pvl :128
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                pvq[(size_t)(m + u) * c.ldn] = q[u];
+                ws[m + u] = q[u] * lw;                       // weight_matrix :519
+                if (panel) wl[m + u] = q[u] * lw;
+            }
         }
-        for (int m = M; m < Wp; ++m) {                       // padding of the last VP tile
+        for (; m < M; ++m) {
+            const double q1 = (panel ? wl[m] : pvq[(size_t)m * c.ldn]) / pl;
+            pvq[(size_t)m * c.ldn] = q1;
+            ws[m] = q1 * lw;
+            if (panel) wl[m] = q1 * lw;
+        }
+        for (m = M; m < Wp; ++m) {                           // padding of the last VP tile
             ws[m] = 0.0;
             if (panel) wl[m] = 0.0;
         }
     }
+    if (tid() == 0) sh.dbuf[15] += lap(tq_);
     if (tid() == 0) sh.ibuf[5] = panel ? Wp : 0;             // consumed (and cleared) by smooth()
     block_sync();
 }
@@ -1692,6 +1759,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         block_sync();
     }
     weights_setup(c);                                         // :227-235
+    line_geometry_setup(c);
     for (int m = tid(); m < MAXM; m += nthreads()) {
         sh.s[m] = 1.0 * (sh.sigma_prior * 1e-6);              // :219,:239
         sh.nxt[3 * m] = 0; sh.nxt[3 * m + 1] = 0; sh.nxt[3 * m + 2] = 0;
@@ -1795,6 +1863,8 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             trace_put(o, P.num_iter, 2, (double)(clock_ticks() - t_begin) * CLOCK_US);
             trace_put(o, P.num_iter, 6, sh.dbuf[8] + sh.dbuf[10]);   // smoother: operand staging + partial reduction
             trace_put(o, P.num_iter, 7, sh.dbuf[9]);                  // smoother: main loop (wave 0)
+            trace_put(o, P.num_iter, 8, sh.dbuf[14]);                 // E-step: prior part
+            trace_put(o, P.num_iter, 9, sh.dbuf[15]);                 // E-step: line part
             write_result(c, o, VPK_EM_OK, i);                 // :439-442
             return;
         }

@@ -53,7 +53,7 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.pvl = o;     o += (size_t)mcap * n;
     L.w = o;       o += (size_t)mcap * n;
     L.wsrc = o;    o += n * (size_t)mcap;
-    L.drow = o;    o += (size_t)nwaves * n;
+    L.drow = o;    o += 6 * n;                         // E-step line constants [5][n] + p_l [n]
     L.part = o;    o += (size_t)nwaves * mcap * n;   // row-slice partials of the smoother
     L.cl = o;      o += do_split ? n * n : 8;
     L.assoc = o;   o += em_align(n, 2) / 2;            // n ints

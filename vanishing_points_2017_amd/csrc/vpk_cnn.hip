@@ -15,8 +15,6 @@
 // 0.6 GB at B = 102; 288 GB of HBM3E makes chunking unnecessary up to B ~ 4000).
 #include "vpk_internal.hpp"
 
-#include <cstdio>
-#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -476,7 +474,7 @@ void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const 
                 int stride, int* counter) {
     long long ntiles = (d.N + 127) / 128;
     long long total = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
-    long long blocks = std::min<long long>(total, (getenv("VPK_CNN_STATIC") ? 1000000ll : 3ll) * h->num_cu);     // three workgroups fit a CU (LDS)
+    long long blocks = std::min<long long>(total, 3ll * h->num_cu);     // three workgroups fit a CU (LDS)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, l.wp, l.bias, l.ktab,
                        out, stride, counter, (int)total);
 }
@@ -518,10 +516,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         return d;
     };
     int evi = 0;
-    int dbg_stop = getenv("VPK_CNN_STOP") ? atoi(getenv("VPK_CNN_STOP")) : 99, dbg_n = 0;
     auto mark = [&]() {
         if (S->profiling && evi < 14) (void)hipEventRecord(S->ev[evi++], st);
-        if (++dbg_n >= dbg_stop) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "stage %d: %s\n", dbg_n, hipGetErrorString(e)); }
     };
     int rc;
     mark();

@@ -7,7 +7,6 @@
 #include "vpk_internal.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -15,7 +14,13 @@ using namespace vpk;
 
 namespace {
 
-constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD, up to 2 workgroups per CU by LDS
+constexpr int EM_THREADS = 512;   // 8 waves: 2 per SIMD
+// One workgroup per CU: the (non-inlined) phase functions touch ~250 VGPRs each -- the calling
+// convention's callee-saved registers are striped through the file, so the allocator spreads over all of
+// it -- and two waves per SIMD fill the register file.  Declaring the kernels for 1024 threads makes
+// hipcc give the phases 128 VGPRs and two workgroups fit, but measured (r1): every phase slows down by
+// 15-40 % (spills, narrower smoother) and the batch gains nothing at YUD sizes, +5 % at the stress shape.
+constexpr int EM_BOUND = EM_THREADS;
 constexpr int EM_WAVES = EM_THREADS / 64;
 // dynamic LDS: [Shared | smoother operand tile]; ~77 KiB -> two workgroups per CU (160 KiB)
 constexpr size_t EM_LDS_BYTES = SH_BYTES + WT_DOUBLES * sizeof(double);
@@ -56,7 +61,7 @@ struct EmBatchArgs {
     int wt_doubles;
 };
 
-__global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
+__global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a) {
     VPK_SHARED_DECL;
     for (;;) {
         if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(EM_THREADS) void em_batch_kernel(EmBatchArgs a) {
 }
 
 // ---- fine-grained kernels (one workgroup, unit parity) ------------------------------------------
-__global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
+__global__ __launch_bounds__(EM_BOUND) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
                                                               double* lsim_out, double* lscore_out,
                                                               double* langle_out) {
     VPK_SHARED_DECL;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(EM_THREADS) void pairwise_kernel(int n, const doubl
     for (int i = tid(); i < n; i += nthreads()) { lscore_out[i] = c.lscore[i]; langle_out[i] = c.langle[i]; }
 }
 
-__global__ __launch_bounds__(EM_THREADS) void init_vps_kernel(const float* cnn, const unsigned char* sphere,
+__global__ __launch_bounds__(EM_BOUND) void init_vps_kernel(const float* cnn, const unsigned char* sphere,
                                                               int ssize, int num_max, double* v0_out,
                                                               int* m0_out, float* weights_out) {
     VPK_SHARED_DECL;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(EM_THREADS) void init_vps_kernel(const float* cnn, 
     for (int k = tid(); k < NCELL; k += nthreads()) weights_out[k] = sh.wts[k];
 }
 
-__global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const double* lp, const float* cnn,
+__global__ __launch_bounds__(EM_BOUND) void estep_kernel(int n, int m, const double* lp, const float* cnn,
                                                            const double* v, double* s, EmLayout L, double* ws,
                                                            double* p_v_out, double* lvsq_out, double* p_vl_out,
                                                            double* p_l_out) {
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const d
     for (int k = tid(); k < m; k += nthreads()) sh.s[k] = s[k];
     if (tid() == 0) sh.M = m;
     block_sync();
+    line_geometry_setup(c);
     estep(c, sh.cur);
     for (int k = tid(); k < m; k += nthreads()) { s[k] = sh.s[k]; p_v_out[k] = sh.pv[k]; }
     for (int p = tid(); p < m * n; p += nthreads()) {
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(EM_THREADS) void estep_kernel(int n, int m, const d
     }
 }
 
-__global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m, const double* p_vl,
+__global__ __launch_bounds__(EM_BOUND) void weight_matrix_kernel(int n, int m, const double* p_vl,
                                                                    const double* lweight, const double* lsim,
                                                                    double bias, EmLayout L, double* ws,
                                                                    double* w_out) {
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(EM_THREADS) void weight_matrix_kernel(int n, int m,
     for (int p = tid(); p < m * n; p += nthreads()) w_out[p] = c.w[(size_t)(p / n) * c.ldn + p % n];
 }
 
-__global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const double* l, const double* w,
+__global__ __launch_bounds__(EM_BOUND) void mstep_kernel(int n, int m, const double* l, const double* w,
                                                            EmLayout L, double* ws, double* vp_out,
                                                            int* valid_out) {
     VPK_SHARED_DECL;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(EM_THREADS) void mstep_kernel(int n, int m, const d
     }
 }
 
-__global__ __launch_bounds__(EM_THREADS) void cluster2_kernel(int n, double* D, int* member, int* csize,
+__global__ __launch_bounds__(EM_BOUND) void cluster2_kernel(int n, double* D, int* member, int* csize,
                                                               int* labels_out, unsigned* flags_out) {
     VPK_SHARED_DECL;
     if (tid() == 0) sh.flags = 0;
@@ -257,32 +263,11 @@ int em_prepare(vpk_handle* h) {
     return VPK_OK;
 }
 
-// How many workgroups share a CU, and how much LDS each gets for the smoother's operand panel.
-//   1 per CU, 128 KiB panel : small batches, and big batches whose N x W panel needs it (single pass over lsim)
-//   2 per CU,  48 KiB panel : big batches whose panel fits 48 KiB
-//   3 per CU,  16 KiB panel : big batches of large images with few VPs (the HBM-streaming stress shape):
-//                             the panel is chunked anyway, so more workgroups per CU = more overlap
+// One workgroup per CU (see EM_BOUND), with the whole remaining LDS (128 KiB) as the smoother's operand
+// panel: single-pass smoothing for every image whose N x W panel fits.
 struct EmMode { int per_cu; int wt_doubles; size_t lds_bytes; };
-constexpr int WT_DOUBLES_SMALL = 2048;
-EmMode em_mode(const vpk_handle* h, int batch, int nmax, int mcap) {
-    const size_t panel = (size_t)nmax * (size_t)(mcap > 32 ? 32 : mcap) * sizeof(double);
-    EmMode big{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
-    EmMode mid{2, WT_DOUBLES, EM_LDS_BYTES};
-    EmMode small{3, WT_DOUBLES_SMALL, SH_BYTES + WT_DOUBLES_SMALL * sizeof(double)};
-    if (const char* f = getenv("VPK_EM_WT")) {         // development override: panel doubles
-        const int wt = atoi(f);
-        return EmMode{1, wt, SH_BYTES + (size_t)wt * sizeof(double)};
-    }
-    if (const char* f = getenv("VPK_EM_MODE")) {       // development override: 1 = big, 2 = mid, 3 = small
-        if (f[0] == '1') return big;
-        if (f[0] == '2') return mid;
-        if (f[0] == '3') return small;
-    }
-    if (batch <= h->num_cu) return big;
-    if (panel <= WT_DOUBLES * sizeof(double)) return mid;
-    if (mcap <= MT) return small;
-    if (panel <= WT_DOUBLES_BIG * sizeof(double)) return big;
-    return mid;
+EmMode em_mode(const vpk_handle*, int, int, int) {
+    return EmMode{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
 }
 
 int em_slots(const vpk_handle* h, int batch, size_t slot_bytes, int per_cu) {
@@ -394,9 +379,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
     a.wt_doubles = mode.wt_doubles;
-    int threads = EM_THREADS;
-    if (const char* f = getenv("VPK_EM_THREADS")) threads = atoi(f);   // development override
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(threads), mode.lds_bytes, h->stream, a);
+    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), mode.lds_bytes, h->stream, a);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
