@@ -201,16 +201,21 @@ def main():
         key = "yud_102" if (args.workload == "yud" and count == 102) else (
             "stress_512x1000x8x50" if (args.workload == "stress" and count == 512) else None)
         t = traffic.get(key) if key else None
+        tc = traffic.get(key + "_conv") if key else None
         roof_em = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None}
-        name = max(cnn.Net.LAYER_FLOP, key=lambda k: layer_ms[k])
+        name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])   # the layer with the most arithmetic (conv2)
         flop = cnn.Net.LAYER_FLOP[name] * count
         roof_cnn = {"kernel": "conv_gemm_dma_kernel(%s)" % name, "bound": "mfma",
                     "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "traffic": None}
+                    "unit": "TFLOP/s",
+                    "traffic": (tc["hbm_read_bytes"] + tc["hbm_write_bytes"]) if tc else None,
+                    "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel"}
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
-        roof = roof_em if (em_ms >= cnn_ms or args.workload == "stress") else roof_cnn
+        # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step,
+        # each EM stream one batch every n_lanes steps
+        roof = roof_em if (em_ms / n_lanes >= cnn_ms or args.workload == "stress") else roof_cnn
         roof["frac"] = roof["achieved"] / roof["peak"]
         line = {
             "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU" if args.workload == "yud"
