@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
+    ap.add_argument("--em-wgs", type=int, default=-1,
+                    help="workgroups (CUs) per EM launch; default: images/3 for yud (the launch lasts as long as its "
+                         "slowest image either way, and the CNN keeps the other CUs), one per image for stress")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images timed on the CPU (default 6 yud / 1 stress)")
     return ap.parse_args()
@@ -111,6 +114,9 @@ def main():
     rt = lanes[0]
     rt_cnn = get_runtime(local_rank, "cnn")
     count = args.images or (102 if args.workload == "yud" else 512)
+    em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if args.workload == "yud" else 0)
+    for r in lanes:
+        r.handle.em_set_workgroups(em_wgs)
     scenes, kw = make_workload(args.workload, rank, count)
     weights = cnn.synthetic_weights(0)
     mean = cnn.synthetic_mean(0)
@@ -228,7 +234,7 @@ def main():
                                    % count if args.workload == "yud" else
                                    "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
                        "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
-            "stage_ms": {"cnn": cnn_ms, "em": em_ms, "em_lanes": n_lanes,
+            "stage_ms": {"cnn": cnn_ms, "em": em_ms, "em_lanes": n_lanes, "em_workgroups": em_wgs,
                          "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"},
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),

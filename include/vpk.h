@@ -84,6 +84,12 @@ int vpk_version(void);
 void vpk_em_default_params(vpk_em_params* p);
 /* device properties as seen by the library: [0]=CU count, [1]=LDS bytes per block, [2]=gfx arch number */
 int vpk_device_info(const vpk_handle* h, int32_t info[4]);
+/* Upper bound on the persistent workgroups (= CUs held) of one vpk_em_batch launch; 0 = one per image up
+ * to the CU count (lowest latency for a single call).  A pipeline that runs other kernels beside the EM
+ * (the reference's run_cnn of the next batch, evaluation.py:254-292) sets about batch/3: the images
+ * queue inside the launch, which then lasts about as long as its slowest image anyway and leaves the
+ * other CUs to the CNN. */
+int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
 
 /* ---- CNN (AlexNet-500, cnn/deploy.prototxt:1-304) -------------------------------------------- */
 /* replaces: caffe.Net(model_def, model_weights, caffe.TEST) + read_mean_blob

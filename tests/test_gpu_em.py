@@ -130,6 +130,26 @@ def test_ragged_batch_equals_single_runs():
             assert np.array_equal(a["vp"], b["vp"]) and np.array_equal(a["vp_assoc"], b["vp_assoc"])
 
 
+def test_workgroup_cap_queues_images():
+    """vpk_em_set_workgroups: fewer persistent workgroups than images -> the images queue inside the launch;
+    results are bit-identical to the uncapped launch."""
+    from vanishing_points_2017_amd import em as gem
+    from vanishing_points_2017_amd.runtime import get_runtime
+    names = [c for c in CASES if not any(k.startswith("kw_") for k in load(c))]
+    gs = [load(n) for n in names]
+    ref = gem.em_batch([_scene(g) for g in gs])
+    rt = get_runtime(0)
+    rt.handle.em_set_workgroups(3)
+    try:
+        res = gem.em_batch([_scene(g) for g in gs])
+    finally:
+        rt.handle.em_set_workgroups(0)
+    for a, b, g in zip(ref, res, gs):
+        check_em_result(b, g)
+        assert np.array_equal(a["vp"], b["vp"]) and np.array_equal(a["vp_assoc"], b["vp_assoc"])
+        assert a["iterations"] == b["iterations"]
+
+
 def test_against_oracle_on_fresh_scenes():
     """YUD-shape scenes not in the golden set: GPU vs CPU oracle, same seeded inputs."""
     from oracle import em_numpy as em

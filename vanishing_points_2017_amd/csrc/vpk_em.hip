@@ -272,6 +272,7 @@ EmMode em_mode(const vpk_handle*, int, int, int) {
 
 int em_slots(const vpk_handle* h, int batch, size_t slot_bytes, int per_cu) {
     int slots = h->num_cu * per_cu;
+    if (h->em_max_workgroups > 0 && slots > h->em_max_workgroups) slots = h->em_max_workgroups;
     if (slots > batch) slots = batch;
     size_t budget = h->total_mem / 2;                // never claim more than half of HBM
     while (slots > 1 && (size_t)slots * slot_bytes > budget) slots /= 2;
@@ -294,6 +295,12 @@ EmLayout small_layout(int n, int m) {
 }  // namespace
 
 extern "C" {
+
+int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups) {
+    if (!h || max_workgroups < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_workgroups: bad argument");
+    h->em_max_workgroups = max_workgroups;
+    return VPK_OK;
+}
 
 size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const vpk_em_params* p, int n_init) {
     if (!h || !p || batch < 1) return 0;

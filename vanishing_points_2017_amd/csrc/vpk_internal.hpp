@@ -16,6 +16,7 @@ struct vpk_handle {
     bool own_stream = false;
     std::string err;
     int num_cu = 0;
+    int em_max_workgroups = 0;   // vpk_em_set_workgroups (0 = no cap)
     int lds_per_block = 0;
     int arch = 0;
     size_t total_mem = 0;
