@@ -341,6 +341,90 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restri
     }
 }
 
+// Tiled version of the same fused layer: a workgroup owns TPH x TPW pooled outputs of 16 channels.
+//   1. the raw input patch ((2 TPH + 1) x (2 TPW + 1) pixels, 16 + 4 halo channels) goes to LDS;
+//   2. one thread per pixel walks the channels with a 5-deep register window and overwrites the patch in
+//      place with the normalised values -- every pixel is normalised ONCE (the thread-per-output kernel
+//      above normalises each of its 9 taps itself: 2.25x the transcendental work and 9 dependent global
+//      loads per channel, which made it latency-bound);
+//   3. 3x3 / stride 2 max over the patch in LDS (window clipped at the border like Caffe), written into the
+//      next convolution's bordered planes.
+template <int TPH, int TPW>
+__global__ __launch_bounds__(256) void lrn5_pool3s2_tiled_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 int C, int H, int W, int PH, int PW, float alpha,
+                                                                 float beta, int PHp, int PWp, int opad) {
+    constexpr int CC = LRN_CCH, NPL = CC + 4;
+    constexpr int TR = 2 * TPH + 1, TC = 2 * TPW + 1, NPIX = TR * TC;
+    __shared__ float patch[NPL][NPIX];
+    const int tiles_w = (PW + TPW - 1) / TPW, tiles_h = (PH + TPH - 1) / TPH;
+    const int nch = (C + CC - 1) / CC;
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int ch = bid % nch;
+    const int b = bid / nch;
+    const int c0 = ch * CC;
+    const int ph0 = th * TPH, pw0 = tw * TPW;
+    const int h0 = 2 * ph0, w0 = 2 * pw0;
+    const int HW = H * W;
+    const float* x = in + (size_t)b * C * HW;
+    // 1. raw patch (zeros outside the blob: they only ever meet clipped windows or the LRN's zero padding)
+    constexpr int LU = 8;                               // loads in flight per thread (the loop is latency-bound without them)
+    for (int e0 = threadIdx.x; e0 < NPL * NPIX; e0 += 256 * LU) {
+        float v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = e0 + u * 256;
+            const int pl = e / NPIX, p = e - pl * NPIX;
+            const int r = p / TC, q = p - r * TC;
+            const int c = c0 - 2 + pl, h = h0 + r, w = w0 + q;
+            v[u] = 0.f;
+            if (e < NPL * NPIX && c >= 0 && c < C && h < H && w < W) v[u] = x[(size_t)c * HW + (size_t)h * W + w];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = e0 + u * 256;
+            if (e < NPL * NPIX) patch[0][e] = v[u];     // patch is contiguous: [pl][p] == flat e
+        }
+    }
+    __syncthreads();
+    // 2. normalise in place, one thread per pixel
+    const float an = alpha / 5.f;
+    for (int p = threadIdx.x; p < NPIX; p += 256) {
+        float v0 = patch[0][p], v1 = patch[1][p], v2 = patch[2][p], v3 = patch[3][p];
+#pragma unroll
+        for (int k = 0; k < CC; ++k) {
+            const float v4 = patch[k + 4][p];
+            const float sc = 1.f + an * (v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4);
+            float pw_;
+            if (beta == 0.75f) { const float r = rsqrtf(sc); pw_ = r * sqrtf(r); }
+            else pw_ = powf(sc, -beta);
+            patch[k + 2][p] = v2 * pw_;                  // plane k+2 holds channel c0+k; its raw value lives in v2
+            v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+        }
+    }
+    __syncthreads();
+    // 3. pool
+    for (int e = threadIdx.x; e < CC * TPH * TPW; e += 256) {
+        const int k = e / (TPH * TPW), o = e - k * (TPH * TPW);
+        const int oy = o / TPW, ox = o - oy * TPW;
+        const int ph = ph0 + oy, pw = pw0 + ox, c = c0 + k;
+        if (ph >= PH || pw >= PW || c >= C) continue;
+        float m = -3.402823466e38f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int r = 2 * oy + dy, q = 2 * ox + dx;
+                if (h0 + r < H && w0 + q < W) {          // Caffe clips the window at the border
+                    const float v = patch[k + 2][r * TC + q];
+                    m = v > m ? v : m;
+                }
+            }
+        out[((size_t)b * C + c) * PHp * PWp + (size_t)(ph + opad) * PWp + pw + opad] = m;
+    }
+}
+
 // MAX pooling 3x3 stride 2, Caffe ceil mode with clipped windows (deploy.prototxt:45-55)
 __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, long long BC, int H, int W,
                                int PH, int PW, int ksz, int stride) {
@@ -529,8 +613,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
     // norm1 + pool1 (fused), written with conv2's border
-    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 61 * 61 * ((96 + LRN_CCH - 1) / LRN_CCH))),
-                       dim3(256), 0, st, R[R_CONV1], R[R_POOL1], batch, 96, 123, 123, 61, 61, 1e-4f, 0.75f, 65, 65, 2);
+    hipLaunchKernelGGL((lrn5_pool3s2_tiled_kernel<7, 16>), dim3((unsigned)(batch * ((96 + LRN_CCH - 1) / LRN_CCH) * 9 * 4)),
+                       dim3(256), 0, st, R[R_CONV1], R[R_POOL1], 96, 123, 123, 61, 61, 1e-4f, 0.75f, 65, 65, 2);
     mark();
     mark();
     tapunpad(1, R[R_POOL1], 96, 61, 61, 2);
@@ -539,8 +623,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
     // norm2 + pool2 (fused), written with conv3's border
-    hipLaunchKernelGGL(lrn5_pool3s2_kernel, dim3(ew_blocks((long long)batch * 30 * 30 * ((256 + LRN_CCH - 1) / LRN_CCH))),
-                       dim3(256), 0, st, R[R_CONV2], R[R_POOL2], batch, 256, 61, 61, 30, 30, 1e-4f, 0.75f, 32, 32, 1);
+    hipLaunchKernelGGL((lrn5_pool3s2_tiled_kernel<6, 15>), dim3((unsigned)(batch * ((256 + LRN_CCH - 1) / LRN_CCH) * 5 * 2)),
+                       dim3(256), 0, st, R[R_CONV2], R[R_POOL2], 256, 61, 61, 30, 30, 1e-4f, 0.75f, 32, 32, 1);
     mark();
     mark();
     tapunpad(3, R[R_POOL2], 256, 30, 30, 1);

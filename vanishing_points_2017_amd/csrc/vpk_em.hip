@@ -271,7 +271,7 @@ EmMode em_mode(const vpk_handle*, int, int, int) {
 }
 
 int em_slots(const vpk_handle* h, int batch, size_t slot_bytes, int per_cu) {
-    int slots = h->num_cu * per_cu;
+    int slots = h->cu_share * per_cu;
     if (h->em_max_workgroups > 0 && slots > h->em_max_workgroups) slots = h->em_max_workgroups;
     if (slots > batch) slots = batch;
     size_t budget = h->total_mem / 2;                // never claim more than half of HBM
