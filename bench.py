@@ -22,6 +22,10 @@ import time
 
 import numpy as np
 
+# one hardware queue per stream (1 CNN + the EM lanes + torch's own): with the default of 4 a fifth stream shares
+# a queue, and a CNN kernel can end up queued behind a 20 ms EM kernel.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,79 @@
+"""Lanes (handle + stream pairs) on one GPU: CU-range streams and asynchronous batches give the same bits."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases
+from golden_util import load
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(g):
+    return {"l": g["l"].copy(), "lp": g["lp"], "cnn_response": g["cnn_response"],
+            "sphere_image": g["sphere_image"], "init_vp": g.get("init_vp")}
+
+
+def test_cu_range_lane_matches_default_lane():
+    """vpk_set_cu_range: a stream limited to 4 CUs per XCD computes the same results (the persistent kernels
+    size their grids from the share; no result depends on how many workgroups run)."""
+    import torch
+    from vanishing_points_2017_amd import cnn, em as gem
+    from vanishing_points_2017_amd.runtime import get_runtime
+    names = [c for c in golden_cases() if not any(k.startswith("kw_") for k in load(c))][:4]
+    gs = [load(n) for n in names]
+    rt0 = get_runtime(0)
+    rt1 = get_runtime(0, "masked", cu_range=(2, 4))
+    assert rt1.handle.lib.vpk_get_stream(rt1.h) == rt1.stream.cuda_stream
+    p = gem._params({})
+    outs = []
+    for rt in (rt0, rt1):
+        d = gem.upload_batch(rt, [_scene(g) for g in gs])
+        o = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, p)
+        rt.synchronize()
+        outs.append({k: v.cpu().numpy() for k, v in o.items() if v is not None})
+    for k in ("vp", "vp_assoc", "num_vp", "iterations", "sigma"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    w, mean = cnn.synthetic_weights(0), cnn.synthetic_mean(0)
+    x = np.stack([g["sphere_image"] for g in gs])
+    y0 = cnn.Net(w, mean, device=0, runtime=rt0).forward(x)
+    y1 = cnn.Net(w, mean, device=0, runtime=rt1).forward(x)
+    assert np.array_equal(y0, y1)
+
+
+def test_bad_cu_range_is_rejected():
+    from vanishing_points_2017_amd import _lib
+    h = _lib.Handle(0)
+    with pytest.raises(_lib.VpkError):
+        h.set_cu_range(30, 8)          # 30 + 8 > 32 CUs per XCD
+    h.set_cu_range(0, 0)               # back to an unrestricted stream
+    h.close()
+
+
+def test_queued_batches_on_one_lane_are_independent():
+    """vpk_em_batch is asynchronous: several batches queued on one stream without host synchronisation
+    (the header staging ring wraps) return what they return one at a time."""
+    from vanishing_points_2017_amd import em as gem
+    from vanishing_points_2017_amd.runtime import get_runtime
+    names = [c for c in golden_cases() if not any(k.startswith("kw_") for k in load(c))][:3]
+    gs = [load(n) for n in names]
+    rt = get_runtime(0)
+    p = gem._params({})
+    ds = [gem.upload_batch(rt, [_scene(g)]) for g in gs]
+    def launch(d, keep):
+        with rt.on_stream():           # the copy of l (normalised in place) must be ordered on the lane's stream
+            l = d["l"].clone()
+        keep.append(l)                 # ... and must outlive the launch that reads it
+        return gem.em_batch_device(rt, d["offsets"], l, d["lp"], d["cnn"], d["sphere"], None, p)
+
+    ref, keep = [], []
+    for d in ds:
+        o = launch(d, keep)
+        rt.synchronize()
+        ref.append(o["vp"].cpu().numpy())
+    outs = []
+    for rep in range(3):               # 9 launches back to back: more than the 4 staging buffers
+        for d in ds:
+            outs.append(launch(d, keep))
+    rt.synchronize()
+    for k, o in enumerate(outs):
+        assert np.array_equal(o["vp"].cpu().numpy(), ref[k % len(ds)], equal_nan=True)

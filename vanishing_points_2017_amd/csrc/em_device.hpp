@@ -233,20 +233,33 @@ VPK_DEV void group_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
     double ev[3] = {0, 0, 0};
     for (int pass = 0; pass < 5; ++pass) {
         double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
-        for (int n = lane() % G; n < N; n += G) {
-            const double r = rw(n);
-            if (r == 0) continue;
-            cgdp ln = l + 3 * (size_t)n;
-            double y0, y1, y2;
-            if (pass == 0) {
-                y0 = r * ln[0]; y1 = r * ln[1]; y2 = r * ln[2];
-            } else {
-                y0 = r * (ln[0] * V[0][0] + ln[1] * V[1][0] + ln[2] * V[2][0]);
-                y1 = r * (ln[0] * V[0][1] + ln[1] * V[1][1] + ln[2] * V[2][1]);
-                y2 = r * (ln[0] * V[0][2] + ln[1] * V[1][2] + ln[2] * V[2][2]);
+        // four lines per step with all their loads issued first: with 16 lanes per VP a lane walks N/16
+        // lines, and one L2 round trip per line was most of the M-step
+        constexpr int LB = 4;
+        for (int n0 = lane() % G; n0 < N; n0 += LB * G) {
+            double r[LB], a0[LB], a1[LB], a2[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int n = n0 + u * G;
+                const bool in = n < N;
+                r[u] = in ? rw(n) : 0.0;
+                cgdp ln = l + 3 * (size_t)(in ? n : 0);
+                a0[u] = ln[0]; a1[u] = ln[1]; a2[u] = ln[2];
             }
-            g00 += y0 * y0; g01 += y0 * y1; g02 += y0 * y2;
-            g11 += y1 * y1; g12 += y1 * y2; g22 += y2 * y2;
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                if (r[u] == 0) continue;
+                double y0, y1, y2;
+                if (pass == 0) {
+                    y0 = r[u] * a0[u]; y1 = r[u] * a1[u]; y2 = r[u] * a2[u];
+                } else {
+                    y0 = r[u] * (a0[u] * V[0][0] + a1[u] * V[1][0] + a2[u] * V[2][0]);
+                    y1 = r[u] * (a0[u] * V[0][1] + a1[u] * V[1][1] + a2[u] * V[2][1]);
+                    y2 = r[u] * (a0[u] * V[0][2] + a1[u] * V[1][2] + a2[u] * V[2][2]);
+                }
+                g00 += y0 * y0; g01 += y0 * y1; g02 += y0 * y2;
+                g11 += y1 * y1; g12 += y1 * y2; g22 += y2 * y2;
+            }
         }
         g00 = group_sum<G>(g00); g01 = group_sum<G>(g01); g02 = group_sum<G>(g02);
         g11 = group_sum<G>(g11); g12 = group_sum<G>(g12); g22 = group_sum<G>(g22);
@@ -1213,14 +1226,28 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         double sv = 0, sp = 0;
         cgdp lvs = c.lvsq + (size_t)m * c.ldn;
         cgdp pvl = c.pvl + (size_t)m * c.ldn;
-        for (int n = gl; n < N; n += G) {
-            double pq = pvl[n];
-            sv += lvs[n] * pq;                                // :303 (all lines, also in hard mode :374)
-            sp += pq;
-            if (mode == 1 && c.assoc[n] != m) continue;
-            wmax = nanmax(wmax, wm[n]);
-            ++nsel;
-            selidx = n;
+        constexpr int LB = 4;                                 // loads of four lines in flight (see group_null_vector)
+        for (int n0 = gl; n0 < N; n0 += LB * G) {
+            double pq[LB], lq[LB], wq[LB];
+            int aq[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int n = n0 + u * G;
+                const int nc = n < N ? n : 0;
+                pq[u] = pvl[nc]; lq[u] = lvs[nc]; wq[u] = wm[nc];
+                aq[u] = mode == 1 ? c.assoc[nc] : m;
+            }
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int n = n0 + u * G;
+                if (n >= N) break;
+                sv += lq[u] * pq[u];                          // :303 (all lines, also in hard mode :374)
+                sp += pq[u];
+                if (mode == 1 && aq[u] != m) continue;
+                wmax = nanmax(wmax, wq[u]);
+                ++nsel;
+                selidx = n;
+            }
         }
         wmax = group_max<G>(wmax);
         nsel = group_sum_int<G>(nsel);

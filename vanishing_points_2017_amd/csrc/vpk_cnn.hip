@@ -282,71 +282,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
 }
 
 
-// Fused LRN (across channels, local_size 5) + MAX pool 3x3 stride 2 (deploy.prototxt:34-55, 82-103):
-// one thread per pooled output (b, ph, pw) walks the channels keeping a 5-deep register window for
-// each of the 9 taps of its pooling footprint, so the normalised map (0.6 GB at B = 102 for norm1)
-// is never written to or re-read from HBM: traffic = conv output once (L1/L2 absorb the 2.25x
-// footprint overlap) + the pooled output.
-constexpr int LRN_CCH = 16;   // channels per thread (plus a 2-channel halo on each side)
-// The pooled map is written into planes of PHp x PWp at offset opad (the next convolution's zero border).
-__global__ __launch_bounds__(256) void lrn5_pool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
-                                                           int C, int H, int W, int PH, int PW, float alpha,
-                                                           float beta, int PHp, int PWp, int opad) {
-    const int nch = (C + LRN_CCH - 1) / LRN_CCH;
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * nch * PH * PW) return;
-    const int pw = (int)(idx % PW);
-    const int ph = (int)((idx / PW) % PH);
-    const int ch = (int)((idx / ((long long)PW * PH)) % nch);
-    const int b = (int)(idx / ((long long)PW * PH * nch));
-    const int c0 = ch * LRN_CCH;
-    const int c1 = (c0 + LRN_CCH) < C ? (c0 + LRN_CCH) : C;
-    const int HW = H * W;
-    const float* x = in + (size_t)b * C * HW;
-    float* y = out + (size_t)b * C * PHp * PWp + (size_t)(ph + opad) * PWp + pw + opad;
-    int off[9];
-    bool ok[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int h = ph * 2 + t / 3, w = pw * 2 + t % 3;
-        ok[t] = h < H && w < W;                         // Caffe clips the window at the border
-        off[t] = ok[t] ? h * W + w : 0;
-    }
-    const float an = alpha / 5.f;
-    float v0[9], v1[9], v2[9], v3[9];                   // x[c-2], x[c-1], x[c], x[c+1] per tap
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        v0[t] = (c0 - 2 >= 0) ? x[(size_t)(c0 - 2) * HW + off[t]] : 0.f;
-        v1[t] = (c0 - 1 >= 0) ? x[(size_t)(c0 - 1) * HW + off[t]] : 0.f;
-        v2[t] = x[(size_t)c0 * HW + off[t]];
-        v3[t] = (c0 + 1 < C) ? x[(size_t)(c0 + 1) * HW + off[t]] : 0.f;
-    }
-    for (int c = c0; c < c1; ++c) {
-        float m = -3.402823466e38f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float v4 = (c + 2 < C) ? x[(size_t)(c + 2) * HW + off[t]] : 0.f;
-            const float sum = v0[t] * v0[t] + v1[t] * v1[t] + v2[t] * v2[t] + v3[t] * v3[t] + v4 * v4;
-            // scale^-beta: beta = 0.75 in this net -> rsqrt(s) * sqrt(rsqrt(s)) (two hardware
-            // transcendentals, ~1 ulp) instead of a ~80-instruction powf per tap
-            const float sc = 1.f + an * sum;
-            float pw_;
-            if (beta == 0.75f) { const float r = rsqrtf(sc); pw_ = r * sqrtf(r); }
-            else pw_ = powf(sc, -beta);
-            const float val = v2[t] * pw_;
-            if (ok[t]) m = val > m ? val : m;
-            v0[t] = v1[t]; v1[t] = v2[t]; v2[t] = v3[t]; v3[t] = v4;
-        }
-        y[(size_t)c * PHp * PWp] = m;
-    }
-}
-
-// Tiled version of the same fused layer: a workgroup owns TPH x TPW pooled outputs of 16 channels.
+// Fused LRN (across channels, local_size 5, x * (1 + alpha/n * sum x^2)^-beta) + MAX pool 3x3 stride 2, ceil
+// mode with clipped windows (deploy.prototxt:34-55, 82-103): the normalised map (0.6 GB at B = 102 for
+// norm1) is never written to or re-read from HBM.
+constexpr int LRN_CCH = 16;   // channels per workgroup (plus a 2-channel halo on each side)
+// A workgroup owns TPH x TPW pooled outputs of 16 channels.
 //   1. the raw input patch ((2 TPH + 1) x (2 TPW + 1) pixels, 16 + 4 halo channels) goes to LDS;
 //   2. one thread per pixel walks the channels with a 5-deep register window and overwrites the patch in
-//      place with the normalised values -- every pixel is normalised ONCE (the thread-per-output kernel
-//      above normalises each of its 9 taps itself: 2.25x the transcendental work and 9 dependent global
-//      loads per channel, which made it latency-bound);
+//      place with the normalised values -- every pixel is normalised ONCE (a thread per pooled output
+//      normalises each of its 9 taps itself: 2.25x the work and 9 dependent global loads per channel);
 //   3. 3x3 / stride 2 max over the patch in LDS (window clipped at the border like Caffe), written into the
 //      next convolution's bordered planes.
 template <int TPH, int TPW>
