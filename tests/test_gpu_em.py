@@ -164,3 +164,46 @@ def test_against_oracle_on_fresh_scenes():
         assert np.array_equal(r["vp_assoc"], ref["vp_assoc"])
         assert abserr(r["vp"], ref["vp"]) <= 1e-4
         assert np.array_equal(r["counts"], ref["counts"])
+
+
+def test_edge_cases_in_one_ragged_batch():
+    """Degenerate images next to ordinary ones in one launch: no lines, two lines, a blank CNN response (the
+    reference raises ValueError at vp_localisation.py:165), and 40 supplied VPs (more than one smoother pass
+    and more hypotheses than the 32 accumulators).  Checked against the CPU oracle."""
+    from oracle import em_numpy as em
+    from vanishing_points_2017_amd import em as gem, synth
+    base = list(synth.config_scenes(2, count=3, start=50))
+    empty = dict(base[0], l=np.zeros((0, 3)), lp=np.zeros((0, 4)))
+    two = dict(base[1], l=base[1]["l"][:2].copy(), lp=base[1]["lp"][:2].copy())
+    blank = dict(base[2], cnn_response=np.zeros((20, 20), dtype=np.float32))
+    res = gem.em_batch([base[0], empty, two, blank, base[1]])
+    for k in (0, 4):
+        sc = base[0] if k == 0 else base[1]
+        ref = em.expectation_maximisation(sc["l"].copy(), sc["lp"].copy(), sc["cnn_response"].copy(),
+                                          sphere_image=sc["sphere_image"])
+        assert res[k]["status"] == 0 and np.array_equal(res[k]["vp_assoc"], ref["vp_assoc"])
+        assert abserr(res[k]["vp"], ref["vp"]) <= 1e-4
+    assert res[1]["status"] != 0 and res[1]["vp"] is None                 # nothing to estimate from
+    ref2 = em.expectation_maximisation(two["l"].copy(), two["lp"].copy(), two["cnn_response"].copy(),
+                                       sphere_image=two["sphere_image"])
+    if ref2["vp"] is None:
+        assert res[2]["vp"] is None
+    else:
+        assert np.array_equal(res[2]["vp_assoc"], ref2["vp_assoc"]) and abserr(res[2]["vp"], ref2["vp"]) <= 1e-4
+    assert res[3]["status"] == 2                                          # VPK_EM_NO_INITIAL_VP
+    with pytest.raises(ValueError):
+        em.expectation_maximisation(blank["l"].copy(), blank["lp"].copy(), blank["cnn_response"].copy(),
+                                    sphere_image=blank["sphere_image"])
+    # 40 hypotheses supplied by the caller
+    rs = np.random.RandomState(3)
+    v = rs.normal(size=(40, 3))
+    v[:, 2] = np.abs(v[:, 2]) + 0.2
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    many = dict(base[2], init_vp=v)
+    kw = dict(do_split=False, num_iter=12, final_convergence=-1)
+    got = gem.em_batch([many], **kw)[0]
+    ref = em.expectation_maximisation(many["l"].copy(), many["lp"].copy(), many["cnn_response"].copy(),
+                                      sphere_image=many["sphere_image"], init_vp=v, **kw)
+    assert got["status"] == 0 and got["iterations"] == ref["iterations"]
+    assert np.array_equal(got["vp_assoc"], ref["vp_assoc"])
+    assert abserr(got["vp"], ref["vp"]) <= 1e-4
