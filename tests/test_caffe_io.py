@@ -62,3 +62,30 @@ def test_reference_deploy_prototxt_if_present():
     if not os.path.isfile(path):
         pytest.skip("reference tree not present (GPU box)")
     assert caffe_io.check_deploy_prototxt(path)
+
+
+def test_reference_result_pickles_load(tmp_path):
+    """A datum written by the reference holds EM_result['distribution'] = probability_functions.PDF(...)
+    (vp_localisation.py:441) pickled under the top-level module name; evaluation._load_pickle resolves it."""
+    import pickle
+    import sys
+    import types
+    from collections import namedtuple
+    import numpy as np
+    from vanishing_points_2017_amd import evaluation
+    fake = types.ModuleType("probability_functions")          # stands in for the reference's module while writing
+    fake.PDF = namedtuple("PDF", "v lv vl l lvsq angles")
+    fake.PDF.__module__ = "probability_functions"
+    sys.modules["probability_functions"] = fake
+    try:
+        datum = {"EM_result": {"vp": np.eye(3), "distribution": fake.PDF(np.ones(3), None, None, None, None, None)},
+                 "cnn_prediction": np.zeros((20, 20), np.float32)}
+        path = tmp_path / "datum.pkl"
+        with open(path, "wb") as fp:
+            pickle.dump(datum, fp, 2)
+    finally:
+        del sys.modules["probability_functions"]
+    got = evaluation._load_pickle(str(path))
+    assert type(got["EM_result"]["distribution"]).__name__ == "PDF"
+    assert got["EM_result"]["distribution"]._fields == ("v", "lv", "vl", "l", "lvsq", "angles")
+    assert np.array_equal(got["EM_result"]["vp"], np.eye(3))

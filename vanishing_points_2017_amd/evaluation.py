@@ -17,13 +17,24 @@ from . import caffe_io, cnn, em as _em, sphere_mapping, vp_localisation as vp
 PICKLE_PROTOCOL = 2      # readable by the reference's Python 2 (it writes protocol -1 of cPickle)
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """The reference's scripts run with their directory on sys.path, so its pickles name the module
+    ``probability_functions`` at top level; resolve it to this package's record types."""
+
+    def find_class(self, module, name):
+        if module == "probability_functions":
+            from . import probability_functions as pf
+            return getattr(pf, name)
+        return super().find_class(module, name)
+
+
 def _load_pickle(path):
     with open(path, 'rb') as fp:
         try:
-            return pickle.load(fp)
+            return _ReferenceUnpickler(fp).load()
         except UnicodeDecodeError:
             fp.seek(0)
-            return pickle.load(fp, encoding='latin1')      # pickles written by the Python 2 reference
+            return _ReferenceUnpickler(fp, encoding='latin1').load()   # written by the Python 2 reference
 
 
 def _dump_pickle(obj, path):
