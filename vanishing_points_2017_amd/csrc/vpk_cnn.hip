@@ -257,13 +257,23 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
     }   // tile loop
 }
 
-// conv1 input: float(uint8 raster) - mean (evaluation.py:35), so that conv1 can use the DMA kernel
+// conv1 input: float(uint8 raster) - mean (evaluation.py:35), written as the 16 stride-4 phase planes
+//   P[py][px][Y][X] = x[4Y + py][4X + px]   (125 x 125 each)
+// so that conv1 (11 x 11, stride 4) is a stride-1 gather for the DMA kernel: tap (kh, kw) of output (oh, ow)
+// is P[kh % 4][kw % 4][oh + kh / 4][ow + kw / 4], and the 64 lanes of a gather (consecutive ow) read 256
+// contiguous bytes instead of 64 words 16 bytes apart (8-16 cache lines per gather).  Measured (r1): conv1
+// 2.76 -> 2.57 ms at B = 512, unchanged at B = 102.  With its MFMAs and stores removed conv1 still takes
+// 0.36 of its 0.58 ms: with only 8 K-stages per tile it is bound by the issue rate of the 4-byte gather DMAs
+// (about one per 40-60 cycles per CU), which a wider (16-byte, row-tiled) loader would relieve.
+constexpr int C1_PH = 4, C1_PW = 125;     // phases per axis, phase-plane width/height (500 / 4)
 __global__ void prep_input_kernel(const unsigned char* __restrict__ sphere, const float* __restrict__ mean,
                                   float* __restrict__ out, int plane) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;       // pixel within the image
     if (p >= plane) return;
-    const size_t idx = (size_t)blockIdx.y * plane + p;         // blockIdx.y = image
-    out[idx] = (float)sphere[idx] - mean[p];
+    const size_t img = (size_t)blockIdx.y * plane;             // blockIdx.y = image
+    const int y = p / 500, x = p - y * 500;
+    const int q = ((y % C1_PH) * C1_PH + (x % C1_PH)) * (C1_PW * C1_PW) + (y / C1_PH) * C1_PW + x / C1_PH;
+    out[img + q] = (float)sphere[img + p] - mean[p];
 }
 
 // sum the split-K partials, add bias, activation: act 0 = none, 1 = ReLU, 2 = sigmoid
@@ -553,7 +563,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
     hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
                        500 * 500);
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 4, ctr + 0);
+    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 1, ctr + 0);   // stride 1 over the phase planes
     mark();
     if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
     // norm1 + pool1 (fused), written with conv2's border
@@ -648,6 +658,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
         ConvDims& d = l.d;
         d.B = 0; d.IC = t.IC; d.Hp = t.H + 2 * t.P; d.Wp = t.W + 2 * t.P; d.OC = t.OC; d.OH = t.OH; d.OW = t.OW; d.groups = t.G;
         d.OHp = t.OH + 2 * t.OP; d.OWp = t.OW + 2 * t.OP; d.opad = t.OP;
+        if (li == 0) { d.IC = C1_PH * C1_PH; d.Hp = C1_PW; d.Wp = C1_PW; }   // phase planes (K stays 11 x 11)
         d.K = t.IC * t.KH * t.KH;
         d.Kp = (d.K + BK - 1) / BK * BK;
         d.Mp = (t.OC + t.BM - 1) / t.BM * t.BM;
@@ -669,7 +680,10 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             std::vector<unsigned> tab(d.Kp, 0u);
             for (int k = 0; k < d.K; ++k) {
                 int ic = k / (t.KH * t.KH), r = k % (t.KH * t.KH), kh = r / t.KH, kw = r % t.KH;
-                tab[k] = (unsigned)((ic * d.Hp + kh) * d.Wp + kw) * 4u;
+                if (li == 0)   // conv1 reads the stride-4 phase planes written by prep_input_kernel
+                    tab[k] = (unsigned)((((kh % C1_PH) * C1_PH + kw % C1_PH) * C1_PW + kh / C1_PH) * C1_PW + kw / C1_PH) * 4u;
+                else
+                    tab[k] = (unsigned)((ic * d.Hp + kh) * d.Wp + kw) * 4u;
             }
             VPK_HIP(h, hipMalloc((void**)&l.ktab, tab.size() * sizeof(unsigned)));
             VPK_HIP(h, hipMemcpy(l.ktab, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
