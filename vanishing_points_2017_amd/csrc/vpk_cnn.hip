@@ -226,6 +226,12 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
         __builtin_amdgcn_s_barrier();                   // ... for every wave; stage t's buffer is free again
     }
 
+    // Epilogue.  The 32 x 32 accumulator tile holds rows 8q + 4 khalf + (0..3) in registers 4q .. 4q + 3: a
+    // group of eight rows (one q) is in or out of range as a whole (OC is a multiple of 8 in every layer),
+    // its bias is eight consecutive floats fetched by ONE scalar load, and a lane's addresses are a 64-bit
+    // base (its column) plus 32-bit row offsets.  (Per-element vector bias loads were each followed by
+    // s_waitcnt vmcnt(0), which also waits for the store just issued: 48-64 store round trips in series per
+    // tile, more than half of conv1's tile time.)
     const int oplane = d.OHp * d.OWp;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -234,20 +240,36 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
         const int bb = nn / ohw;
         const int rr = nn - bb * ohw;
         const int oh = rr / d.OW, ow = rr - oh * d.OW;
-        const size_t opos = (size_t)(oh + d.opad) * d.OWp + ow + d.opad;
+        if (d.ksplit == 1) {
+            float* ocol = out + ((size_t)bb * d.groups + g) * d.OC * oplane + (size_t)(oh + d.opad) * d.OWp + ow + d.opad;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mt * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (m >= d.OC) continue;
-                float v = acc[i][j][r];
-                if (d.ksplit == 1) {
-                    v += bias[g * d.OC + m];
-                    if (d.relu) v = v > 0.f ? v : 0.f;
-                    out[((size_t)bb * d.groups * d.OC + (size_t)g * d.OC + m) * oplane + opos] = v;
-                } else {
-                    out[((size_t)ks * d.N + nn) * d.OC + m] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int m0 = __builtin_amdgcn_readfirstlane(mt * BM + wm * TM * 32 + i * 32 + 8 * q);
+                    if (m0 >= d.OC) continue;                       // whole group of eight rows is padding
+                    const float* bp = bias + g * d.OC + m0;         // wave-uniform: scalar load of 8 floats
+                    float bl[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bl[e] = bp[e];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * q + e] + (khalf ? bl[4 + e] : bl[e]);
+                        if (d.relu) v = v > 0.f ? v : 0.f;
+                        ocol[(m0 + 4 * khalf + e) * oplane] = v;
+                    }
+                }
+            }
+        } else {
+            float* prow = out + ((size_t)ks * d.N + nn) * d.OC;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m0 = __builtin_amdgcn_readfirstlane(mt * BM + wm * TM * 32 + i * 32 + 8 * q);
+                    if (m0 >= d.OC) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) prow[m0 + 4 * khalf + e] = acc[i][j][4 * q + e];
                 }
             }
         }
