@@ -37,8 +37,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
     ap.add_argument("--em-lanes", type=int, default=3,
