@@ -179,6 +179,18 @@ int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, dou
 int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out,
                  uint32_t* flags_out);
 
+/* ---- horizon from the best orthogonal VP triplet, batched ------------------------------------------ */
+/* replaces: calc_horizon.calculate_horizon_and_ortho_vp -- calc_horizon.py:19-225 -- called per image from the
+ * scoring loop of benchmark.py:229-243 (maxbest = 20, theta_vmin = pi/10; theta_z = pi/4 at :19).
+ *   vp / counts / num_vp  the outputs of vpk_em_batch (B x max_vp x 3, B x max_vp, B; device)
+ *   order   B x maxbest int32 (device): np.argsort(counts[:M])[::-1][:maxbest] per image (:34-36); the caller
+ *           supplies it because the order of equal counts is a property of its NumPy sort
+ *   out     B x 15 fp64 (device): hP1 | hP2 | zVP | hVP1 | hVP2 (3 each), the first five returned values
+ *   combo_out  B x 3 int32: best_combo (VP indices; [0,1,-1] / [0,0,-1] in the < 3 VP fallbacks, :200-217) */
+int vpk_horizon_batch(vpk_handle* h, int batch, int max_vp, const double* vp, const double* counts,
+                      const int32_t* num_vp, const int32_t* order, int maxbest, double theta_vmin, double theta_z,
+                      double* out, int32_t* combo_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,32 @@ def test_run_cnn_surface_with_written_model_files(tmp_path):
         pred = evaluation._load_pickle(f)['cnn_prediction']
         assert pred.shape == (20, 20) and pred.dtype == np.float32
         assert np.abs(pred - r).max() <= 2e-5
+
+
+def test_horizon_batch_matches_host_selection():
+    """vpk_horizon_batch (calc_horizon.py:19-225 on the GPU) against the host port on the EM results of the
+    goldens and of fresh scenes, plus the < 3 VP fallbacks: same triplet, end points to 1e-12."""
+    from conftest import golden_cases
+    from golden_util import load
+    from vanishing_points_2017_amd import calc_horizon as ch, em as gem, synth
+    results = []
+    for name in golden_cases():
+        g = load(name)
+        if "o_vp" in g:
+            results.append({"vp": g["o_vp"], "counts": g["o_counts"]})
+    scenes = list(synth.config_scenes(3, count=24, start=7)) + list(synth.config_scenes(2, count=24, start=60))
+    for r in gem.em_batch(scenes):
+        if r["status"] == 0:
+            results.append({"vp": r["vp"], "counts": r["counts"]})
+    rs = np.random.RandomState(11)
+    for m in (0, 1, 2, 3, 30):            # fallbacks, the smallest triplet case, more VPs than maxbest
+        v = rs.normal(size=(m, 3))
+        v /= np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+        results.append({"vp": v, "counts": np.floor(rs.uniform(3, 40, m))})
+    got = ch.calculate_horizon_batch(results, maxbest=20, theta_vmin=np.pi / 10)
+    assert len(got) == len(results) and len(results) > 50
+    for r, g_ in zip(results, got):
+        ref = ch.calculate_horizon_and_ortho_vp(r, maxbest=20, theta_vmin=np.pi / 10)
+        assert np.array_equal(np.asarray(ref[5]).ravel(), np.asarray(g_[5]).ravel())
+        for a, b in zip(ref[:5], g_[:5]):
+            assert np.allclose(np.asarray(a, dtype=float), b, rtol=0, atol=1e-12, equal_nan=True)

@@ -31,7 +31,7 @@ EXPORTS = [
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_last_layer_ms",
     "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
-    "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_cluster2",
+    "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_cluster2", "vpk_horizon_batch",
 ]
 
 _lib = None
@@ -55,6 +55,8 @@ def load():
     lib.vpk_synchronize.argtypes = [c_void]
     lib.vpk_device_info.argtypes = [c_void, ctypes.POINTER(ctypes.c_int32)]
     lib.vpk_em_set_workgroups.argtypes = [c_void, ctypes.c_int]
+    lib.vpk_horizon_batch.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, ctypes.c_int,
+                                      ctypes.c_double, ctypes.c_double, c_void, c_void]
     lib.vpk_set_cu_range.argtypes = [c_void, ctypes.c_int, ctypes.c_int]
     lib.vpk_get_stream.argtypes = [c_void]
     lib.vpk_get_stream.restype = ctypes.c_void_p

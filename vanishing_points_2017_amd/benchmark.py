@@ -60,6 +60,7 @@ def synthetic_dataset(name, result_dir, count, update):
 def score(dataset, start=0, n_vp=20, theta_vmin=np.pi / 10, err_cutoff=0.25):
     """benchmark.py:108-266 with the ground truth supplied by the dataset dict."""
     errors = []
+    todo = []
     for idx, data_file in enumerate(dataset['pickle_files']):
         if idx < start:
             continue
@@ -68,7 +69,10 @@ def score(dataset, start=0, n_vp=20, theta_vmin=np.pi / 10, err_cutoff=0.25):
         assert em_result is not None, "no EM result!"                        # :231
         if em_result['vp'] is None:
             em_result = {'vp': np.zeros((0, 3)), 'counts': np.zeros(0)}
-        hp1, hp2, _, _, _, _ = ch.calculate_horizon_and_ortho_vp(em_result, maxbest=n_vp, theta_vmin=theta_vmin)
+        todo.append((idx, em_result))
+    # the reference calls calculate_horizon_and_ortho_vp image by image (:237-243); one batched launch here
+    horizons = ch.calculate_horizon_batch([r for _, r in todo], maxbest=n_vp, theta_vmin=theta_vmin)
+    for (idx, _), (hp1, hp2, _, _, _, _) in zip(todo, horizons):
         errors.append(ch.horizon_error(hp1, hp2, dataset['true_horizon'][idx], dataset['image_shape'][idx]))
     errors = np.array(errors)
     auc, pts = auc_mod.calc_auc(errors, cutoff=err_cutoff)

@@ -22,6 +22,7 @@ UNITS = {
     "vpk_em.hip": ["-ffp-contract=off"],
     "vpk_cnn.hip": [],
     "vpk_raster.hip": [],
+    "vpk_horizon.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result"]

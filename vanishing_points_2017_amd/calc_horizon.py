@@ -1,6 +1,9 @@
 """Horizon line from the best orthogonal VP triplet -- host-side port of the reference's
 calc_horizon.calculate_horizon_and_ortho_vp (calc_horizon.py:19-225).  Post-processing of the EM
-result: needed to report the horizon-AUC half of the metric; not a kernel."""
+result: needed to report the horizon-AUC half of the metric.
+``calculate_horizon_batch`` runs the same selection for a whole dataset on the GPU (vpk_horizon_batch):
+the reference's per-image Python loop over C(20,3) triplets is otherwise the slowest stage of the scoring
+loop once the EM runs on the GPU."""
 import itertools
 
 import numpy as np
@@ -106,3 +109,44 @@ def horizon_error(hp1, hp2, true_horizon, image_shape):
     t1 = t1 / t1[2]
     t2 = t2 / t2[2]
     return np.maximum(np.abs(hp1[1] - t1[1]), np.abs(hp2[1] - t2[1])) / 2 * scale * 1.0 / height
+
+
+def calculate_horizon_batch(em_results, maxbest=10, theta_vmin=np.pi / 10., theta_z=np.pi / 4., device=0):
+    """calculate_horizon_and_ortho_vp for a list of EM results in one launch of vpk_horizon_batch.
+    Returns one (hP1, hP2, zVP, hVP1, hVP2, best_combo) tuple per result, like the per-image function."""
+    import ctypes
+    from .runtime import get_runtime
+    rt = get_runtime(device)
+    torch = rt.torch
+    batch = len(em_results)
+    max_vp = max([1] + [r['vp'].shape[0] for r in em_results])
+    if max_vp > 64 or maxbest > 64:
+        raise ValueError("vpk_horizon_batch handles at most 64 VPs per image")
+    vp = np.zeros((batch, max_vp, 3))
+    counts = np.zeros((batch, max_vp))
+    num = np.zeros(batch, dtype=np.int32)
+    order = np.zeros((batch, maxbest), dtype=np.int32)
+    for b, r in enumerate(em_results):
+        m = r['vp'].shape[0]
+        num[b] = m
+        vp[b, :m] = r['vp']
+        counts[b, :m] = r['counts']
+        nb = min(maxbest, m)
+        order[b, :nb] = np.argsort(r['counts'])[::-1][0:nb]          # calc_horizon.py:34-36 (the caller's tie order)
+    with rt.on_stream():
+        d_vp, d_cnt = torch.from_numpy(vp).to(rt.tdev), torch.from_numpy(counts).to(rt.tdev)
+        d_num, d_ord = torch.from_numpy(num).to(rt.tdev), torch.from_numpy(order).to(rt.tdev)
+        out = torch.empty((batch, 15), dtype=torch.float64, device=rt.tdev)
+        combo = torch.empty((batch, 3), dtype=torch.int32, device=rt.tdev)
+        rt.check(rt.lib.vpk_horizon_batch(rt.h, batch, max_vp, rt.ptr(d_vp), rt.ptr(d_cnt), rt.ptr(d_num), rt.ptr(d_ord),
+                                          int(maxbest), ctypes.c_double(theta_vmin), ctypes.c_double(theta_z), rt.ptr(out),
+                                          rt.ptr(combo)))
+    rt.synchronize()
+    out, combo = out.cpu().numpy(), combo.cpu().numpy()
+    res = []
+    for b in range(batch):
+        o = out[b]
+        c = combo[b]
+        res.append((o[0:3].copy(), o[3:6].copy(), o[6:9].copy(), o[9:12].copy(), o[12:15].copy(),
+                    c.astype(np.int64) if c[2] >= 0 else c[:2].astype(np.int64)))
+    return res
