@@ -250,7 +250,7 @@ def main():
             "roofline": roof,
             "roofline_secondary": roof_cnn if roof is roof_em else roof_em,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             sample = args.cpu_sample or (6 if args.workload == "yud" else 1)
             line["cpu_baseline"] = cpu_baseline(scenes, kw, weights, mean, sample)
         print(json.dumps(line))
