@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--em-cus", type=int, default=-1,
                     help="CU slots per XCD reserved for the EM streams (the CNN stream gets the other 32 - k); "
                          "0 = no partition (default: measured r1, a partition only moves the CUs the EM would take anyway)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images timed on the CPU (default 6 yud / 1 stress)")
     return ap.parse_args()
@@ -100,9 +102,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -178,6 +183,9 @@ def main():
     for k in range(args.warmup):
         step(k)
     sync_all()
+    if dist is not None:                                 # RCCL writes its banner through C stdio: push it out now,
+        import ctypes                                    # so that the JSON line below is the last line on stdout
+        ctypes.CDLL(None).fflush(None)
     t0 = time.perf_counter()
     evs = []
     for k in range(args.steps):
@@ -253,7 +261,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             sample = args.cpu_sample or (6 if args.workload == "yud" else 1)
             line["cpu_baseline"] = cpu_baseline(scenes, kw, weights, mean, sample)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
