@@ -65,8 +65,44 @@ def test_cluster2_matches_sklearn():
             warnings.simplefilter("ignore")
             model.fit_predict(ld)
         labels, flags = simlib.cluster2(ld)
-        if flags == 0:          # no exact tie: the merge order is unambiguous
-            assert np.array_equal(labels, model.labels_)
+        # random angles: no two candidate merges are exactly tied, so the merge order is unambiguous
+        assert flags == 0
+        assert np.array_equal(labels, model.labels_)
+
+
+def test_cluster2_flags_exact_tie():
+    """Four lines at 0/90 degrees twice over: every cross distance is exactly 1 - cos(pi/2), the first
+    merge candidates are tied and sklearn's choice depends on Python heap order -> the flag is raised."""
+    ang = np.array([0.0, 0.5, 0.0, 0.5, 0.25, 0.75, 0.25, 0.75]) * np.pi
+    lp = np.stack([np.cos(ang), np.sin(ang), np.zeros(8), np.zeros(8)], 1)
+    rows = np.repeat(np.arange(8), 8).reshape(8, 8)
+    ld = 1 - em.pair_cosangle(lp, 2, rows, rows.T)
+    np.fill_diagonal(ld, 0)
+    _, flags = simlib.cluster2(ld)
+    assert flags & 1
+
+
+@pytest.mark.parametrize("seed,freq,num_iter,peak", [(12, 1, 60, 41), (14, 2, 60, 30), (12, 5, 100, 26)])
+def test_frequent_splits_do_not_overrun_the_vp_capacity(seed, freq, num_iter, peak):
+    """split_merge_freq < 10 allows more than nine splits (vp_localisation.py:262 splits at every
+    i % freq == 0, 0 < i < 100): the [vp][line] scratch must be sized for them (em_layout.hpp: em_mcap)."""
+    from vanishing_points_2017_amd import synth
+    sc = synth.make_scene(seed, 400, 8)
+    kw = dict(split_merge_freq=freq, num_iter=num_iter, final_convergence=-1)
+    tr = {"want_states": True}
+    ref = em.expectation_maximisation(sc["l"].copy(), sc["lp"].copy(), sc["cnn_response"].copy(),
+                                      sphere_image=sc["sphere_image"], trace=tr, **kw)
+    res = simlib.em_single(sc["l"].copy(), sc["lp"], sc["cnn_response"], sc["sphere_image"], **kw)
+    assert res["status"] == 0 and res["flags"] & 4 == 0
+    assert max(v.shape[0] for v, _ in tr["states"]) >= peak       # 41: beyond the 40 rows sized for nine splits
+    # the hypothesis count follows the oracle through every iteration (an overrun loses VPs: 27 vs 50 before
+    # the fix); the VPs themselves agree while the forced, never-converging run is still well conditioned --
+    # 60 forced iterations with sigma^2 ~ 1e-12 amplify last-ulp differences by ~1.5x per iteration
+    for i, ((rv, _), (sv, _)) in enumerate(zip(tr["states"][:46], res["states"][:46])):
+        assert rv.shape == sv.shape, "iteration %d: %d vs %d VPs" % (i, rv.shape[0], sv.shape[0])
+        if i <= 25:
+            assert abserr(rv, sv) <= 1e-9
+    assert abs(res["vp"].shape[0] - ref["vp"].shape[0]) <= 2
 
 
 def test_degenerate_no_initial_vp():

@@ -1674,7 +1674,7 @@ VPK_DEVFN void split_vp(EmCtx& c) {
         if (!too_similar) {                                   // :617-628 (both clusters valid here)
             sh.cur[3 * worst] = v0[0]; sh.cur[3 * worst + 1] = v0[1]; sh.cur[3 * worst + 2] = v0[2];
             sh.s[worst] = stdd;
-            if (sh.M < MAXM) {
+            if (sh.M < MAXM && sh.M < c.mcap) {               // the [vp][line] scratch has mcap rows
                 int m = sh.M;
                 sh.cur[3 * m] = v1[0]; sh.cur[3 * m + 1] = v1[1]; sh.cur[3 * m + 2] = v1[2];
                 sh.nxt[3 * m] = 0; sh.nxt[3 * m + 1] = 0; sh.nxt[3 * m + 2] = 0;

@@ -25,9 +25,11 @@ inline int em_mcap(int num_init_vp, int n_init, bool has_init, bool do_split, in
     int m0 = has_init ? n_init : num_init_vp;
     int splits = 0;
     if (do_split && freq > 0) {
-        splits = (num_iter - 1) / freq;
-        if (splits > 9) splits = 9;          // split only for 0 < i < 100 (vp_localisation.py:262)
-        if (splits < 0) splits = 0;
+        // one split attempt at every i with i % freq == 0 and 0 < i < min(num_iter, 100)
+        // (vp_localisation.py:256,262): floor(min(num_iter - 1, 99) / freq) of them -- 9 at the default
+        // freq = 10, 99 at freq = 1.  The caller clamps to maxm; split_vp refuses to grow past mcap.
+        int last = num_iter - 1 < 99 ? num_iter - 1 : 99;
+        splits = last > 0 ? last / freq : 0;
     }
     int m = m0 + splits;
     if (m > maxm) m = maxm;
