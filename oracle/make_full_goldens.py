@@ -22,7 +22,6 @@ reference's merge_vps / split_best_vp in memory (nothing is written into the ref
 
 Usage:  python oracle/make_full_goldens.py <config> [count] [stride]
 """
-import hashlib
 import os
 import sys
 import time
@@ -37,15 +36,9 @@ sys.path.insert(0, HERE)
 
 from ref_shim import load_reference  # noqa: E402
 from vanishing_points_2017_amd import synth  # noqa: E402
+from vanishing_points_2017_amd.parity import input_sha  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-
-
-def input_sha(sc):
-    h = hashlib.sha1()
-    for k in ("l", "lp", "cnn_response", "sphere_image"):
-        h.update(np.ascontiguousarray(sc[k]).tobytes())
-    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
 
 
 def instrument(mods, ev):

@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-from . import auc as auc_mod, calc_horizon as ch, config, evaluation, sphere_mapping, synth
+from . import auc as auc_mod, calc_horizon as ch, config, evaluation, sharding, sphere_mapping, synth
 
 SHAPES = {"york": 2, "eurasian": 3, "horizon": 4}
 
@@ -34,6 +34,9 @@ def build_parser():
     p.add_argument('--run_em', dest='run_em', action='store_true', help='Run EM refinement on the data')
     p.add_argument('--synthetic', action='store_true', help='use the seeded synthetic set of the dataset shape')
     p.add_argument('--count', type=int, default=None, help='number of synthetic images (default: dataset size)')
+    p.add_argument('--gpus', type=int, default=1,
+                   help='GPUs of this node to shard the images over (one process per GPU; results gathered with one '
+                        'RCCL all_gather).  Without a launcher environment the ranks are started as child processes.')
     return p
 
 
@@ -47,7 +50,8 @@ def synthetic_dataset(name, result_dir, count, update):
     dataset = {'source_folder': "synthetic:%s" % name, 'destination_folder': dest, 'use_weights': True,
                'distance_measure': "angle", 'do_split': True, 'do_merge': True, 'name': "synthetic_" + name,
                'image_files': ["synthetic:%s:%d" % (name, s["seed"]) for s in scenes], 'pickle_files': files,
-               'true_horizon': [s["true_horizon"] for s in scenes], 'image_shape': [s["image_shape"] for s in scenes]}
+               'true_horizon': [s["true_horizon"] for s in scenes], 'image_shape': [s["image_shape"] for s in scenes],
+               'line_counts': [int(s["lp"].shape[0]) for s in scenes]}
     if update or not all(os.path.isfile(f) for f in files):
         rasters = sphere_mapping.raster_batch([s["l"] for s in scenes], size=500, alpha=0.1)
         for s, f, r in zip(scenes, files, rasters):
@@ -55,6 +59,49 @@ def synthetic_dataset(name, result_dir, count, update):
                      "image": None, "line_segments": s["lp"], "lines": s["l"]}
             evaluation._dump_pickle({'lines': datum, 'sphere_image': r, 'cnn_prediction': s["cnn_response"]}, f)
     return dataset
+
+
+def horizon_errors(dataset, indices, n_vp=20, theta_vmin=np.pi / 10, horizon_fn=None, device=0):
+    """Per-image part of the scoring loop (benchmark.py:229-257) for the images in ``indices``: returns
+    (em_results, errors).  ``horizon_fn`` defaults to the batched GPU selection."""
+    todo = []
+    for idx in indices:
+        datum = evaluation._load_pickle(dataset['pickle_files'][int(idx)])
+        em_result = datum.get('EM_result')
+        assert em_result is not None, "no EM result!"                        # :231
+        if em_result['vp'] is None:
+            em_result = {'vp': np.zeros((0, 3)), 'counts': np.zeros(0)}
+        todo.append(em_result)
+    fn = horizon_fn or (lambda rs: ch.calculate_horizon_batch(rs, maxbest=n_vp, theta_vmin=theta_vmin, device=device))
+    horizons = fn(todo) if todo else []
+    errors = [ch.horizon_error(h[0], h[1], dataset['true_horizon'][int(idx)], dataset['image_shape'][int(idx)])
+              for idx, h in zip(indices, horizons)]
+    return todo, np.array(errors)
+
+
+def run_sharded(dataset, rank=0, world=1, dist=None, device=0, start=0, run_em=True, em_fn=None,
+                horizon_fn=None, err_cutoff=0.25, gather_on=None):
+    """BASELINE configs[3]: the images of a dataset sharded over the ranks of one node.
+
+    The reference's only multi-process facility is the start/end slice of run_em (evaluation.py:295-307).
+    Here every rank (one process per GPU) takes one part of a cost-balanced partition (cost = N^2: the
+    pairwise and smoothing work), refines and scores its images, and ONE all_gather of fixed-size records
+    (sharding.pack_records / gather_records: RCCL over xGMI with the nccl backend, gloo on CPU) brings VPs,
+    counts and horizon errors to every rank; rank 0 reports the AUC (benchmark.py:264).  No other exchange.
+    ``em_fn(dataset, indices)`` defaults to evaluation.run_em on GPU ``device``; ``gather_on`` = torch device
+    the records are gathered on (the rank's GPU for nccl, None = CPU tensors for gloo)."""
+    n = len(dataset['pickle_files'])
+    costs = np.asarray(dataset.get('line_counts', np.ones(n)), dtype=np.float64) ** 2
+    mine = sharding.shard_balanced(costs, world)[rank]
+    if run_em and len(mine):
+        (em_fn or (lambda ds, idx: evaluation.run_em(ds, indices=idx, device=device)))(dataset, mine)
+    results, errors = horizon_errors(dataset, mine, horizon_fn=horizon_fn, device=device)
+    rec = sharding.pack_records(mine, results, errors)
+    allrec = sharding.gather_records(dist, rec, device=gather_on) if dist is not None else rec
+    assert allrec.shape[0] == n and np.array_equal(allrec[:, 0], np.arange(n)), "records lost in the gather"
+    errs = allrec[start:, -1]
+    auc, pts = auc_mod.calc_auc(errs.copy(), cutoff=err_cutoff)
+    return auc, errs, allrec
 
 
 def score(dataset, start=0, n_vp=20, theta_vmin=np.pi / 10, err_cutoff=0.25):
@@ -79,7 +126,24 @@ def score(dataset, start=0, n_vp=20, theta_vmin=np.pi / 10, err_cutoff=0.25):
     return auc, errors, pts
 
 
+def _spawn(args_list, gpus):
+    """Start one process per GPU (torch.distributed.run) as children of this not-yet-GPU-initialised process."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "vanishing_points_2017_amd.benchmark"] + args_list
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
+    import sys
     args = build_parser().parse_args(argv)
     if args.yud:
         name = "york"
@@ -93,23 +157,49 @@ def main(argv=None):
         raise NotImplementedError(
             "the real %s dataset and its ground-truth loaders are out of scope (no dataset offline, LSD not "
             "vendored); run with --synthetic, or use evaluation.run_cnn / run_em on existing reference pickles" % name)
-    dataset = synthetic_dataset(name, args.result_dir, args.count, args.update_datafiles or args.update_datalist)
-    if args.run_cnn:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _spawn(list(sys.argv[1:] if argv is None else argv), args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    device = args.gpu
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        device = local_rank
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+    if rank == 0:    # one rank writes the input pickles; the others read them after the barrier
+        dataset = synthetic_dataset(name, args.result_dir, args.count, args.update_datafiles or args.update_datalist)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        dataset = synthetic_dataset(name, args.result_dir, args.count, False)
+    if args.run_cnn and rank == 0:
         if not all(os.path.isfile(f) for f in (config.cnn_weights_path, config.cnn_mean_path)):
             print("no trained weights at %s: keeping the generator's response maps as cnn_prediction"
                   % config.cnn_weights_path)
         else:
             evaluation.run_cnn(dataset, mean_file=config.cnn_mean_path, model_def=config.cnn_config_path,
-                               model_weights=config.cnn_weights_path, gpu=args.gpu)
-    if args.run_em:
-        t0 = time.time()
-        evaluation.run_em(dataset)
-        print("EM time: ", time.time() - t0)
+                               model_weights=config.cnn_weights_path, gpu=device)
+    if dist is not None:
+        dist.barrier()
     start = 25 if (args.yud or args.ecd) else 0                              # :69
     t0 = time.time()
-    auc, errors, _ = score(dataset, start=start)
-    print("time elapsed: ", time.time() - t0)
-    print("AUC: ", auc)
+    tdev = None
+    if dist is not None:
+        import torch
+        tdev = torch.device("cuda", device)
+    auc, errors, _ = run_sharded(dataset, rank, world, dist, device=device, start=start, run_em=args.run_em,
+                                 gather_on=tdev)
+    if rank == 0:
+        print("EM + scoring time (%d rank(s)): " % world, time.time() - t0)
+        print("AUC: ", auc)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return auc
 
 

@@ -151,37 +151,57 @@ def run_cnn(dataset, model_def, model_weights, mean_file, gpu=0, net=None):
     print("finished ", dataset['destination_folder'])
 
 
-def run_em_batch(data, distance_measure="angle", use_weights=True, do_split=True, do_merge=True, device=0):
-    """EM over a list of datum dicts in ONE launch; fills datum['EM_result'] like run_em_single."""
+def run_em_batch(data, distance_measure="angle", use_weights=True, do_split=True, do_merge=True, device=0,
+                 defer_errors=False):
+    """EM over a list of datum dicts in ONE launch; fills datum['EM_result'] like run_em_single.
+    An image without any initial VP raises ValueError like the reference (vp_localisation.py:165) -- after
+    the results of all other images have been filled in; with ``defer_errors`` the positions of such images
+    are returned instead (their EM_result stays None)."""
     todo = [d for d in data if d.get('cnn_prediction') is not None]
     scenes = [{"l": d['lines']['lines'], "lp": d['lines']['line_segments'],
                "cnn_response": d['cnn_prediction'][:, :], "sphere_image": d['sphere_image']} for d in todo]
     results = _em.em_batch(scenes, device=device, want_metric=True, distance_measure=distance_measure,
                            use_weights=use_weights, do_split=do_split, do_merge=do_merge) if scenes else []
+    failed = []
     for d, r in zip(todo, results):
         status = r.pop("status")
         d['lines']['lines'][...] = r.pop("l")            # the reference normalises l in place (:339,:350)
         if status == 2:
-            raise ValueError("need at least one array to concatenate")      # vp_localisation.py:165
+            d['EM_result'] = None
+            failed.append(next(i for i, x in enumerate(data) if x is d))
+            continue
         d['EM_result'] = r
     for d in data:
         if d.get('cnn_prediction') is None:
             d['EM_result'] = None                                            # :351-352
+    if defer_errors:
+        return failed
+    if failed:
+        raise ValueError("need at least one array to concatenate")          # vp_localisation.py:165
     return data
 
 
-def run_em(dataset, start=None, end=None):
-    """evaluation.py:295-329."""
+def run_em(dataset, start=None, end=None, indices=None, device=0):
+    """evaluation.py:295-329.  ``start``/``end`` slice the file list like the reference (:304-307: its only
+    means of spreading a dataset over several processes); ``indices`` selects an arbitrary subset instead
+    (one rank's share of a cost-balanced partition, sharding.shard_balanced) and ``device`` the GPU."""
     files = [f[0] if isinstance(f, tuple) else f for f in dataset['pickle_files']]
-    if not (start is None or end is None):
+    if indices is not None:
+        files = [files[int(i)] for i in indices]
+    elif not (start is None or end is None):
         files = files[start:min(end, len(files))]
     data = [_load_pickle(f) for f in files]
-    run_em_batch(data, distance_measure=dataset['distance_measure'], use_weights=dataset['use_weights'],
-                 do_split=dataset['do_split'], do_merge=dataset['do_merge'])
+    failed = run_em_batch(data, distance_measure=dataset['distance_measure'], use_weights=dataset['use_weights'],
+                          do_split=dataset['do_split'], do_merge=dataset['do_merge'], device=device, defer_errors=True)
     for f, d in zip(files, data):
-        if d['EM_result'] is None:
+        if d.get('EM_result') is None:
             print("SKIPPING: file %s is incomplete" % f)
         _dump_pickle(d, f)
+    if failed:
+        # the reference dies with this ValueError at the first such image (vp_localisation.py:165) after
+        # having stored every earlier one; here every other image of the dataset is stored first
+        raise ValueError("need at least one array to concatenate (no initial VP in: %s)"
+                         % ", ".join(files[i] for i in failed))
 
 
 def run_em_single(datum, distance_measure="angle", use_weights=True, do_split=True, do_merge=True):

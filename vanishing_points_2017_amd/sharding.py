@@ -48,6 +48,42 @@ def unpack_record(row):
             "counts": row[3 + 3 * REC_VPS:3 + 3 * REC_VPS + m].copy(), "error": float(row[-1])}
 
 
+def device_records(torch, image_ids, out):
+    """The same records as pack_records, built from vpk_em_batch's DEVICE outputs without a host round
+    trip (bench.py gathers once per step inside its timed region).  image_ids: int64 tensor (B) on the
+    device; out: the dict returned by em.em_batch_device.  VPs are ordered by descending line count like
+    calc_horizon.py:34-36; the order among EQUAL counts is torch's stable sort here and NumPy's
+    reversed argsort in pack_records -- the set of VPs kept is the same."""
+    counts, nv = out["counts"], out["num_vp"].to(torch.int64)
+    b, max_vp = counts.shape
+    dev = counts.device
+    valid = torch.arange(max_vp, device=dev)[None, :] < nv[:, None]
+    key = torch.where(valid, counts, torch.full_like(counts, -1.0))
+    width = min(REC_VPS, max_vp)
+    order = torch.argsort(key, dim=1, descending=True, stable=True)[:, :width]
+    m = torch.clamp(nv, max=width)
+    keep = (torch.arange(width, device=dev)[None, :] < m[:, None]).to(torch.float64)
+    vp = torch.gather(out["vp"], 1, order[:, :, None].expand(-1, -1, 3)) * keep[:, :, None]
+    cnt = torch.gather(counts, 1, order) * keep
+    rec = torch.zeros((b, REC_WIDTH), dtype=torch.float64, device=dev)
+    rec[:, 0] = image_ids.to(torch.float64)
+    rec[:, 1] = out["status"].to(torch.float64)
+    rec[:, 2] = m.to(torch.float64)
+    rec[:, 3:3 + 3 * width] = vp.reshape(b, -1)
+    rec[:, 3 + 3 * REC_VPS:3 + 3 * REC_VPS + width] = cnt
+    rec[:, -1] = float("nan")
+    return rec
+
+
+def gather_device(dist, rec):
+    """all_gather of equally sized per-rank record blocks that stay on the device (RCCL over xGMI with the
+    nccl backend; gloo on CPU tensors): (B, W) per rank -> (world * B, W), rank-major."""
+    blocks = [rec.new_empty(rec.shape) for _ in range(dist.get_world_size())]
+    dist.all_gather(blocks, rec)
+    import torch
+    return torch.cat(blocks, 0)
+
+
 def gather_records(dist, rec, device=None):
     """all_gather of ragged per-rank record blocks (padded to the largest block).  Works with the
     nccl (= RCCL) backend on GPU tensors and with gloo on CPU tensors."""
@@ -62,8 +98,7 @@ def gather_records(dist, rec, device=None):
     nmax = int(max(int(c.item()) for c in counts))
     pad = torch.zeros((nmax, t.shape[1] if t.ndim == 2 else REC_WIDTH), dtype=torch.float64, device=t.device)
     pad[:t.shape[0]] = t
-    blocks = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(blocks, pad)
+    blocks = gather_device(dist, pad).reshape(world, nmax, -1)
     out = [b[:int(c.item())].cpu().numpy() for b, c in zip(blocks, counts)]
     allrec = np.concatenate(out, 0) if out else np.zeros((0, REC_WIDTH))
     return allrec[np.argsort(allrec[:, 0], kind="stable")]
