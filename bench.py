@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
+    ap.add_argument("--em-mode", default="slice", choices=["slice", "lanes"],
+                    help="slice: ONE stream, CNN(k) then a time-sliced EM launch on all CUs (unfinished images are parked and "
+                         "resumed by the next step's launch; vpk_em_set_time_slice); lanes: round 1's scheme, whole EM "
+                         "batches on --em-lanes streams beside the CNN stream")
+    ap.add_argument("--em-slice-ms", type=float, default=1.6, help="time budget of one sliced EM launch")
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--em-wgs", type=int, default=-1,
@@ -135,6 +140,8 @@ def reference_parity(rt, gem, scenes, d, l_pristine, params, max_vp, first_index
     ref = parity.ReferenceResults(2)
     l = l_pristine.clone()                          # the EM normalises l in place
     out = gem.em_batch_device(rt, d["offsets"], l, d["lp"], d["cnn"], d["sphere"], None, params, max_vp=max_vp)
+    with rt.on_stream():
+        rt.handle.em_flush()                        # time-sliced mode: finish what the launch parked (no-op otherwise)
     rt.synchronize()
     host = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
     offs = d["offsets"]
@@ -194,19 +201,28 @@ def main():
 
     from vanishing_points_2017_amd import cnn, em as gem, sharding
     from vanishing_points_2017_amd.runtime import get_runtime
-    # lanes (library handle + HIP stream each) on the same GPU: one for the CNN, --em-lanes for the EM,
-    # used round-robin.  Steps are software-pipelined: the EM of step k (one persistent workgroup per
-    # image: 102 of 256 CUs, and a tail of a few images still iterating) overlaps the CNN of step k+1 and
-    # the EM of steps k+1, k+2.  All K steps complete inside the timed region.
-    n_lanes = max(1, args.em_lanes)
-    em_cus = max(0, args.em_cus)
-    lanes = [get_runtime(local_rank, "em%d" % i, cu_range=(0, em_cus) if em_cus else None) for i in range(n_lanes)]
-    rt = lanes[0]
-    rt_cnn = get_runtime(local_rank, "cnn", cu_range=(em_cus, 32 - em_cus) if em_cus else None)
     count = args.images or (102 if args.workload == "yud" else 512)
-    em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if (args.workload == "yud" and not em_cus) else 0)
-    for r in lanes:
-        r.handle.em_set_workgroups(em_wgs)
+    sliced = args.em_mode == "slice" and args.workload == "yud"
+    if sliced:
+        # ONE stream: CNN(k) on all CUs, then a time-sliced EM launch on all CUs.  An image that is still iterating
+        # when the launch's budget is spent is parked in HBM and resumed by step k+1's launch, so no launch waits
+        # for a 99-iteration straggler and the two kernels never compete for CUs.
+        n_lanes, em_cus, em_wgs = 1, 0, 0
+        rt = rt_cnn = get_runtime(local_rank, "main")
+        lanes = [rt]
+    else:
+        # lanes (library handle + HIP stream each) on the same GPU: one for the CNN, --em-lanes for the EM,
+        # used round-robin.  Steps are software-pipelined: the EM of step k (one persistent workgroup per
+        # image: 102 of 256 CUs, and a tail of a few images still iterating) overlaps the CNN of step k+1 and
+        # the EM of steps k+1, k+2.  All K steps complete inside the timed region.
+        n_lanes = max(1, args.em_lanes)
+        em_cus = max(0, args.em_cus)
+        lanes = [get_runtime(local_rank, "em%d" % i, cu_range=(0, em_cus) if em_cus else None) for i in range(n_lanes)]
+        rt = lanes[0]
+        rt_cnn = get_runtime(local_rank, "cnn", cu_range=(em_cus, 32 - em_cus) if em_cus else None)
+        em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if (args.workload == "yud" and not em_cus) else 0)
+        for r in lanes:
+            r.handle.em_set_workgroups(em_wgs)
     scenes, kw = make_workload(args.workload, rank, count)
     weights = cnn.synthetic_weights(0)
     mean = cnn.synthetic_mean(0)
@@ -219,11 +235,36 @@ def main():
     rt.synchronize()
     n_lines = np.diff(d["offsets"])
     max_vp = 64
+    if sliced:
+        rt.handle.em_set_time_slice(args.em_slice_ms, int(n_lines.max()))
 
     sphere_cnn = d["sphere"]
     image_ids = torch.arange(rank * count, (rank + 1) * count, dtype=torch.int64, device=rt.tdev)
+    alive = []                                           # sliced mode: a step's buffers live until the flush
 
-    def step(k):
+    def step_sliced(k):
+        with rt.on_stream():
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            resp = net.forward_device(sphere_cnn)        # B x 20 x 20 fp32
+            e[1].record()
+            l_buf = l_pristine.clone()                   # parked images keep reading their step's inputs
+            e[2].record()
+            out = gem.em_batch_device(rt, d["offsets"], l_buf, d["lp"], resp.reshape(-1, 400), d["sphere"],
+                                      d["init_vp"], params, max_vp=max_vp)
+            e[3].record()
+        alive.append((resp, l_buf, out))
+        return e, out
+
+    def finish_sliced():
+        """End of a run of steps: finish every parked image; then the one collective of the path."""
+        with rt.on_stream():
+            rt.handle.em_flush()
+            if dist is not None:
+                rec = torch.cat([sharding.device_records(torch, image_ids, o) for _, _, o in alive], 0)
+                alive[-1][2]["records"] = sharding.gather_device(dist, rec)
+
+    def step_lanes(k):
         rt = lanes[k % n_lanes]
         l_buf = l_lane[k % n_lanes]
         with rt_cnn.on_stream():
@@ -243,7 +284,11 @@ def main():
                 out["records"] = sharding.gather_device(dist, sharding.device_records(torch, image_ids, out))
         return e, out
 
+    step = step_sliced if sliced else step_lanes
+
     def sync_all():
+        if sliced and alive:
+            finish_sliced()
         if dist is not None:
             with rt.on_stream():
                 dist.barrier()
@@ -251,6 +296,7 @@ def main():
         for r in lanes:
             r.synchronize()
         torch.cuda.synchronize()
+        del alive[:-1]                                   # the last step's outputs feed the statistics below
 
     for k in range(n_lanes):                             # setup: every lane allocates its workspace once
         step(k)
@@ -328,8 +374,13 @@ def main():
                                    % count if args.workload == "yud" else
                                    "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
                        "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
-            "stage_ms": {"cnn": cnn_ms, "em": em_ms, "em_lanes": n_lanes, "em_workgroups": em_wgs, "em_cus_per_xcd": em_cus,
-                         "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"},
+            "stage_ms": ({"cnn": cnn_ms, "em_slice": em_ms, "em_mode": "slice", "em_slice_budget_ms": args.em_slice_ms,
+                          "note": "one stream: CNN(k), then one time-sliced EM launch on all CUs; images unfinished at the end "
+                                  "of a launch are parked and resumed by the next one, the last step is followed by a flush"}
+                         if sliced else
+                         {"cnn": cnn_ms, "em": em_ms, "em_mode": "lanes", "em_lanes": n_lanes, "em_workgroups": em_wgs,
+                          "em_cus_per_xcd": em_cus,
+                          "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"}),
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
                          "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},

@@ -99,6 +99,23 @@ int vpk_device_info(const vpk_handle* h, int32_t info[4]);
  * other CUs to the CNN. */
 int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
 
+/* Time-sliced EM launches for pipelines (run_cnn of batch k+1 while the EM of batch k is unfinished,
+ * evaluation.py:254-329).  The EM of a never-converging image takes 99 iterations (vp_localisation.py:256)
+ * where the average image takes ~25, so a launch that runs every image to completion holds its CUs for the
+ * slowest one.  With slice_ms > 0 every vpk_em_batch launch on this handle gets a time budget instead: an
+ * image still iterating when it expires is suspended at the top of its next iteration (its state is parked in
+ * HBM) and resumed -- by any workgroup, before fresh images -- in the next launch on the handle; images that
+ * had not started yet are parked likewise.  Results are bit-identical to an uninterrupted run.  Consequences
+ * for the caller: the outputs of a call are complete only after vpk_em_flush (or once later launches have
+ * finished its images), and the INPUT buffers of a call (l, lp, cnn, sphere, init_vp) as well as its output
+ * buffers must stay alive and untouched until then.  n_max: slots are sized for images of up to n_max lines
+ * (a later batch with more lines, or with other EM parameters, needs a vpk_em_flush first).
+ * slice_ms = 0 switches back (flushing first).  replaces: nothing in the reference (its run_em is one
+ * sequential loop, evaluation.py:309-329); this is what lets CNN and EM share one GPU without a tail. */
+int vpk_em_set_time_slice(vpk_handle* h, double slice_ms, int n_max);
+/* enqueue one launch that runs every parked image to completion (asynchronous on the handle's stream) */
+int vpk_em_flush(vpk_handle* h);
+
 /* ---- CNN (AlexNet-500, cnn/deploy.prototxt:1-304) -------------------------------------------- */
 /* replaces: caffe.Net(model_def, model_weights, caffe.TEST) + read_mean_blob
  * (evaluation.py:17-31).  blobs [host]: 16 host pointers to fp32 arrays in Caffe layout,

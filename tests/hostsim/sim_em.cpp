@@ -40,7 +40,31 @@ int sim_em_single(int n, double* l, const double* lp, const float* cnn, const un
     o.flags = flags_out; o.metric = metric_out; o.trace = trace_out; o.max_vp = max_vp;
     g_dbg.assign((size_t)p->num_iter * (1 + 4 * MAXM), 0.0);
     o.dbg = g_dbg.data();
-    em_run(c, o);
+    EmSlice sl;
+    sl.deadline = EM_NO_DEADLINE;
+    sl.start_iter = -1;
+    if (getenv("VPK_SIM_SLICED")) {
+        // time-sliced run: the stand-in clock always reads 0, so a deadline of 0 suspends the image at every
+        // checkpoint; the LDS image is destroyed and the caller's l / lp arrays are poisoned between slices
+        // (a suspended image must live in its slot only)
+        sl.deadline = 0;
+        int slices = 0;
+        std::vector<double> lp_copy(lp, lp + 4 * (size_t)n);
+        c.lp = lp_copy.data();
+        std::vector<double> l_keep;
+        while (em_run(c, o, sl) == EM_SUSPENDED) {
+            memset(g_sim_lds, 0xff, sizeof(g_sim_lds));
+            if (slices == 0) {
+                l_keep.assign(l, l + 3 * (size_t)n);
+                for (size_t q = 0; q < lp_copy.size(); ++q) lp_copy[q] = 1e300;
+                for (size_t q = 0; q < 3 * (size_t)n; ++q) l[q] = -1e300;
+            }
+            ++slices;
+        }
+        if (slices) memcpy(l, l_keep.data(), l_keep.size() * sizeof(double));
+        return slices;
+    }
+    em_run(c, o, sl);
     return 0;
 }
 

@@ -55,7 +55,7 @@ def default_params(**kw):
     return p
 
 
-def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, **kw):
+def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, sliced=False, **kw):
     n = lp.shape[0]
     p = default_params(**kw)
     l = np.ascontiguousarray(l, dtype=np.float64)
@@ -69,7 +69,11 @@ def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, **
     metric = np.zeros((n, max_vp)) if want_metric else None
     trace = np.zeros((p.num_iter + 1, 12))
     D, I, L, U = ctypes.c_double, ctypes.c_int32, ctypes.c_longlong, ctypes.c_uint32
-    lib().sim_em_single(n, _p(l, D), _p(lp, D), _p(cnn, ctypes.c_float), _p(sphere, ctypes.c_ubyte),
+    if sliced:      # suspend at every checkpoint, destroy the LDS image and the caller's arrays in between
+        os.environ["VPK_SIM_SLICED"] = "1"
+    else:
+        os.environ.pop("VPK_SIM_SLICED", None)
+    slices = lib().sim_em_single(n, _p(l, D), _p(lp, D), _p(cnn, ctypes.c_float), _p(sphere, ctypes.c_ubyte),
                         sphere.shape[0], _p(iv, D), 0 if iv is None else iv.shape[0], ctypes.byref(p),
                         max_vp, _p(vp, D), _p(sigma, D), _p(counts, D), _p(cw, D), _p(num, I), _p(assoc, L),
                         _p(it, I), _p(st, I), _p(fl, U), _p(metric, D), _p(trace, D))
@@ -77,7 +81,8 @@ def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, **
     lib().sim_last_states.restype = ctypes.POINTER(ctypes.c_double)
     raw = np.ctypeslib.as_array(lib().sim_last_states(), shape=(p.num_iter, 1 + 4 * 64)).copy()
     states = [(raw[i, 65:65 + 3 * int(raw[i, 0])].reshape(-1, 3), raw[i, 1:1 + int(raw[i, 0])]) for i in range(p.num_iter)]
-    return {"states": states, "status": int(st[0]), "flags": int(fl[0]), "iterations": int(it[0]), "vp": vp[:m],
+    os.environ.pop("VPK_SIM_SLICED", None)
+    return {"slices": slices, "states": states, "status": int(st[0]), "flags": int(fl[0]), "iterations": int(it[0]), "vp": vp[:m],
             "sigma": sigma[:m], "counts": counts[:m], "counts_weighted": cw[:m], "vp_assoc": assoc,
             "l": l, "trace": trace, "decision_metric": None if metric is None else metric[:, :m].T}
 

@@ -1,0 +1,112 @@
+"""Whole BASELINE.json configs through the HIP EM path against the REFERENCE's own stored results.
+
+tests/golden/full_c<config>.npz hold what the reference (vp_localisation.expectation_maximisation +
+calc_horizon, run in the build container by oracle/make_full_goldens.py) returned for EVERY scene of
+configs[1] (YUD-shape, 102 images = bench.py's workload) and configs[2] (ECD-shape, 103), for the
+configs[0] image (N = 800) and for a 64-image subsample of configs[3] (HLW-shape).  Bar per image:
+line->VP assignments bit-exact, same iteration count, same VP count and per-VP line counts, VP
+directions within 1e-4.
+
+Images listed in UNSTABLE are the ones where the reference's own answer is not stable: they never
+converge (99 iterations with sigma^2 at its 1e-12..1e-6 clamp, where one EM iteration amplifies a
+perturbation ~1.3x) and a ONE-ulp change of one input coordinate moves the reference's own VPs by more
+than the 1e-4 bar or flips assignments (oracle/ref_instability.py, tests/test_instability.py; DESIGN.md
+section 4).  For those the test asserts what is stable (status, iteration count, VP count) and bounds
+the damage (a handful of assignments) instead of skipping them.
+"""
+import numpy as np
+import pytest
+
+from vanishing_points_2017_amd import parity, synth
+
+pytestmark = pytest.mark.gpu
+
+# config -> {image index: max assignments allowed to differ}
+UNSTABLE = {
+    2: {86: 12},
+}
+
+
+def _run(cfg):
+    import os
+    if not os.path.isfile(parity.golden_path(cfg)):
+        pytest.skip("no stored reference results for config %d" % cfg)
+    from vanishing_points_2017_amd import em as gem
+    ref = parity.ReferenceResults(cfg)
+    scenes = [next(synth.config_scenes(cfg, count=1, start=int(i))) for i in ref.index]
+    for i, s in zip(ref.index, scenes):
+        assert parity.input_sha(s) == ref.get(i)["input_sha"], \
+            "config %d image %d: the generator produced other inputs than the reference saw" % (cfg, i)
+    res = gem.em_batch(scenes)
+    return ref, scenes, res
+
+
+def _check(cfg):
+    ref, scenes, res = _run(cfg)
+    unstable = UNSTABLE.get(cfg, {})
+    bad = []
+    for i, r in zip(ref.index, res):
+        g = ref.get(i)
+        c = parity.compare_one(r, g)
+        if int(i) in unstable:
+            assert c["status"] and c["iterations"] and c["num_vp"], (cfg, int(i), c)
+            assert 0 <= c["assoc_diff"] <= unstable[int(i)], (cfg, int(i), c)
+            continue
+        if not parity.passes(c):
+            bad.append((int(i), c))
+        assert r["flags"] & 4 == 0
+    assert not bad, "config %d: %d of %d images miss the parity bar: %s" % (cfg, len(bad), len(ref), bad[:5])
+    return ref, res
+
+
+def test_config2_yud_shape_all_102_images():
+    ref, _ = _check(2)
+    assert len(ref) == 102
+
+
+def test_config3_ecd_shape_all_103_images():
+    ref, _ = _check(3)
+    assert len(ref) == 103
+
+
+def test_config4_hlw_shape_subsample():
+    ref, _ = _check(4)
+    assert len(ref) >= 32
+
+
+def test_config1_single_image_n800_through_the_reference_call_surface():
+    """configs[0]: one image, N = 800, through vp_localisation.expectation_maximisation (example.py's path)."""
+    import os
+    if not os.path.isfile(parity.golden_path(1)):
+        pytest.skip("no stored reference results for config 1")
+    from vanishing_points_2017_amd import vp_localisation
+    ref = parity.ReferenceResults(1)
+    sc = next(synth.config_scenes(1, count=1))
+    g = ref.get(0)
+    assert sc["lp"].shape[0] == 800 and parity.input_sha(sc) == g["input_sha"]
+    l = sc["l"].copy()
+    res = vp_localisation.expectation_maximisation(l, sc["lp"].copy(), sc["cnn_response"], sphere_image=sc["sphere_image"])
+    res = dict(res, status=0 if res["vp"] is not None else 1)
+    c = parity.compare_one(res, g)
+    assert parity.passes(c), c
+    assert np.allclose(np.linalg.norm(l, axis=1), 1.0)          # l normalised in place (:185-186)
+
+
+def test_horizon_auc_equals_the_reference_on_config2():
+    """The 'horizon-AUC parity' half of the metric: errors of images 26..102 (benchmark.py:69) from the GPU
+    EM + GPU horizon selection vs the reference's stored horizons, same synthetic ground truth."""
+    from vanishing_points_2017_amd import auc as auc_mod, calc_horizon as ch
+    ref, scenes, res = _run(2)
+    todo = [(int(i), s, r) for i, s, r in zip(ref.index, scenes, res) if int(i) >= 25 and r["status"] == 0]
+    horizons = ch.calculate_horizon_batch([r for _, _, r in todo], maxbest=20, theta_vmin=np.pi / 10)
+    e_gpu, e_ref = [], []
+    for (i, s, _), h in zip(todo, horizons):
+        g = ref.get(i)
+        e_gpu.append(ch.horizon_error(h[0], h[1], s["true_horizon"], s["image_shape"]))
+        e_ref.append(ch.horizon_error(g["hP1"], g["hP2"], s["true_horizon"], s["image_shape"]))
+        if i not in UNSTABLE[2]:
+            assert np.array_equal(np.asarray(h[5]), g["combo"]), i       # same orthogonal triplet
+            assert abs(e_gpu[-1] - e_ref[-1]) <= 1e-6, i
+    a_gpu = auc_mod.calc_auc(np.array(e_gpu), cutoff=0.25)[0]
+    a_ref = auc_mod.calc_auc(np.array(e_ref), cutoff=0.25)[0]
+    assert abs(a_gpu - a_ref) <= 1e-4, (a_gpu, a_ref)

@@ -1,0 +1,68 @@
+"""Time-sliced EM launches (vpk_em_set_time_slice / vpk_em_flush): images suspended at a launch's deadline
+and resumed by later launches must give bit-identical results to uninterrupted runs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(out):
+    return {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+
+
+@pytest.mark.parametrize("slice_ms,wgs", [(0.3, 0), (1.5, 0), (0.2, 24)])
+def test_sliced_batches_equal_uninterrupted_batches(slice_ms, wgs):
+    import torch
+    from vanishing_points_2017_amd import em as gem, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(0, "slice%d" % wgs)
+    rt.handle.em_set_workgroups(wgs)
+    scenes = list(synth.config_scenes(2, count=60, start=40)) + [next(synth.config_scenes(2, count=1, start=86))]
+    p = gem._params({})
+    d = gem.upload_batch(rt, scenes)
+    l0 = d["l"].clone()
+    rt.handle.em_set_time_slice(0.0)
+    ref = gem.em_batch_device(rt, d["offsets"], l0.clone(), d["lp"], d["cnn"], d["sphere"], None, p)
+    rt.synchronize()
+    ref = _host(ref)
+    assert ref["iterations"].max() == 99                  # the straggler is in the batch
+    rt.handle.em_set_time_slice(slice_ms, int(np.diff(d["offsets"]).max()))
+    keep = []
+    for step in range(4):                                 # four calls in flight before the flush
+        lb = l0.clone()
+        keep.append((lb, gem.em_batch_device(rt, d["offsets"], lb, d["lp"], d["cnn"], d["sphere"], None, p)))
+    with rt.on_stream():
+        rt.handle.em_flush()
+    rt.synchronize()
+    for lb, out in keep:
+        got = _host(out)
+        for k in ("status", "iterations", "num_vp", "vp_assoc", "flags"):
+            assert np.array_equal(got[k], ref[k]), k
+        for b in range(len(scenes)):
+            m = int(ref["num_vp"][b])
+            for k in ("vp", "sigma", "counts", "counts_weighted"):
+                assert np.array_equal(got[k][b, :m], ref[k][b, :m]), (k, b)
+        assert torch.equal(lb, keep[0][0])
+    rt.handle.em_set_time_slice(0.0)
+    again = _host(gem.em_batch_device(rt, d["offsets"], l0.clone(), d["lp"], d["cnn"], d["sphere"], None, p))
+    rt.synchronize()
+    assert np.array_equal(again["vp_assoc"], ref["vp_assoc"])
+
+
+def test_layout_change_while_images_are_parked_is_refused():
+    from vanishing_points_2017_amd import _lib, em as gem, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(0, "slice_guard")
+    small = [next(synth.config_scenes(2, count=1, start=86))]
+    big = [synth.make_scene(9, 700, 3)]
+    p = gem._params({})
+    rt.handle.em_set_time_slice(0.05, 0)
+    ds, db = gem.upload_batch(rt, small), gem.upload_batch(rt, big)
+    out = gem.em_batch_device(rt, ds["offsets"], ds["l"], ds["lp"], ds["cnn"], ds["sphere"], None, p)
+    with pytest.raises(_lib.VpkError):
+        gem.em_batch_device(rt, db["offsets"], db["l"], db["lp"], db["cnn"], db["sphere"], None, p)
+    with rt.on_stream():
+        rt.handle.em_flush()
+    rt.synchronize()
+    assert int(out["iterations"].cpu()[0]) == 99
+    rt.handle.em_set_time_slice(0.0)

@@ -112,3 +112,18 @@ def test_degenerate_no_initial_vp():
     with pytest.raises(ValueError):
         em.expectation_maximisation(g["l"].copy(), g["lp"].copy(), g["cnn_response"].copy(),
                                     sphere_image=np.zeros((500, 500), np.uint8))
+
+
+@pytest.mark.parametrize("name", ["yud_n250", "ecd_n300_v8", "stress_n300", "tiny_n12", "noweights_n100"])
+def test_suspended_and_resumed_run_is_bit_identical(name):
+    """Time-sliced launches (vpk_em_set_time_slice): the image is suspended at EVERY checkpoint, its LDS state
+    destroyed and the caller's l / lp arrays poisoned in between -- the result must not differ in a single bit
+    from the uninterrupted run (splits and merges included: yud_n250 / ecd_n300_v8 split)."""
+    g = load(name)
+    kw = em_kwargs(g)
+    a = simlib.em_single(g["l"].copy(), g["lp"], g["cnn_response"], g["sphere_image"], **kw)
+    b = simlib.em_single(g["l"].copy(), g["lp"], g["cnn_response"], g["sphere_image"], sliced=True, **kw)
+    assert b["slices"] >= min(a["iterations"], 1) and a["slices"] == 0
+    assert a["status"] == b["status"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"]
+    for k in ("vp", "sigma", "counts", "counts_weighted", "vp_assoc", "l"):
+        assert np.array_equal(a[k], b[k]), k

@@ -58,9 +58,11 @@ struct Shared {
     int ibuf[8];
     double dbuf[16];
     double sigma_prior;
+    double active_us;       // device time spent on this image in earlier time slices
 };
 
 constexpr size_t SH_BYTES = (sizeof(Shared) + 15) / 16 * 16;
+static_assert(sizeof(Shared) % 8 == 0 && sizeof(Shared) <= EM_STATE_DOUBLES * 8, "Shared must fit the slot's state region");
 // LDS layout of every EM kernel: [Shared | smoother operand panel]
 VPK_DEV Shared& SH() { return *reinterpret_cast<Shared*>(lds_base()); }
 VPK_DEV double* WT() { return reinterpret_cast<double*>(lds_base() + SH_BYTES); }
@@ -96,6 +98,9 @@ struct EmCtx {
     gdp rowsum;   // N : sum_j lsim[j][k]
     int wt_doubles;   // its capacity (WT_DOUBLES, or more when the launch gives the workgroup a whole CU)
     gdp part;     // global: nwaves x mcap x ldn row-slice partial sums of the smoother
+    gdp lcopy;    // N x 3 normalised lines (l points here once the setup has run)
+    gdp lpcopy;   // N x 4 segment end points (lp likewise)
+    gdp state;    // snapshot of Shared while the image is suspended
 };
 
 // point the context's scratch pointers into one slot
@@ -108,6 +113,7 @@ VPK_DEV void bind_scratch(EmCtx& c, double* base_, const EmLayout& L, bool do_sp
     c.cl = do_split ? base + L.cl : (gdp) nullptr;
     c.rowsum = base + L.rowsum;
     c.part = base + L.part;
+    c.lcopy = base + L.lcopy; c.lpcopy = base + L.lpcopy; c.state = base + L.state;
     c.assoc = (gip)(base + L.assoc);
     c.idx = (gip)(base + L.idx);
 }
@@ -1751,28 +1757,68 @@ VPK_DEV void trace_add(EmOut& o, int i, int slot, double v) {
 // ---------------------------------------------------------------------------------------------
 // the driver: expectation_maximisation (vp_localisation.py:168-450)
 // ---------------------------------------------------------------------------------------------
-VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
+// Time slicing.  A launch may carry a deadline: an image that is still iterating when it passes is SUSPENDED
+// at the top of its next iteration -- the only state that lives outside the slot's HBM scratch at that point
+// is the Shared block in LDS, which is copied into the slot -- and resumed by a later launch (any workgroup)
+// at exactly that point.  The arithmetic does not depend on where an image was suspended: results are
+// bit-identical to an uninterrupted run.  Why: the EM of a never-converging image takes 99 iterations (~20 ms)
+// against ~5 ms for the average one, and a launch that must run every image to completion holds its CUs for
+// the slowest image.
+constexpr int EM_DONE = 0, EM_SUSPENDED = 1;
+constexpr long long EM_NO_DEADLINE = 0x7fffffffffffffffll;
+struct EmSlice {
+    long long deadline;   // clock_ticks() value; EM_NO_DEADLINE = run to completion
+    int start_iter;       // in: -1 = fresh image, i >= 0 = resume at the top of iteration i; out: where it was suspended
+};
+
+VPK_DEVFN void save_state(EmCtx& c) {
+    typedef VPK_GLOBAL unsigned long long* gup;
+    gup dst = (gup)c.state;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&SH());
+    for (int q = tid(); q < (int)(sizeof(Shared) / 8); q += nthreads()) dst[q] = src[q];
+    block_sync();
+}
+VPK_DEVFN void restore_state(EmCtx& c) {
+    typedef const VPK_GLOBAL unsigned long long* cgup;
+    cgup src = (cgup)c.state;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&SH());
+    block_sync();
+    for (int q = tid(); q < (int)(sizeof(Shared) / 8); q += nthreads()) dst[q] = src[q];
+    block_sync();
+}
+
+VPK_DEVFN int em_run(EmCtx& c, EmOut& o, EmSlice& sl) {
     Shared& sh = SH();
     const vpk_em_params& P = c.prm;
     const double max_stdd = 1e-6;                             // :196-198 ("angle")
     const double merge_thresh_final = P.merge_thresh * 10;    // :190
     const int split_merge_it = 100;                           // :193
-    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.ibuf[5] = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
+    long long tk = clock_ticks();
+    const long long t_begin = tk;
+    int first = 0;
+    if (sl.start_iter >= 0) {
+        restore_state(c);
+        first = sl.start_iter;
+    } else {
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.ibuf[5] = 0; sh.active_us = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
     block_sync();
     if (o.trace)
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;
-    if (c.N <= 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }
+    if (c.N <= 0) { write_result(c, o, VPK_EM_NO_VP, 0); return EM_DONE; }
 
-    long long tk = clock_ticks();
-    const long long t_begin = tk;
     if (P.use_weights) pairwise_setup(c, true);               // :177-178 (+ :230 kNN score)
     else pairwise_setup(c, false);                            // only lines_angles is needed
     trace_put(o, P.num_iter, 0, lap(tk));                     // last trace row: setup timings
-    normalise_lines(c);                                       // :185-186, :226
+    normalise_lines(c);                                       // :185-186, :226 (the caller's array, in place)
+    for (int q = tid(); q < 3 * c.N; q += nthreads()) c.lcopy[q] = c.l[q];
+    for (int q = tid(); q < 4 * c.N; q += nthreads()) c.lpcopy[q] = c.lp[q];
+    block_sync();
+    c.l = c.lcopy;                                            // from here on the image lives in its slot only
+    c.lp = c.lpcopy;
     initial_vps(c);                                           // :208
     const int m_found = sh.M;
     prior_setup(c);                                           // :210
-    if (m_found == 0) { write_result(c, o, VPK_EM_NO_INITIAL_VP, 0); return; }   // ValueError at :165
+    if (m_found == 0) { write_result(c, o, VPK_EM_NO_INITIAL_VP, 0); return EM_DONE; }   // ValueError at :165
     if (c.init_vp) {                                          // :212-215
         if (tid() == 0) {
             int m = c.n_init < MAXM ? c.n_init : MAXM;
@@ -1801,10 +1847,23 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
     block_sync();
     compact_vps(c);
     trace_put(o, P.num_iter, 1, lap(tk));
+    }
 
-    for (int i = 0; i < P.num_iter; ++i) {
+    for (int i = first; i < P.num_iter; ++i) {
+        if (sl.deadline != EM_NO_DEADLINE && i > sl.start_iter) {   // checkpoint (at least one iteration per slice)
+            if (tid() == 0) sh.ibuf[6] = clock_ticks() >= sl.deadline;
+            block_sync();
+            if (sh.ibuf[6]) {
+                if (tid() == 0) sh.active_us += (double)(clock_ticks() - t_begin) * CLOCK_US;
+                block_sync();
+                save_state(c);
+                sl.start_iter = i;
+                return EM_SUSPENDED;
+            }
+        }
+        tk = clock_ticks();
         const long long t_iter = tk;
-        if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }             // :258-260
+        if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return EM_DONE; }     // :258-260
         double events = 0;
         if (i % P.split_merge_freq == 0 && i > 0 && i < split_merge_it && P.do_split) {   // :262-269
             int mb = sh.M;
@@ -1847,7 +1906,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         if (max_err < P.final_convergence || i == P.num_iter - 1 || !P.do_iterations) {   // :335
             if (P.do_merge) merge_vps(c, true, merge_thresh_final);                       // :339
             trace_put(o, P.num_iter, 3, (double)sh.M);        // finalisation audit trail: M after merge
-            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, i); return; }   // reference: argmax of empty (:349)
+            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, i); return EM_DONE; }   // reference: argmax of empty (:349)
             estep(c, sh.cur);                                 // :344 (stale index i)
             smooth(c);                                        // :346
             assign_lines(c, false);                           // :349
@@ -1856,7 +1915,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             trace_put(o, P.num_iter, 4, (double)sh.M);        // ... after the hard-assignment M-step
             estep(c, sh.cur);                                 // :398 (still index i)
             smooth(c);                                        // :400
-            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return; }               // :402-404
+            if (sh.M == 0) { write_result(c, o, VPK_EM_NO_VP, 0); return EM_DONE; }       // :402-404
             assign_lines(c, false);                           // :406
             for (int m = tid(); m < sh.M; m += nthreads()) sh.icnt[m] = 0;
             block_sync();
@@ -1887,13 +1946,13 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
             trace_put(o, i, 2, (double)sh.M);
             trace_put(o, i, 3, events + 2);
             trace_put(o, i, 7, (double)(clock_ticks() - t_iter) * CLOCK_US);
-            trace_put(o, P.num_iter, 2, (double)(clock_ticks() - t_begin) * CLOCK_US);
+            trace_put(o, P.num_iter, 2, sh.active_us + (double)(clock_ticks() - t_begin) * CLOCK_US);
             trace_put(o, P.num_iter, 6, sh.dbuf[8] + sh.dbuf[10]);   // smoother: operand staging + partial reduction
             trace_put(o, P.num_iter, 7, sh.dbuf[9]);                  // smoother: main loop (wave 0)
             trace_put(o, P.num_iter, 8, sh.dbuf[14]);                 // E-step: prior part
             trace_put(o, P.num_iter, 9, sh.dbuf[15]);                 // E-step: line part
             write_result(c, o, VPK_EM_OK, i);                 // :439-442
-            return;
+            return EM_DONE;
         }
         if (i % P.split_merge_freq == 0 && i > 0 && i <= split_merge_it + P.split_merge_freq && P.do_merge) {
             int mb = sh.M;
@@ -1912,6 +1971,7 @@ VPK_DEVFN void em_run(EmCtx& c, EmOut& o) {
         block_sync();
     }
     write_result(c, o, VPK_EM_NO_VP, 0);                      // :450
+    return EM_DONE;
 }
 
 }  // namespace vpk

@@ -15,10 +15,15 @@ namespace vpk {
 struct EmLayout {
     int ldn, ld, mcap, nwaves;
     size_t lsim, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, part, cl, assoc, idx;
+    size_t lcopy, lpcopy, state;
     size_t total_doubles;
 };
 
 inline size_t em_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// doubles reserved per slot for the snapshot of the workgroup's LDS state (em_device.hpp: Shared) that a
+// suspended image resumes from (time-sliced launches, vpk_em_set_time_slice)
+constexpr size_t EM_STATE_DOUBLES = 2048;
 
 inline int em_mcap(int num_init_vp, int n_init, bool has_init, bool do_split, int num_iter, int freq,
                    int maxm) {
@@ -60,6 +65,9 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.cl = o;      o += do_split ? n * n : 8;
     L.assoc = o;   o += em_align(n, 2) / 2;            // n ints
     L.idx = o;     o += em_align(3 * n, 2) / 2;        // 3n ints
+    L.lcopy = o;   o += 3 * n;                         // normalised lines: the image no longer depends on the
+    L.lpcopy = o;  o += 4 * n;                         //   caller's l / lp buffers once its setup has run
+    L.state = o;   o += EM_STATE_DOUBLES;
     L.total_doubles = em_align(o, 32);                 // 256-byte aligned slots
     return L;
 }

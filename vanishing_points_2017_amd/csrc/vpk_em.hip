@@ -7,6 +7,7 @@
 #include "vpk_internal.hpp"
 
 #include <algorithm>
+#include <string.h>
 #include <numeric>
 #include <vector>
 
@@ -61,43 +62,139 @@ struct EmBatchArgs {
     int wt_doubles;
 };
 
-__global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a) {
-    VPK_SHARED_DECL;
-    for (;;) {
-        if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
-        block_sync();
-        const int q = sh.ibuf[7];
-        block_sync();
-        if (q >= a.B) break;
-        const int img = a.order[q];
-        const long long off = a.offsets[img];
-        EmCtx c;
-        c.N = (int)(a.offsets[img + 1] - off);
-        c.l = (gdp)(a.l + 3 * off);
-        c.lp = (cgdp)(a.lp + 4 * off);
-        c.cnn = (cgfp)(a.cnn + (size_t)img * NCELL);
-        c.sphere = (cgbp)(a.sphere + (size_t)img * a.ssize * a.ssize);
-        c.ssize = a.ssize;
-        c.init_vp = a.init_vp ? (cgdp)(a.init_vp + (size_t)img * a.n_init * 3) : (cgdp) nullptr;
-        c.n_init = a.n_init;
-        c.prm = a.prm;
-        c.wt_doubles = a.wt_doubles;
-        bind_scratch(c, a.scratch + (size_t)block_id() * a.L.total_doubles, a.L, a.prm.do_split != 0);
-        EmOut o;
-        o.max_vp = a.max_vp;
-        o.vp = a.vp_out + (size_t)img * a.max_vp * 3;
-        o.sigma = a.sigma_out + (size_t)img * a.max_vp;
-        o.counts = a.counts_out + (size_t)img * a.max_vp;
-        o.counts_w = a.counts_w_out + (size_t)img * a.max_vp;
-        o.num_vp = a.num_vp_out + img;
-        o.assoc = a.assoc_out + off;
-        o.iterations = a.iterations_out + img;
-        o.status = a.status_out + img;
-        o.flags = a.flags_out + img;
-        o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
-        o.trace = a.trace_out ? a.trace_out + (size_t)img * (a.prm.num_iter + 1) * TRACE_COLS : nullptr;
-        em_run(c, o);
+// ---- time-sliced launches (vpk_em_set_time_slice) ------------------------------------------------
+// An image that is not finished when its launch's deadline passes is parked as an EmCarry entry: the next
+// launch on the handle drains the entries of the previous one before it takes fresh images.  Entries of
+// images that were never started (the deadline passed first) carry slot = -1.
+struct EmCarry {
+    EmCtx c;
+    EmOut o;
+    int iter;     // -1: not started; >= 0: resume at the top of this iteration (state in the slot)
+    int slot;     // -1: none yet
+};
+struct EmSliceArgs {
+    int enabled;
+    long long budget_ticks;   // 0 = no deadline (flush): everything runs to completion
+    int* ctr;                 // [0] consumed entries of `in`, [1] entries in `in`, [2] entries appended to `out`
+    EmCarry* in;
+    EmCarry* out;
+    int cap;                  // capacity of `out`
+    int* busy;                // slot flags
+    int nslots;
+};
+
+// take a free slot (session mode: slots outlive the launch, so they are not tied to the workgroup)
+VPK_DEV int acquire_slot(const EmSliceArgs& ss) {
+    Shared& sh = SH();
+    if (tid() == 0) {
+        int got = -1;
+        for (int start = (block_id() * 2) % ss.nslots; got < 0;)
+            for (int k = 0; k < ss.nslots && got < 0; ++k) {
+                const int s = (start + k) % ss.nslots;
+                if (atomicCAS(&ss.busy[s], 0, 1) == 0) got = s;
+            }
+        sh.ibuf[7] = got;
     }
+    block_sync();
+    const int slot = sh.ibuf[7];
+    block_sync();
+    return slot;
+}
+
+__global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSliceArgs ss) {
+    VPK_SHARED_DECL;
+    const long long t_start = clock_ticks();
+    const long long deadline = (ss.enabled && ss.budget_ticks > 0) ? t_start + ss.budget_ticks : EM_NO_DEADLINE;
+    for (;;) {
+        EmCtx c;
+        EmOut o;
+        EmSlice sl;
+        sl.deadline = deadline;
+        sl.start_iter = -1;
+        int slot = -1;
+        bool have = false;
+        // 1. images parked by the previous launch
+        if (ss.enabled) {
+            if (tid() == 0) {
+                int e = -1;
+                if (ss.ctr[0] < ss.ctr[1]) { e = atomicAdd(&ss.ctr[0], 1); if (e >= ss.ctr[1]) e = -1; }
+                sh.ibuf[7] = e;
+            }
+            block_sync();
+            const int e = sh.ibuf[7];
+            block_sync();
+            if (e >= 0) {
+                const EmCarry& k = ss.in[e];
+                c = k.c; o = k.o; sl.start_iter = k.iter; slot = k.slot;
+                have = true;
+            }
+        }
+        // 2. fresh images of this call
+        if (!have) {
+            if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
+            block_sync();
+            const int q = sh.ibuf[7];
+            block_sync();
+            if (q >= a.B) break;
+            const int img = a.order[q];
+            const long long off = a.offsets[img];
+            c.N = (int)(a.offsets[img + 1] - off);
+            c.l = (gdp)(a.l + 3 * off);
+            c.lp = (cgdp)(a.lp + 4 * off);
+            c.cnn = (cgfp)(a.cnn + (size_t)img * NCELL);
+            c.sphere = (cgbp)(a.sphere + (size_t)img * a.ssize * a.ssize);
+            c.ssize = a.ssize;
+            c.init_vp = a.init_vp ? (cgdp)(a.init_vp + (size_t)img * a.n_init * 3) : (cgdp) nullptr;
+            c.n_init = a.n_init;
+            c.prm = a.prm;
+            c.wt_doubles = a.wt_doubles;
+            o.max_vp = a.max_vp;
+            o.vp = a.vp_out + (size_t)img * a.max_vp * 3;
+            o.sigma = a.sigma_out + (size_t)img * a.max_vp;
+            o.counts = a.counts_out + (size_t)img * a.max_vp;
+            o.counts_w = a.counts_w_out + (size_t)img * a.max_vp;
+            o.num_vp = a.num_vp_out + img;
+            o.assoc = a.assoc_out + off;
+            o.iterations = a.iterations_out + img;
+            o.status = a.status_out + img;
+            o.flags = a.flags_out + img;
+            o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
+            o.trace = a.trace_out ? a.trace_out + (size_t)img * (a.prm.num_iter + 1) * TRACE_COLS : nullptr;
+        }
+        int result = EM_SUSPENDED;
+        // an image that has not been started when the deadline has passed is parked as it is -- unless the
+        // list is full: then it runs now (a longer launch, never a lost image)
+        bool park_unstarted = false;
+        if (ss.enabled && sl.start_iter < 0 && slot < 0 && deadline != EM_NO_DEADLINE) {
+            if (tid() == 0) sh.ibuf[7] = (clock_ticks() >= deadline) && (ss.ctr[2] < ss.cap - nblocks());
+            block_sync();
+            park_unstarted = sh.ibuf[7] != 0;
+            block_sync();
+        }
+        if (!park_unstarted) {
+            if (slot < 0) slot = ss.enabled ? acquire_slot(ss) : block_id();
+            if (sl.start_iter < 0) bind_scratch(c, a.scratch + (size_t)slot * a.L.total_doubles, a.L, c.prm.do_split != 0);
+            result = em_run(c, o, sl);
+        }
+        if (result == EM_SUSPENDED) {          // only in session mode
+            if (tid() == 0) {
+                const int e = atomicAdd(&ss.ctr[2], 1);
+                EmCarry& k = ss.out[e];
+                k.c = c; k.o = o; k.iter = park_unstarted ? -1 : sl.start_iter; k.slot = slot;
+            }
+            block_sync();
+        } else if (ss.enabled) {
+            block_sync();
+            if (tid() == 0) { __threadfence(); atomicExch(&ss.busy[slot], 0); }
+        }
+    }
+}
+
+// between two time-sliced launches: what the last launch parked becomes the next launch's input list
+__global__ void em_rotate_kernel(int* ctr) {
+    ctr[1] = ctr[2];
+    ctr[0] = 0;
+    ctr[2] = 0;
 }
 
 // ---- fine-grained kernels (one workgroup, unit parity) ------------------------------------------
@@ -288,6 +385,42 @@ int check_params(vpk_handle* h, const vpk_em_params* p, int n_init, bool has_ini
     return VPK_OK;
 }
 
+constexpr int EM_CARRY_CAP = 4096;     // parked images per list (a full list makes further images run on instead)
+constexpr size_t EM_SESS_HEAD = 256;    // counters
+
+struct SessView { int* ctr; int* busy; EmCarry* list[2]; };
+SessView sess_view(vpk_handle* h) {
+    char* base = (char*)h->em_sess;
+    SessView v;
+    v.ctr = (int*)base;
+    v.busy = (int*)(base + EM_SESS_HEAD);
+    char* lists = base + EM_SESS_HEAD + em_align((size_t)h->em_sess_slots * 4, 256);
+    v.list[0] = (EmCarry*)lists;
+    v.list[1] = (EmCarry*)(lists + em_align(sizeof(EmCarry) * EM_CARRY_CAP, 256));
+    return v;
+}
+
+// launch that finishes every parked image (no deadline, no fresh images); asynchronous on the handle's stream
+int em_flush(vpk_handle* h) {
+    if (!h->em_unflushed) return VPK_OK;
+    SessView v = sess_view(h);
+    hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr);
+    h->em_sess_in ^= 1;
+    EmBatchArgs a = {};
+    a.B = 0;
+    a.queue = v.ctr + 8;                       // a counter that is never below B = 0
+    a.L = h->em_sess_layout;
+    a.scratch = (double*)h->em_ws;
+    a.wt_doubles = h->em_sess_wt_doubles;
+    EmSliceArgs ss;
+    ss.enabled = 1; ss.budget_ticks = 0; ss.ctr = v.ctr; ss.in = v.list[h->em_sess_in]; ss.out = v.list[h->em_sess_in ^ 1];
+    ss.cap = EM_CARRY_CAP; ss.busy = v.busy; ss.nslots = h->em_sess_slots;
+    hipLaunchKernelGGL(em_batch_kernel, dim3(h->em_sess_wgs), dim3(EM_THREADS), h->em_sess_lds, h->stream, a, ss);
+    VPK_HIP(h, hipGetLastError());
+    h->em_unflushed = false;
+    return VPK_OK;
+}
+
 EmLayout small_layout(int n, int m) {
     return em_layout(n, (int)em_align((size_t)(m > 0 ? m : 1), 8), EM_WAVES, true, false);
 }
@@ -333,11 +466,40 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     }
     if (nmax > 46000) return vpk_fail(h, VPK_ERR_LIMIT, "vpk_em_batch: more than 46000 lines in one image");
     const bool has_init = init_vp != nullptr;
+    const bool sliced = h->em_slice_ms > 0.0;
+    if (!sliced && h->em_unflushed) { rc = em_flush(h); if (rc) return rc; }
+    if (sliced && (long long)h->em_slice_nmax > nmax) nmax = h->em_slice_nmax;
     int mcap = em_mcap(p->num_init_vp, n_init, has_init, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
     EmLayout L = em_layout((int)nmax, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
     const size_t slot_bytes = L.total_doubles * sizeof(double);
     const EmMode mode = em_mode(h, batch, (int)nmax, mcap);
-    const int slots = em_slots(h, batch, slot_bytes, mode.per_cu);
+    int slots = em_slots(h, batch, slot_bytes, mode.per_cu);
+    int wgs = slots;
+    if (sliced) {
+        // the workgroups of a sliced launch also resume what earlier launches parked, so their number does not
+        // follow the batch; slots outlive the launch: running (<= wgs) + parked and not yet resumed (<= wgs)
+        wgs = h->cu_share * mode.per_cu;
+        if (h->em_max_workgroups > 0 && wgs > h->em_max_workgroups) wgs = h->em_max_workgroups;
+        slots = 2 * wgs + 8;
+        if ((size_t)slots * slot_bytes > h->total_mem / 2)
+            return vpk_fail(h, VPK_ERR_LIMIT, "vpk_em_batch: time-sliced slots exceed half of the device memory");
+        const bool same = h->em_sess && h->em_sess_slot_bytes == slot_bytes && h->em_sess_slots == slots &&
+                          h->em_sess_wgs == wgs && memcmp(&h->em_sess_layout, &L, sizeof(L)) == 0;
+        if (!same) {
+            if (h->em_unflushed)
+                return vpk_fail(h, VPK_ERR_STATE, "vpk_em_batch: the slot layout changed (more lines than "
+                                "vpk_em_set_time_slice was told, or other parameters) while images are parked: vpk_em_flush first");
+            const size_t need = EM_SESS_HEAD + em_align((size_t)slots * 4, 256) + 2 * em_align(sizeof(EmCarry) * EM_CARRY_CAP, 256);
+            rc = vpk_reserve(h, &h->em_sess, &h->em_sess_bytes, need, "hipMalloc(EM session)");
+            if (rc) return rc;
+            VPK_HIP(h, hipMemsetAsync(h->em_sess, 0, need, h->stream));
+            h->em_sess_slot_bytes = slot_bytes; h->em_sess_slots = slots; h->em_sess_wgs = wgs;
+            h->em_sess_layout = L; h->em_sess_in = 0;
+            h->em_sess_wt_doubles = mode.wt_doubles; h->em_sess_lds = mode.lds_bytes;
+        }
+    }
+    if (h->em_unflushed && (size_t)slots * slot_bytes > h->em_ws_bytes)
+        return vpk_fail(h, VPK_ERR_STATE, "vpk_em_batch: workspace would move while images are parked: vpk_em_flush first");
     rc = vpk_reserve(h, &h->em_ws, &h->em_ws_bytes, (size_t)slots * slot_bytes, "hipMalloc(EM workspace)");
     if (rc) return rc;
     // header: offsets (B+1 i64) | order (B i32) | queue counter
@@ -386,9 +548,37 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
     a.wt_doubles = mode.wt_doubles;
-    hipLaunchKernelGGL(em_batch_kernel, dim3(slots), dim3(EM_THREADS), mode.lds_bytes, h->stream, a);
+    EmSliceArgs ss = {};
+    if (sliced) {
+        SessView v = sess_view(h);
+        hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr);   // last launch's parked list -> input
+        h->em_sess_in ^= 1;
+        ss.enabled = 1;
+        ss.budget_ticks = (long long)(h->em_slice_ms * 1e-3 / (CLOCK_US * 1e-6));
+        if (ss.budget_ticks < 1) ss.budget_ticks = 1;
+        ss.ctr = v.ctr; ss.in = v.list[h->em_sess_in]; ss.out = v.list[h->em_sess_in ^ 1];
+        ss.cap = EM_CARRY_CAP; ss.busy = v.busy; ss.nslots = slots;
+        h->em_unflushed = true;
+    }
+    hipLaunchKernelGGL(em_batch_kernel, dim3(wgs), dim3(EM_THREADS), mode.lds_bytes, h->stream, a, ss);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
+}
+
+int vpk_em_set_time_slice(vpk_handle* h, double slice_ms, int n_max) {
+    if (!h || !(slice_ms >= 0.0) || n_max < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_time_slice: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
+    if (slice_ms == 0.0 && h->em_unflushed) { int rc = em_flush(h); if (rc) return rc; }
+    h->em_slice_ms = slice_ms;
+    h->em_slice_nmax = n_max;
+    return VPK_OK;
+}
+
+int vpk_em_flush(vpk_handle* h) {
+    if (!h) return VPK_ERR_ARG;
+    VPK_HIP(h, hipSetDevice(h->device));
+    return em_flush(h);
 }
 
 int vpk_pairwise(vpk_handle* h, int n, const double* lp, double* lsim_out, double* lscore_out,

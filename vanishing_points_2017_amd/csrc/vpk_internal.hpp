@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/vpk.h"
+#include "em_layout.hpp"
 
 struct vpk_cnn_state;   // vpk_cnn.hip
 
@@ -40,6 +41,20 @@ struct vpk_handle {
     void* raster_hdr = nullptr;
     size_t raster_hdr_bytes = 0;
     bool em_ready = false;    // dynamic-LDS attribute set on the EM kernels
+    // time-sliced EM launches (vpk_em_set_time_slice): images not finished within a launch's budget are parked
+    // in device-side lists and resumed by the next launch; their slots outlive the launch
+    double em_slice_ms = 0.0;        // 0 = off: every call runs its images to completion
+    int em_slice_nmax = 0;           // slots are sized for at least this many lines
+    void* em_sess = nullptr;         // [counters | slot flags | parked-image list A | list B]
+    size_t em_sess_bytes = 0;
+    int em_sess_in = 0;              // which list the next launch drains
+    bool em_unflushed = false;       // parked images may exist
+    size_t em_sess_slot_bytes = 0;   // geometry the parked images were laid out with
+    int em_sess_slots = 0;
+    int em_sess_wgs = 0;
+    int em_sess_wt_doubles = 0;
+    size_t em_sess_lds = 0;
+    vpk::EmLayout em_sess_layout = {};
     vpk_cnn_state* cnn = nullptr;
 };
 

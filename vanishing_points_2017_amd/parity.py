@@ -1,6 +1,6 @@
 """Comparison of EM results with stored results of the REFERENCE (tests/golden/full_c<config>.npz).
 
-The files are written in the build container by oracle/make_full_goldens.py, which runs the
+The files are written in the build container by make_full_goldens.py (test infrastructure), which runs the
 reference's own expectation_maximisation (vp_localisation.py:168-450) and
 calculate_horizon_and_ortho_vp (calc_horizon.py:19-225) over every seeded scene of a BASELINE.json
 config.  This module only reads that data and applies the parity bar of BASELINE.json's north_star:
