@@ -48,11 +48,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
-    ap.add_argument("--em-mode", default="slice", choices=["slice", "lanes"],
-                    help="slice: ONE stream, CNN(k) then a time-sliced EM launch on all CUs (unfinished images are parked and "
-                         "resumed by the next step's launch; vpk_em_set_time_slice); lanes: round 1's scheme, whole EM "
-                         "batches on --em-lanes streams beside the CNN stream")
-    ap.add_argument("--em-slice-ms", type=float, default=1.6, help="time budget of one sliced EM launch")
+    ap.add_argument("--em-mode", default="slice", choices=["slice", "serial", "lanes"],
+                    help="slice: one CNN stream + one EM stream whose launches are time-sliced (vpk_em_set_time_slice): a launch "
+                         "holds --em-wgs CUs for at most --em-slice-ms, images unfinished by then are parked and resumed by the "
+                         "next launch, so no launch waits for a 99-iteration straggler; serial: ONE stream, CNN(k) then a sliced EM "
+                         "launch on all CUs; lanes: round 1's scheme, whole EM batches on --em-lanes streams beside the CNN stream")
+    ap.add_argument("--em-slice-ms", type=float, default=-1.0, help="time budget of one sliced EM launch (default 8 slice / 1.6 serial)")
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--em-wgs", type=int, default=-1,
@@ -202,13 +203,20 @@ def main():
     from vanishing_points_2017_amd import cnn, em as gem, sharding
     from vanishing_points_2017_amd.runtime import get_runtime
     count = args.images or (102 if args.workload == "yud" else 512)
-    sliced = args.em_mode == "slice" and args.workload == "yud"
+    sliced = args.em_mode in ("slice", "serial") and args.workload == "yud"
     if sliced:
-        # ONE stream: CNN(k) on all CUs, then a time-sliced EM launch on all CUs.  An image that is still iterating
-        # when the launch's budget is spent is parked in HBM and resumed by step k+1's launch, so no launch waits
-        # for a 99-iteration straggler and the two kernels never compete for CUs.
-        n_lanes, em_cus, em_wgs = 1, 0, 0
-        rt = rt_cnn = get_runtime(local_rank, "main")
+        # Time-sliced EM launches: an image that is still iterating when its launch's budget is spent is parked in
+        # HBM and resumed by the next launch, so no launch holds CUs for a 99-iteration straggler.
+        #   slice : CNN stream + ONE EM stream; an EM launch holds at most em_wgs CUs for at most the budget, its
+        #           workgroups leave as soon as no image is waiting, and the CNN's kernels take every other CU
+        #   serial: one stream, CNN(k) on all CUs, then an EM launch on all CUs
+        n_lanes, em_cus = 1, 0
+        serial = args.em_mode == "serial"
+        em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else 64)
+        slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 8.0)
+        rt = get_runtime(local_rank, "main" if serial else "em")
+        rt_cnn = rt if serial else get_runtime(local_rank, "cnn")
+        rt.handle.em_set_workgroups(em_wgs)
         lanes = [rt]
     else:
         # lanes (library handle + HIP stream each) on the same GPU: one for the CNN, --em-lanes for the EM,
@@ -236,18 +244,21 @@ def main():
     n_lines = np.diff(d["offsets"])
     max_vp = 64
     if sliced:
-        rt.handle.em_set_time_slice(args.em_slice_ms, int(n_lines.max()))
+        rt.handle.em_set_time_slice(slice_ms, int(n_lines.max()))
 
     sphere_cnn = d["sphere"]
     image_ids = torch.arange(rank * count, (rank + 1) * count, dtype=torch.int64, device=rt.tdev)
     alive = []                                           # sliced mode: a step's buffers live until the flush
 
     def step_sliced(k):
-        with rt.on_stream():
+        with rt_cnn.on_stream():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
             resp = net.forward_device(sphere_cnn)        # B x 20 x 20 fp32
             e[1].record()
+        with rt.on_stream():
+            if rt is not rt_cnn:
+                rt.stream.wait_event(e[1])               # EM(k) needs CNN(k)
             l_buf = l_pristine.clone()                   # parked images keep reading their step's inputs
             e[2].record()
             out = gem.em_batch_device(rt, d["offsets"], l_buf, d["lp"], resp.reshape(-1, 400), d["sphere"],
@@ -358,7 +369,7 @@ def main():
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step,
         # each EM stream one batch every n_lanes steps
-        roof = roof_em if (em_ms / n_lanes >= cnn_ms or args.workload == "stress") else roof_cnn
+        roof = roof_em if (em_ms / n_lanes >= cnn_ms * 1.5 or args.workload == "stress") else roof_cnn
         roof["frac"] = roof["achieved"] / roof["peak"]
         line = {
             "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU" if args.workload == "yud"
@@ -374,9 +385,11 @@ def main():
                                    % count if args.workload == "yud" else
                                    "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
                        "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
-            "stage_ms": ({"cnn": cnn_ms, "em_slice": em_ms, "em_mode": "slice", "em_slice_budget_ms": args.em_slice_ms,
-                          "note": "one stream: CNN(k), then one time-sliced EM launch on all CUs; images unfinished at the end "
-                                  "of a launch are parked and resumed by the next one, the last step is followed by a flush"}
+            "stage_ms": ({"cnn": cnn_ms, "em_slice": em_ms, "em_mode": args.em_mode, "em_slice_budget_ms": slice_ms,
+                          "em_workgroups": em_wgs,
+                          "note": "time-sliced EM launches: images unfinished at the end of a launch are parked and resumed by "
+                                  "the next one, the last step is followed by a flush; slice = CNN stream + one EM stream, "
+                                  "serial = one stream"}
                          if sliced else
                          {"cnn": cnn_ms, "em": em_ms, "em_mode": "lanes", "em_lanes": n_lanes, "em_workgroups": em_wgs,
                           "em_cus_per_xcd": em_cus,

@@ -192,6 +192,10 @@ int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const dou
 /* calc_new_vanishing_point (:453-479) for every row of w [m][n]: vp_out m x 3, valid_out m. */
 int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, double* vp_out,
               int32_t* valid_out);
+/* calc_vp_line_counts (:482-512, thresh = 1.96^2 at :248,:419): v m x 3, s m, w [m][n] (the decision metric),
+ * lweight n -> counts_out m, counts_w_out m, assoc_out n int64 (-1 = outlier). */
+int vpk_line_counts(vpk_handle* h, int n, int m, const double* lp, const double* v, const double* s, const double* w,
+                    const double* lweight, double thresh, double* counts_out, double* counts_w_out, int64_t* assoc_out);
 /* the clustering inside split_best_vp (:568-578): ldist n x n -> labels n (0/1), flags 1. */
 int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out,
                  uint32_t* flags_out);

@@ -502,10 +502,15 @@ class _EM(object):
                     self.s[k] = np.exp(np.log(np.sum(0.5 * (p.lvsq[:, j] + p.lvsq[:, k]) * pv))
                                        - np.log(np.sum(pv)))          # :663-666, written before the abort test
                 if new is None or self.s[k] > max_stdd:
+                    if self.trace is not None:
+                        self.trace["merge_aborts"] = self.trace.get("merge_aborts", 0) + 1
                     again = False
                     continue
                 x[k, :] = new
                 self.delete([j])
+                if self.trace is not None:
+                    key = "final_merges" if thresh > 5e-3 else "periodic_merges"
+                    self.trace[key] = self.trace.get(key, 0) + 1
             else:
                 again = False
 

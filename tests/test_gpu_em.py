@@ -59,6 +59,10 @@ def test_kernels_against_reference_intermediates(name):
         if sv[1] >= 1e-3:
             assert abserr(vp[m], g["i_mstep0"][m]) <= 1e-9
     assert sum(g["i_counts0"] >= 3) >= 1
+    # calc_vp_line_counts (E14) on its own, on the reference's decision metric: counts and assignments exact
+    counts, counts_w, assoc = kernels.line_counts(g["lp"], g["i_v0"], s, g["i_w0"], g["i_lweight"])
+    assert np.array_equal(assoc, g["i_assoc0"])
+    assert np.array_equal(counts, g["i_counts0"])
 
 
 def test_cluster2_matches_sklearn():
@@ -79,8 +83,24 @@ def test_cluster2_matches_sklearn():
             warnings.simplefilter("ignore")
             model.fit_predict(ld)
         labels, flags = kernels.cluster2(ld)
-        if flags == 0:
-            assert np.array_equal(labels, model.labels_)
+        assert flags == 0          # random angles: no two candidate merges are exactly tied
+        assert np.array_equal(labels, model.labels_)
+
+
+def test_cluster2_flags_exact_tie():
+    """Four directions twice over: the first merge candidates are exactly tied and sklearn's choice depends on
+    Python heap order -> VPK_EM_FLAG_SPLIT_TIE (both the one-wave LDS version and the workgroup version)."""
+    from oracle import em_numpy as em
+    from vanishing_points_2017_amd import kernels
+    for reps in (2, 40):           # 8 lines (LDS path), 160 lines (workgroup path)
+        ang = np.tile(np.array([0.0, 0.5, 0.25, 0.75]) * np.pi, reps)
+        n = ang.shape[0]
+        lp = np.stack([np.cos(ang), np.sin(ang), np.zeros(n), np.zeros(n)], 1)
+        rows = np.repeat(np.arange(n), n).reshape(n, n)
+        ld = 1 - em.pair_cosangle(lp, 2, rows, rows.T)
+        np.fill_diagonal(ld, 0)
+        _, flags = kernels.cluster2(ld)
+        assert flags & 1
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -28,7 +28,8 @@ def test_sliced_batches_equal_uninterrupted_batches(slice_ms, wgs):
     assert ref["iterations"].max() == 99                  # the straggler is in the batch
     rt.handle.em_set_time_slice(slice_ms, int(np.diff(d["offsets"]).max()))
     keep = []
-    for step in range(4):                                 # four calls in flight before the flush
+    for step in range(6):                                 # six calls in flight before the flush (24 workgroups: overload,
+                                                          # images wait unstarted across launches)
         lb = l0.clone()
         keep.append((lb, gem.em_batch_device(rt, d["offsets"], lb, d["lp"], d["cnn"], d["sphere"], None, p)))
     with rt.on_stream():
@@ -44,8 +45,9 @@ def test_sliced_batches_equal_uninterrupted_batches(slice_ms, wgs):
                 assert np.array_equal(got[k][b, :m], ref[k][b, :m]), (k, b)
         assert torch.equal(lb, keep[0][0])
     rt.handle.em_set_time_slice(0.0)
-    again = _host(gem.em_batch_device(rt, d["offsets"], l0.clone(), d["lp"], d["cnn"], d["sphere"], None, p))
+    again = gem.em_batch_device(rt, d["offsets"], l0.clone(), d["lp"], d["cnn"], d["sphere"], None, p)
     rt.synchronize()
+    again = _host(again)
     assert np.array_equal(again["vp_assoc"], ref["vp_assoc"])
 
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_last_layer_ms",
     "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
-    "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_cluster2", "vpk_horizon_batch",
+    "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_line_counts", "vpk_cluster2", "vpk_horizon_batch",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
                                       ctypes.c_double, c_void]
     lib.vpk_mstep.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]
     lib.vpk_cluster2.argtypes = [c_void, ctypes.c_int, c_void, c_void, c_void]
+    lib.vpk_line_counts.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, c_void,
+                                    ctypes.c_double, c_void, c_void, c_void]
     lib.vpk_cnn_load.argtypes = [c_void, ctypes.POINTER(c_void), c_void]
     lib.vpk_cnn_forward.argtypes = [c_void, c_void, ctypes.c_int, c_void]
     lib.vpk_cnn_forward_tap.argtypes = [c_void, c_void, ctypes.c_int, c_void, ctypes.c_int, c_void]

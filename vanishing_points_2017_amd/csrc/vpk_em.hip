@@ -72,13 +72,21 @@ struct EmCarry {
     int iter;     // -1: not started; >= 0: resume at the top of this iteration (state in the slot)
     int slot;     // -1: none yet
 };
+// Two lists per launch: images that have been STARTED (they own a slot) and images that have not.  A launch
+// drains the started list before it touches anything else, which bounds the slots in use: every started entry
+// is taken by a workgroup right at the beginning of the launch, so before the deadline each workgroup holds
+// exactly one image, a new image starts only on a free workgroup, and after the deadline nothing starts --
+// at most one started image per workgroup is ever parked (S_k <= workgroups for every launch k, by induction),
+// and a free workgroup always finds a free slot among 2 x workgroups + 8.
 struct EmSliceArgs {
     int enabled;
     long long budget_ticks;   // 0 = no deadline (flush): everything runs to completion
-    int* ctr;                 // [0] consumed entries of `in`, [1] entries in `in`, [2] entries appended to `out`
-    EmCarry* in;
-    EmCarry* out;
-    int cap;                  // capacity of `out`
+    int* ctr;                 // started: [0] consumed, [1] count of `in`, [2] appended to `out`; unstarted: [3], [4], [5]
+    EmCarry* in_started;
+    EmCarry* out_started;
+    EmCarry* in_waiting;
+    EmCarry* out_waiting;
+    int cap_started, cap_waiting;
     int* busy;                // slot flags
     int nslots;
 };
@@ -101,10 +109,26 @@ VPK_DEV int acquire_slot(const EmSliceArgs& ss) {
     return slot;
 }
 
+// pop the next entry of a parked list (workgroup-uniform result; -1 = exhausted)
+VPK_DEV int pop_entry(int* head, const int* count) {
+    Shared& sh = SH();
+    if (tid() == 0) {
+        int e = -1;
+        const int n = *count;
+        if (n > 0) { e = atomicAdd(head, 1); if (e >= n) e = -1; }
+        sh.ibuf[7] = e;
+    }
+    block_sync();
+    const int e = sh.ibuf[7];
+    block_sync();
+    return e;
+}
+
 __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSliceArgs ss) {
     VPK_SHARED_DECL;
     const long long t_start = clock_ticks();
     const long long deadline = (ss.enabled && ss.budget_ticks > 0) ? t_start + ss.budget_ticks : EM_NO_DEADLINE;
+    bool started_left = ss.enabled != 0, waiting_left = ss.enabled != 0;
     for (;;) {
         EmCtx c;
         EmOut o;
@@ -113,23 +137,28 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
         sl.start_iter = -1;
         int slot = -1;
         bool have = false;
-        // 1. images parked by the previous launch
-        if (ss.enabled) {
-            if (tid() == 0) {
-                int e = -1;
-                if (ss.ctr[0] < ss.ctr[1]) { e = atomicAdd(&ss.ctr[0], 1); if (e >= ss.ctr[1]) e = -1; }
-                sh.ibuf[7] = e;
-            }
-            block_sync();
-            const int e = sh.ibuf[7];
-            block_sync();
+        // 1. images suspended by the previous launch (they own their slots), 2. images it could not start
+        if (started_left) {
+            const int e = pop_entry(&ss.ctr[0], &ss.ctr[1]);
             if (e >= 0) {
-                const EmCarry& k = ss.in[e];
+                const EmCarry& k = ss.in_started[e];
                 c = k.c; o = k.o; sl.start_iter = k.iter; slot = k.slot;
                 have = true;
+            } else {
+                started_left = false;
             }
         }
-        // 2. fresh images of this call
+        if (!have && waiting_left) {
+            const int e = pop_entry(&ss.ctr[3], &ss.ctr[4]);
+            if (e >= 0) {
+                const EmCarry& k = ss.in_waiting[e];
+                c = k.c; o = k.o;
+                have = true;
+            } else {
+                waiting_left = false;
+            }
+        }
+        // 3. fresh images of this call
         if (!have) {
             if (tid() == 0) sh.ibuf[7] = atomicAdd(a.queue, 1);
             block_sync();
@@ -161,26 +190,40 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
             o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
             o.trace = a.trace_out ? a.trace_out + (size_t)img * (a.prm.num_iter + 1) * TRACE_COLS : nullptr;
         }
-        int result = EM_SUSPENDED;
-        // an image that has not been started when the deadline has passed is parked as it is -- unless the
-        // list is full: then it runs now (a longer launch, never a lost image)
+        // An image that has not been started when the deadline has passed is parked as it is -- unless its
+        // list is full: then it runs now (a longer launch, never a lost image).
         bool park_unstarted = false;
-        if (ss.enabled && sl.start_iter < 0 && slot < 0 && deadline != EM_NO_DEADLINE) {
-            if (tid() == 0) sh.ibuf[7] = (clock_ticks() >= deadline) && (ss.ctr[2] < ss.cap - nblocks());
+        if (ss.enabled && slot < 0 && deadline != EM_NO_DEADLINE) {
+            if (tid() == 0) {
+                int e = -1;
+                if (clock_ticks() >= deadline) {
+                    e = atomicAdd(&ss.ctr[5], 1);
+                    if (e >= ss.cap_waiting) e = -1;
+                }
+                sh.ibuf[7] = e;
+            }
             block_sync();
-            park_unstarted = sh.ibuf[7] != 0;
+            const int e = sh.ibuf[7];
             block_sync();
+            if (e >= 0) {
+                if (tid() == 0) {
+                    EmCarry& k = ss.out_waiting[e];
+                    k.c = c; k.o = o; k.iter = -1; k.slot = -1;
+                }
+                park_unstarted = true;
+            }
         }
-        if (!park_unstarted) {
-            if (slot < 0) slot = ss.enabled ? acquire_slot(ss) : block_id();
-            if (sl.start_iter < 0) bind_scratch(c, a.scratch + (size_t)slot * a.L.total_doubles, a.L, c.prm.do_split != 0);
-            result = em_run(c, o, sl);
+        if (park_unstarted) continue;
+        if (slot < 0) {
+            slot = ss.enabled ? acquire_slot(ss) : block_id();
+            bind_scratch(c, a.scratch + (size_t)slot * a.L.total_doubles, a.L, c.prm.do_split != 0);
         }
-        if (result == EM_SUSPENDED) {          // only in session mode
+        const int result = em_run(c, o, sl);
+        if (result == EM_SUSPENDED) {          // only with a deadline; at most one per workgroup and launch (see above)
             if (tid() == 0) {
                 const int e = atomicAdd(&ss.ctr[2], 1);
-                EmCarry& k = ss.out[e];
-                k.c = c; k.o = o; k.iter = park_unstarted ? -1 : sl.start_iter; k.slot = slot;
+                EmCarry& k = ss.out_started[e];
+                k.c = c; k.o = o; k.iter = sl.start_iter; k.slot = slot;
             }
             block_sync();
         } else if (ss.enabled) {
@@ -191,10 +234,13 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
 }
 
 // between two time-sliced launches: what the last launch parked becomes the next launch's input list
-__global__ void em_rotate_kernel(int* ctr) {
+__global__ void em_rotate_kernel(int* ctr, int cap_waiting) {
     ctr[1] = ctr[2];
     ctr[0] = 0;
     ctr[2] = 0;
+    ctr[4] = ctr[5] < cap_waiting ? ctr[5] : cap_waiting;   // the counter keeps counting when the list is full
+    ctr[3] = 0;
+    ctr[5] = 0;
 }
 
 // ---- fine-grained kernels (one workgroup, unit parity) ------------------------------------------
@@ -315,6 +361,33 @@ __global__ __launch_bounds__(EM_BOUND) void mstep_kernel(int n, int m, const dou
     }
 }
 
+// calc_vp_line_counts (vp_localisation.py:482-512) on its own: argmax VP per line, the outlier test against
+// calc_lvsq_single of that VP (:504) and lweight == 0 (:506), counts and weighted counts per VP.
+__global__ __launch_bounds__(EM_BOUND) void line_counts_kernel(int n, int m, const double* lp, const double* v,
+                                                                 const double* s, const double* w, const double* lweight,
+                                                                 double thresh, EmLayout L, double* ws, double* counts_out,
+                                                                 double* counts_w_out, long long* assoc_out) {
+    VPK_SHARED_DECL;
+    EmCtx c;
+    c.N = n; c.lp = (cgdp)lp; c.wt_doubles = WT_DOUBLES;
+    c.prm.use_weights = 1;
+    c.prm.outlier_thresh = thresh;
+    bind_scratch(c, ws, L, false);
+    for (int k = tid(); k < n; k += nthreads()) c.lweight[k] = lweight[k];
+    for (int k = tid(); k < 3 * m; k += nthreads()) sh.cur[k] = v[k];
+    for (int k = tid(); k < m; k += nthreads()) sh.s[k] = s[k];
+    if (tid() == 0) { sh.M = m; sh.ncomp = 0; sh.sigma_prior = 1.0; }     // no prior: only lvsq is wanted from the E-step
+    block_sync();
+    line_geometry_setup(c);
+    estep(c, sh.cur);                                                     // lvsq[m][n] (probability_functions.py:157-176)
+    for (int p = tid(); p < m * n; p += nthreads()) c.w[(size_t)(p / n) * c.ldn + p % n] = w[p];
+    block_sync();
+    assign_lines(c, true);
+    count_lines(c);
+    for (int k = tid(); k < m; k += nthreads()) { counts_out[k] = sh.cnt[k]; counts_w_out[k] = sh.cntw[k]; }
+    for (int k = tid(); k < n; k += nthreads()) assoc_out[k] = c.assoc[k];
+}
+
 __global__ __launch_bounds__(EM_BOUND) void cluster2_kernel(int n, double* D, int* member, int* csize,
                                                               int* labels_out, unsigned* flags_out) {
     VPK_SHARED_DECL;
@@ -356,6 +429,7 @@ int em_prepare(vpk_handle* h) {
     if ((rc = allow_lds(h, weight_matrix_kernel))) return rc;
     if ((rc = allow_lds(h, mstep_kernel))) return rc;
     if ((rc = allow_lds(h, cluster2_kernel))) return rc;
+    if ((rc = allow_lds(h, line_counts_kernel))) return rc;
     h->em_ready = true;
     return VPK_OK;
 }
@@ -385,36 +459,53 @@ int check_params(vpk_handle* h, const vpk_em_params* p, int n_init, bool has_ini
     return VPK_OK;
 }
 
-constexpr int EM_CARRY_CAP = 4096;     // parked images per list (a full list makes further images run on instead)
+constexpr int EM_WAIT_CAP = 8192;       // images parked before they were started (a full list makes further ones run on)
+constexpr int EM_STARTED_CAP = 1024;    // suspended images: at most one per workgroup (vpk_em_set_workgroups <= CUs)
 constexpr size_t EM_SESS_HEAD = 256;    // counters
 
-struct SessView { int* ctr; int* busy; EmCarry* list[2]; };
+struct SessView { int* ctr; int* busy; EmCarry* started[2]; EmCarry* waiting[2]; };
 SessView sess_view(vpk_handle* h) {
     char* base = (char*)h->em_sess;
     SessView v;
     v.ctr = (int*)base;
     v.busy = (int*)(base + EM_SESS_HEAD);
-    char* lists = base + EM_SESS_HEAD + em_align((size_t)h->em_sess_slots * 4, 256);
-    v.list[0] = (EmCarry*)lists;
-    v.list[1] = (EmCarry*)(lists + em_align(sizeof(EmCarry) * EM_CARRY_CAP, 256));
+    char* p = base + EM_SESS_HEAD + em_align((size_t)h->em_sess_slots * 4, 256);
+    const size_t sb = em_align(sizeof(EmCarry) * EM_STARTED_CAP, 256), wb = em_align(sizeof(EmCarry) * EM_WAIT_CAP, 256);
+    v.started[0] = (EmCarry*)p; v.started[1] = (EmCarry*)(p + sb);
+    v.waiting[0] = (EmCarry*)(p + 2 * sb); v.waiting[1] = (EmCarry*)(p + 2 * sb + wb);
     return v;
+}
+size_t sess_bytes(int slots) {
+    return EM_SESS_HEAD + em_align((size_t)slots * 4, 256) + 2 * em_align(sizeof(EmCarry) * EM_STARTED_CAP, 256) +
+           2 * em_align(sizeof(EmCarry) * EM_WAIT_CAP, 256);
+}
+// the previous launch's output lists become this launch's input lists
+EmSliceArgs sess_next(vpk_handle* h, double slice_ms) {
+    SessView v = sess_view(h);
+    hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr, EM_WAIT_CAP);
+    h->em_sess_in ^= 1;
+    EmSliceArgs ss;
+    ss.enabled = 1;
+    ss.budget_ticks = slice_ms > 0 ? (long long)(slice_ms * 1e-3 / (CLOCK_US * 1e-6)) : 0;
+    if (slice_ms > 0 && ss.budget_ticks < 1) ss.budget_ticks = 1;
+    ss.ctr = v.ctr;
+    ss.in_started = v.started[h->em_sess_in]; ss.out_started = v.started[h->em_sess_in ^ 1];
+    ss.in_waiting = v.waiting[h->em_sess_in]; ss.out_waiting = v.waiting[h->em_sess_in ^ 1];
+    ss.cap_started = EM_STARTED_CAP; ss.cap_waiting = EM_WAIT_CAP;
+    ss.busy = v.busy; ss.nslots = h->em_sess_slots;
+    return ss;
 }
 
 // launch that finishes every parked image (no deadline, no fresh images); asynchronous on the handle's stream
 int em_flush(vpk_handle* h) {
     if (!h->em_unflushed) return VPK_OK;
-    SessView v = sess_view(h);
-    hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr);
-    h->em_sess_in ^= 1;
+    EmSliceArgs ss = sess_next(h, 0.0);
     EmBatchArgs a = {};
     a.B = 0;
-    a.queue = v.ctr + 8;                       // a counter that is never below B = 0
+    a.queue = ss.ctr + 8;                      // a counter that is never below B = 0
     a.L = h->em_sess_layout;
     a.scratch = (double*)h->em_ws;
     a.wt_doubles = h->em_sess_wt_doubles;
-    EmSliceArgs ss;
-    ss.enabled = 1; ss.budget_ticks = 0; ss.ctr = v.ctr; ss.in = v.list[h->em_sess_in]; ss.out = v.list[h->em_sess_in ^ 1];
-    ss.cap = EM_CARRY_CAP; ss.busy = v.busy; ss.nslots = h->em_sess_slots;
     hipLaunchKernelGGL(em_batch_kernel, dim3(h->em_sess_wgs), dim3(EM_THREADS), h->em_sess_lds, h->stream, a, ss);
     VPK_HIP(h, hipGetLastError());
     h->em_unflushed = false;
@@ -480,6 +571,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
         // follow the batch; slots outlive the launch: running (<= wgs) + parked and not yet resumed (<= wgs)
         wgs = h->cu_share * mode.per_cu;
         if (h->em_max_workgroups > 0 && wgs > h->em_max_workgroups) wgs = h->em_max_workgroups;
+        if (wgs > EM_STARTED_CAP) wgs = EM_STARTED_CAP;
         slots = 2 * wgs + 8;
         if ((size_t)slots * slot_bytes > h->total_mem / 2)
             return vpk_fail(h, VPK_ERR_LIMIT, "vpk_em_batch: time-sliced slots exceed half of the device memory");
@@ -489,7 +581,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
             if (h->em_unflushed)
                 return vpk_fail(h, VPK_ERR_STATE, "vpk_em_batch: the slot layout changed (more lines than "
                                 "vpk_em_set_time_slice was told, or other parameters) while images are parked: vpk_em_flush first");
-            const size_t need = EM_SESS_HEAD + em_align((size_t)slots * 4, 256) + 2 * em_align(sizeof(EmCarry) * EM_CARRY_CAP, 256);
+            const size_t need = sess_bytes(slots);
             rc = vpk_reserve(h, &h->em_sess, &h->em_sess_bytes, need, "hipMalloc(EM session)");
             if (rc) return rc;
             VPK_HIP(h, hipMemsetAsync(h->em_sess, 0, need, h->stream));
@@ -550,14 +642,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.wt_doubles = mode.wt_doubles;
     EmSliceArgs ss = {};
     if (sliced) {
-        SessView v = sess_view(h);
-        hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr);   // last launch's parked list -> input
-        h->em_sess_in ^= 1;
-        ss.enabled = 1;
-        ss.budget_ticks = (long long)(h->em_slice_ms * 1e-3 / (CLOCK_US * 1e-6));
-        if (ss.budget_ticks < 1) ss.budget_ticks = 1;
-        ss.ctr = v.ctr; ss.in = v.list[h->em_sess_in]; ss.out = v.list[h->em_sess_in ^ 1];
-        ss.cap = EM_CARRY_CAP; ss.busy = v.busy; ss.nslots = slots;
+        ss = sess_next(h, h->em_slice_ms);
         h->em_unflushed = true;
     }
     hipLaunchKernelGGL(em_batch_kernel, dim3(wgs), dim3(EM_THREADS), mode.lds_bytes, h->stream, a, ss);
@@ -648,6 +733,21 @@ int vpk_mstep(vpk_handle* h, int n, int m, const double* l, const double* w, dou
     if (rc) return rc;
     hipLaunchKernelGGL(mstep_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, l, w, L, (double*)h->small_ws,
                        vp_out, valid_out);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_line_counts(vpk_handle* h, int n, int m, const double* lp, const double* v, const double* s, const double* w,
+                    const double* lweight, double thresh, double* counts_out, double* counts_w_out, int64_t* assoc_out) {
+    if (!h || n < 1 || m < 1 || m > MAXM || !lp || !v || !s || !w || !lweight || !counts_out || !counts_w_out || !assoc_out)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_line_counts: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    { int rc0 = em_prepare(h); if (rc0) return rc0; }
+    EmLayout L = small_layout(n, m);
+    int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(line_counts_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, lp, v, s, w, lweight,
+                       thresh, L, (double*)h->small_ws, counts_out, counts_w_out, (long long*)assoc_out);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }

@@ -92,6 +92,23 @@ def mstep(l, w, device=0):
     return vp.cpu().numpy(), valid.cpu().numpy()
 
 
+def line_counts(lp, v, s, w, lweight, thresh=1.96 ** 2, device=0):
+    """calc_vp_line_counts (vp_localisation.py:482-512): returns (counts, counts_weighted, assoc)."""
+    rt = get_runtime(device)
+    t = rt.torch
+    m, n = w.shape
+    with rt.on_stream():
+        d_lp, d_v, d_s = _up(rt, lp, np.float64), _up(rt, v, np.float64), _up(rt, s, np.float64)
+        d_w, d_lw = _up(rt, w, np.float64), _up(rt, lweight, np.float64)
+        counts = t.empty((m,), dtype=t.float64, device=rt.tdev)
+        counts_w = t.empty((m,), dtype=t.float64, device=rt.tdev)
+        assoc = t.empty((n,), dtype=t.int64, device=rt.tdev)
+        rt.check(rt.lib.vpk_line_counts(rt.h, n, m, rt.ptr(d_lp), rt.ptr(d_v), rt.ptr(d_s), rt.ptr(d_w), rt.ptr(d_lw),
+                                        float(thresh), rt.ptr(counts), rt.ptr(counts_w), rt.ptr(assoc)))
+    rt.synchronize()
+    return counts.cpu().numpy(), counts_w.cpu().numpy(), assoc.cpu().numpy()
+
+
 def cluster2(ldist, device=0):
     """The 2-cluster average-linkage agglomeration of split_best_vp (vp_localisation.py:568-578)."""
     rt = get_runtime(device)
