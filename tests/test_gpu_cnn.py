@@ -43,3 +43,22 @@ def test_batch_invariance_and_single_image_call(net_and_ref):
     assert np.abs(one - full[1]).max() <= 1e-6        # batch composition does not change a result
     big = net.forward(np.concatenate([sphere] * 5)[:13])
     assert np.array_equal(big[:3], full)              # deterministic: same bits for the same image
+
+
+@pytest.mark.parametrize("batch", [13, 102])
+def test_bench_batch_against_the_oracle(batch):
+    """B = 102 is bench.py's batch (other tile tails than B = 3, the persistent tile queue goes round more than
+    once, split-K partials of the dense layers span 102 rows); B = 13 an odd size.  The rasters are bench.py's own."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=batch)])
+    ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
+    net = cnn.Net(w, mean)
+    for tap in (1, 2, 7, 8):                               # pool1, conv2, pool5, fc6
+        out, got = net.forward(sphere, tap=tap)
+        want = taps[cnn_torch.TAPS[tap]].reshape(got.shape)
+        assert np.abs(got - want).max() <= 2e-4 * (1.0 + np.abs(want).max()), cnn_torch.TAPS[tap]
+        assert np.abs(out - ref).max() <= 2e-5
+    assert np.abs(ref - 0.5).max() > 1e-3                  # the response maps are not a constant
