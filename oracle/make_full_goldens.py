@@ -41,8 +41,9 @@ from vanishing_points_2017_amd.parity import input_sha  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def instrument(mods, ev):
-    """Count control-flow events inside the reference (in-memory wrappers)."""
+def instrument(mods, ev, merge_thresh=1e-3):
+    """Count control-flow events inside the reference (in-memory wrappers).  merge_thresh: the keyword the run
+    uses (the final merge is called with ten times that, vp_localisation.py:190)."""
     vpl = mods["vp_localisation"]
     prob = mods["probability_functions"]
     orig_merge, orig_split, orig_prob = vpl.merge_vps, vpl.split_best_vp, prob.calc_probabilities
@@ -61,7 +62,8 @@ def instrument(mods, ev):
         finally:
             state["in_merge"] = False
         merged = mb - out["v"].shape[1]
-        final = thresh > 5e-3
+        mt = merge_thresh[0] if isinstance(merge_thresh, list) else merge_thresh   # a list: read at call time
+        final = thresh > 5 * mt
         ev["final_merge" if final else "merge"] += merged
         ev["abort"] += state["esteps"] - merged        # an E-step inside merge_vps that removed no VP (:668-670)
         return out

@@ -25,6 +25,8 @@ from ref_shim import load_reference  # noqa: E402
 from vanishing_points_2017_amd import synth  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+EVENTS = {"split": 0, "merge": 0, "abort": 0, "final_merge": 0}      # filled by the wrappers of make_full_goldens.instrument
+EVENTS_THRESH = [1e-3]
 
 # name: dict(seed, n, vps, outlier_frac, em kwargs, stress?)
 CASES = {
@@ -46,6 +48,11 @@ CASES = {
     # line in the hard-assignment M-step, so LAPACK's 1 x 3 null vector decides (:353-392)
     "hard1row_n387": dict(inputs="hard1row_n387"),
     "hard1row_n289": dict(inputs="hard1row_n289"),
+    # control flow the default parameters rarely reach (searched with the CPU restatement's event trace):
+    # a wider merge threshold makes merge_vps (:633-684) fire at i = 10 next to a split, merge several pairs in
+    # the finalisation and ABORT on a pair whose pooled variance exceeds 0.01 (:666-670, s[k] written first)
+    "periodicmerge_n220": dict(seed=2208, n=220, vps=6, em=dict(merge_thresh=0.12)),
+    "mergeabort_n200": dict(seed=2102, n=200, vps=6, em=dict(merge_thresh=0.07)),
 }
 FULL_INTERMEDIATES_MAX_N = 260
 
@@ -83,6 +90,13 @@ def run_case(name, spec, mods):
         kwargs["init_vp"] = init_vp
     for k, v in spec.get("em", {}).items():
         out["kw_" + k] = np.array(v)
+    ev = {"split": 0, "merge": 0, "abort": 0, "final_merge": 0}
+    if not getattr(vpl, "_vpk_instrumented", False):
+        from make_full_goldens import instrument
+        instrument(mods, EVENTS, EVENTS_THRESH)
+        vpl._vpk_instrumented = True
+    EVENTS.update(ev)
+    EVENTS_THRESH[0] = kwargs.get("merge_thresh", 1e-3)
 
     with joblib.parallel_backend("multiprocessing"):
         # --- intermediates, by calling the reference's own functions ---------------------------
@@ -123,6 +137,7 @@ def run_case(name, spec, mods):
         res = vpl.expectation_maximisation(l, lp.copy(), cnn.copy(), sphere_image=sphere, **kwargs)
         dt = time.time() - t0
     out["ref_seconds"] = np.array(dt)
+    out["o_events"] = np.array([EVENTS[k] for k in ("split", "merge", "abort", "final_merge")])
     out["l_normalised"] = l
     if res["vp"] is None:
         out["o_status"] = np.array(1)
