@@ -120,7 +120,7 @@ def test_goldens_reach_the_rare_control_flow():
     a successful PERIODIC merge (vp_localisation.py:444-448), several final merges and a merge ABORT
     (:666-670, s[k] written before the test) in these two cases -- so every test that checks them against the
     reference (oracle here, device source in test_hostsim_em.py, HIP in test_gpu_em.py) covers those paths."""
-    a = load("periodicmerge_n220")["o_events"]      # split, periodic merge, abort, final merge
-    b = load("mergeabort_n200")["o_events"]
+    a = _load("periodicmerge_n220")["o_events"]      # split, periodic merge, abort, final merge
+    b = _load("mergeabort_n200")["o_events"]
     assert a[1] >= 1 and a[2] >= 1 and a[3] >= 1
     assert b[2] >= 1 and b[3] >= 3
