@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
-    ap.add_argument("--em-mode", default="slice", choices=["slice", "serial", "lanes"],
+    ap.add_argument("--em-mode", default="lanes", choices=["lanes", "slice", "serial"],
                     help="slice: one CNN stream + one EM stream whose launches are time-sliced (vpk_em_set_time_slice): a launch "
                          "holds --em-wgs CUs for at most --em-slice-ms, images unfinished by then are parked and resumed by the "
                          "next launch, so no launch waits for a 99-iteration straggler; serial: ONE stream, CNN(k) then a sliced EM "

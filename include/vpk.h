@@ -132,9 +132,14 @@ int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out)
 int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap,
                         float* tap_out);
 
+/* conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55) run as ONE kernel by default (the 96 x 123 x 123 conv1 blob is
+ * never written); on = 0 selects the separate conv1 and LRN/pool kernels (also used whenever tap 0 is requested). */
+int vpk_cnn_set_fusion(vpk_handle* h, int on);
+
 /* per-layer device time of the last vpk_cnn_forward (single chunk), from HIP events recorded on
  * the handle's stream between the layers: ms[13] = conv1, norm1, pool1, conv2, norm2, pool2, conv3,
- * conv4, conv5, pool5, fc6, fc7, fc8.  vpk_cnn_last_layer_ms waits for the pass to finish. */
+ * conv4, conv5, pool5, fc6, fc7, fc8 (with the fused first stage: conv1 = the whole fused kernel, norm1 = pool1 = 0).
+ * vpk_cnn_last_layer_ms waits for the pass to finish. */
 int vpk_cnn_set_profiling(vpk_handle* h, int on);
 int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
 

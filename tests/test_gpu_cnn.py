@@ -62,3 +62,18 @@ def test_bench_batch_against_the_oracle(batch):
         assert np.abs(got - want).max() <= 2e-4 * (1.0 + np.abs(want).max()), cnn_torch.TAPS[tap]
         assert np.abs(out - ref).max() <= 2e-5
     assert np.abs(ref - 0.5).max() > 1e-3                  # the response maps are not a constant
+
+
+def test_fused_first_stage_equals_separate_kernels(net_and_ref):
+    """conv1 + norm1 + pool1 as one kernel (2-D patches, LRN and pooling out of LDS) against the separate conv1 and
+    LRN/pool kernels: the same K order and the same LRN expression, so pool1 agrees to rounding -- including
+    the clipped windows at the right / bottom border (61 = 7 x 8 + 5 columns, 20 x 3 + 1 rows of patches)."""
+    net, sphere, ref, taps = net_and_ref
+    net.set_fusion(True)
+    out_f, pool_f = net.forward(sphere, tap=1)
+    net.set_fusion(False)
+    out_s, pool_s = net.forward(sphere, tap=1)
+    net.set_fusion(True)
+    # (the two kernels are separate compilations: the LRN's multiply-adds may be contracted differently)
+    assert np.abs(pool_f - pool_s).max() <= 1e-6 * (1 + np.abs(pool_s).max())
+    assert np.abs(out_f - out_s).max() <= 1e-6

@@ -80,6 +80,10 @@ class Net(object):
                   "conv4": 2 * 384 * 900 * 1728, "conv5": 2 * 256 * 900 * 1728, "fc6": 2 * 57600 * 4096,
                   "fc7": 2 * 4096 * 4096, "fc8": 2 * 4096 * 400}
 
+    def set_fusion(self, on=True):
+        """conv1 + norm1 + pool1 as one kernel (default) or as separate kernels."""
+        self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(bool(on))))
+
     def set_profiling(self, on=True):
         self.rt.check(self.rt.lib.vpk_cnn_set_profiling(self.rt.h, int(bool(on))))
 

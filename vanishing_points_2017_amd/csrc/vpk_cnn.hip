@@ -15,6 +15,7 @@
 // 0.6 GB at B = 102; 288 GB of HBM3E makes chunking unnecessary up to B ~ 4000).
 #include "vpk_internal.hpp"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -80,7 +81,18 @@ __device__ __forceinline__ void dma4(unsigned voff, const void* sbase, unsigned 
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE>
+// conv1 + norm1 + pool1 as ONE kernel (C1FUSE): a tile's 128 columns are a 2-D patch of 7 x 17 conv1 outputs
+// (all 96 channels: one M tile, so the LRN across channels is local to the tile); after the K loop the patch
+// goes to LDS (over the then idle stage buffers), is normalised in place and max-pooled to 3 x 8 outputs per
+// channel, and only those are written -- conv1's 0.59 GB output (B = 102) never exists.  Neighbouring patches
+// share one conv row / column (pooling windows overlap by one), i.e. 7/6 x 17/16 = 1.24x the MFMA work.
+constexpr int C1_PR = 7, C1_PC = 17;               // conv outputs per patch (rows x cols): 119 of the tile's 128 columns
+constexpr int C1_QR = 3, C1_QC = 8;                // pooled outputs per patch
+constexpr int C1_OUT = 123, C1_POOL = 61;          // conv1 / pool1 output size (deploy.prototxt:9-55)
+constexpr int C1_TR = (C1_POOL + C1_QR - 1) / C1_QR, C1_TC = (C1_POOL + C1_QC - 1) / C1_QC;   // 21 x 8 patches per image
+constexpr int C1_LD = 129;                         // row stride of the patch in LDS ([channel][column])
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE, bool C1FUSE = false>
 __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
@@ -90,9 +102,13 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(BN == 128, "the B-tile loader assumes 128 columns");
+    static_assert(!C1FUSE || (BM == 96 && TN == 1 && !DENSE), "the fused conv1 tile is 96 channels x 128 columns");
     constexpr int NST = 3;
-    __shared__ __attribute__((aligned(16))) float As[NST][BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[NST][BK][BN];
+    constexpr int STAGE_FLOATS = NST * BK * (BM + BN);
+    constexpr int LDS_FLOATS = C1FUSE ? (96 * C1_LD > STAGE_FLOATS ? 96 * C1_LD : STAGE_FLOATS) : STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
+    float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(lds_raw);
+    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(lds_raw + NST * BK * BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,7 +146,17 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
     n = n < d.N ? n : d.N - 1;                        // tail columns re-read the last valid one
     const float* bbase;                               // wave-uniform base of this tile's gather
     unsigned boff;                                    // this lane's byte offset from it
-    if (DENSE) {
+    if (C1FUSE) {
+        // tile = (image, patch row, patch column); column j of the tile = conv output (6 pr + j / 17, 16 pc + j % 17),
+        // clamped into the blob (overhanging positions only ever meet pooling windows that Caffe clips away)
+        const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
+        const int j = tid & 127;
+        int oh = (C1_PR - 1) * pr + j / C1_PC, ow = (C1_PC - 1) * pc + j % C1_PC;
+        oh = oh < C1_OUT ? oh : C1_OUT - 1;
+        ow = ow < C1_OUT ? ow : C1_OUT - 1;
+        bbase = in + (size_t)b * d.IC * d.Hp * d.Wp;
+        boff = (unsigned)(oh * d.Wp + ow) * 4u;
+    } else if (DENSE) {
         bbase = in;
         boff = (unsigned)n * (unsigned)d.K * 4u;
     } else {
@@ -232,6 +258,64 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
     // base (its column) plus 32-bit row offsets.  (Per-element vector bias loads were each followed by
     // s_waitcnt vmcnt(0), which also waits for the store just issued: 48-64 store round trips in series per
     // tile, more than half of conv1's tile time.)
+    if (C1FUSE) {
+        // ---- fused epilogue: bias + ReLU -> LDS patch -> LRN (in place) -> 3x3/2 max pool -> store ----
+        float (*Cs)[C1_LD] = reinterpret_cast<float (*)[C1_LD]>(lds_raw);    // [channel][column]; the stage buffers are idle now
+        const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m0 = __builtin_amdgcn_readfirstlane(i * 32 + 8 * q);
+                const float* bp = bias + m0;                        // wave-uniform: scalar load of 8 floats
+                float bl[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bl[e] = bp[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][0][4 * q + e] + (khalf ? bl[4 + e] : bl[e]);
+                    Cs[m0 + 4 * khalf + e][col] = v > 0.f ? v : 0.f;
+                }
+            }
+        __syncthreads();
+        {   // LRN across channels (deploy.prototxt:34-44): two threads per column, 48 channels each, 5-deep window
+            const int p = tid & 127, c0 = (tid >> 7) * 48;
+            float v0 = c0 >= 2 ? Cs[c0 - 2][p] : 0.f, v1 = c0 >= 1 ? Cs[c0 - 1][p] : 0.f;
+            float v2 = Cs[c0][p], v3 = Cs[c0 + 1][p];
+            const float e0 = c0 + 48 < 96 ? Cs[c0 + 48][p] : 0.f, e1 = c0 + 49 < 96 ? Cs[c0 + 49][p] : 0.f;
+            __syncthreads();                                        // every raw halo value has been read
+            const float an = 1e-4f / 5.f;
+#pragma unroll 8
+            for (int k = 0; k < 48; ++k) {
+                const float v4 = k + 2 < 48 ? Cs[c0 + k + 2][p] : (k + 2 == 48 ? e0 : e1);
+                const float sc = 1.f + an * (v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4);
+                const float r = rsqrtf(sc);
+                Cs[c0 + k][p] = v2 * (r * sqrtf(r));                // sc^-0.75
+                v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 96 * C1_QR * C1_QC; e += CONV_THREADS) {
+            const int k = e / (C1_QR * C1_QC), o = e - k * (C1_QR * C1_QC);
+            const int py = o / C1_QC, px = o - py * C1_QC;
+            const int ph = C1_QR * pr + py, pw = C1_QC * pc + px;
+            if (ph >= C1_POOL || pw >= C1_POOL) continue;
+            float m = -3.402823466e38f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int r = 2 * py + dy, q = 2 * px + dx;
+                    if ((C1_PR - 1) * pr + r < C1_OUT && (C1_PC - 1) * pc + q < C1_OUT) {   // Caffe clips the window
+                        const float v = Cs[k][r * C1_PC + q];
+                        m = v > m ? v : m;
+                    }
+                }
+            out[((size_t)b * 96 + k) * d.OHp * d.OWp + (size_t)(ph + d.opad) * d.OWp + pw + d.opad] = m;
+        }
+        __syncthreads();                                            // the next tile's DMA overwrites the patch
+    } else {
     const int oplane = d.OHp * d.OWp;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -273,6 +357,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
                 }
             }
         }
+    }
     }
     tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
     parity ^= 1;
@@ -449,6 +534,7 @@ struct vpk_cnn_state {
     size_t act_bytes = 0;
     int act_batch = 0;
     // optional per-layer timing (HIP events on the handle's stream)
+    bool fuse_conv1 = true;  // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion)
     bool profiling = false;
     hipEvent_t ev[14] = {};
     bool ev_ready = false;
@@ -585,14 +671,26 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
     hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
                        500 * 500);
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 1, ctr + 0);   // stride 1 over the phase planes
-    mark();
-    if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
-    // norm1 + pool1 (fused), written with conv2's border
-    hipLaunchKernelGGL((lrn5_pool3s2_tiled_kernel<7, 16>), dim3((unsigned)(batch * ((96 + LRN_CCH - 1) / LRN_CCH) * 9 * 4)),
-                       dim3(256), 0, st, R[R_CONV1], R[R_POOL1], 96, 123, 123, 61, 61, 1e-4f, 0.75f, 65, 65, 2);
-    mark();
-    mark();
+    if (tap == 0 || !S->fuse_conv1) {
+        launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 1, ctr + 0);   // stride 1 over the phase planes
+        mark();
+        if ((rc = tapcopy(0, R[R_CONV1], A_CONV1))) return rc;
+        // norm1 + pool1 (fused), written with conv2's border
+        hipLaunchKernelGGL((lrn5_pool3s2_tiled_kernel<7, 16>), dim3((unsigned)(batch * ((96 + LRN_CCH - 1) / LRN_CCH) * 9 * 4)),
+                           dim3(256), 0, st, R[R_CONV1], R[R_POOL1], 96, 123, 123, 61, 61, 1e-4f, 0.75f, 65, 65, 2);
+        mark();
+        mark();
+    } else {
+        // conv1 + relu1 + norm1 + pool1 in one kernel: 21 x 8 patches of 7 x 17 conv outputs per image, straight into
+        // pool1's planes (with conv2's border of 2); the conv1 blob only exists when a caller taps it
+        ConvDims df = dims(0);
+        df.N = batch * C1_TR * C1_TC * 128;               // one 128-column tile per patch
+        df.OHp = 65; df.OWp = 65; df.opad = 2;
+        launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false, true>, df, 96, R[R_IN], S->L[0], R[R_POOL1], 1, ctr + 0);
+        mark();
+        mark();
+        mark();
+    }
     tapunpad(1, R[R_POOL1], 96, 61, 61, 2);
     // conv2 + relu2
     launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, R[R_POOL1], S->L[1], R[R_CONV2], 1, ctr + 1);
@@ -653,6 +751,12 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
     }
     h->cnn->profiling = on != 0;
     h->cnn->ev_valid = false;
+    return VPK_OK;
+}
+
+int vpk_cnn_set_fusion(vpk_handle* h, int on) {
+    if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
+    h->cnn->fuse_conv1 = on != 0;
     return VPK_OK;
 }
 
