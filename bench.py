@@ -59,9 +59,6 @@ def parse():
     ap.add_argument("--em-wgs", type=int, default=-1,
                     help="workgroups (CUs) per EM launch; default: images/3 for yud (the launch lasts as long as its "
                          "slowest image either way, and the CNN keeps the other CUs), one per image for stress")
-    ap.add_argument("--em-cus", type=int, default=-1,
-                    help="CU slots per XCD reserved for the EM streams (the CNN stream gets the other 32 - k); "
-                         "0 = no partition (default: measured r1, a partition only moves the CUs the EM would take anyway)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,7 +207,7 @@ def main():
         #   slice : CNN stream + ONE EM stream; an EM launch holds at most em_wgs CUs for at most the budget, its
         #           workgroups leave as soon as no image is waiting, and the CNN's kernels take every other CU
         #   serial: one stream, CNN(k) on all CUs, then an EM launch on all CUs
-        n_lanes, em_cus = 1, 0
+        n_lanes = 1
         serial = args.em_mode == "serial"
         em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else 64)
         slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 8.0)
@@ -224,11 +221,10 @@ def main():
         # image: 102 of 256 CUs, and a tail of a few images still iterating) overlaps the CNN of step k+1 and
         # the EM of steps k+1, k+2.  All K steps complete inside the timed region.
         n_lanes = max(1, args.em_lanes)
-        em_cus = max(0, args.em_cus)
-        lanes = [get_runtime(local_rank, "em%d" % i, cu_range=(0, em_cus) if em_cus else None) for i in range(n_lanes)]
+        lanes = [get_runtime(local_rank, "em%d" % i) for i in range(n_lanes)]
         rt = lanes[0]
-        rt_cnn = get_runtime(local_rank, "cnn", cu_range=(em_cus, 32 - em_cus) if em_cus else None)
-        em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if (args.workload == "yud" and not em_cus) else 0)
+        rt_cnn = get_runtime(local_rank, "cnn")
+        em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if args.workload == "yud" else 0)
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)
     scenes, kw = make_workload(args.workload, rank, count)
@@ -392,7 +388,6 @@ def main():
                                   "serial = one stream"}
                          if sliced else
                          {"cnn": cnn_ms, "em": em_ms, "em_mode": "lanes", "em_lanes": n_lanes, "em_workgroups": em_wgs,
-                          "em_cus_per_xcd": em_cus,
                           "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"}),
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),

@@ -78,13 +78,7 @@ int vpk_create(int device, vpk_handle** out);
 int vpk_destroy(vpk_handle* h);
 /* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int vpk_set_stream(vpk_handle* h, void* hip_stream);
-/* Give the handle its own stream restricted to a share of the CUs: slots [first, first + count) of EVERY
- * XCD (0 <= first, first + count <= CUs per XCD = 32 on MI355X), i.e. count * 8 CUs spread evenly over
- * the XCDs (hipExtStreamCreateWithCUMask; mask bit i = XCD i % 8, slot i / 8).  For pipelines that run
- * the CNN of one batch beside the EM of another (run_cnn / run_em, evaluation.py:254-329): disjoint
- * shares keep the EM's long-lived workgroups from holding CUs the CNN's kernels were about to use.
- * count = 0 returns to an unrestricted stream.  vpk_get_stream returns the hipStream_t in use. */
-int vpk_set_cu_range(vpk_handle* h, int first, int count);
+/* the hipStream_t the handle enqueues on */
 void* vpk_get_stream(const vpk_handle* h);
 int vpk_synchronize(vpk_handle* h);
 const char* vpk_last_error(const vpk_handle* h);

@@ -1,0 +1,57 @@
+"""Build profiles/rNN_pmc_mfma.json from the MFMA counter passes of profile_round.sh.
+
+    python3 scripts/make_mfma_json.py <prof dir> <out json>
+
+Per kernel (averages over its dispatches): duration, SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipes were
+busy, summed over the SIMDs), GRBM_GUI_ACTIVE (cycles the GPU was active during the dispatch) and
+mfma_util = MFMA_BUSY / (GUI_ACTIVE x 256 CUs x 4 SIMDs) -- the gfx94x MfmaUtil formula (ROCm 7.2 ships no gfx950
+derived counters, MI355X_MICROARCH.md); plus the SQ wave-cycle split (wait / issue-stall / active)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_traffic_json import first_db, per_kernel   # noqa: E402
+
+SIMDS = 256 * 4
+
+
+def short(name):
+    for tag, s in (("ILi2ELi2ELi2ELi2ELb0ELb0", "conv_gemm_dma<2,2,2,2> (conv2/3/5)"),
+                   ("ILi1ELi4ELi3ELi1ELb0ELb1", "conv_gemm_dma<1,4,3,1,fused> (conv1+norm1+pool1)"),
+                   ("ILi1ELi4ELi3ELi1ELb0ELb0", "conv_gemm_dma<1,4,3,1> (conv4)"),
+                   ("ILi2ELi2ELi2ELi2ELb1ELb0", "conv_gemm_dma<2,2,2,2,dense> (fc6/7/8)"),
+                   ("em_batch_kernel", "em_batch_kernel"), ("lrn5_pool3s2", "lrn5_pool3s2_tiled (norm2+pool2)")):
+        if tag in name:
+            return s
+    return None
+
+
+def main(prof, out):
+    res = {"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                   "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (own pass); mfma_util = MFMA_BUSY / (GUI_ACTIVE * 1024)"}
+    for tag, label in (("cnn_mfma", "cnn_alone_B102"), ("yud_mfma", "bench_yud_102")):
+        try:
+            k = per_kernel(first_db(os.path.join(prof, tag)))
+        except SystemExit:
+            continue
+        sec = {}
+        for name, c in k.items():
+            s = short(name)
+            if s is None:
+                continue
+            busy, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+            wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            sec[s] = {"avg_ms": c["_ms"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
+                      "mfma_util": busy / (gui * SIMDS) if gui else None,
+                      "wave_cycles_wait_frac": c.get("SQ_WAIT_ANY", 0.0) / wc,
+                      "wave_cycles_issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                      "wave_cycles_active_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
+        res[label] = sec
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -6,7 +6,9 @@ import sqlite3
 import sys
 
 
-def main(db, out):
+def main(db, out, skip_passes=0, passes=0):
+    """skip_passes / passes: the traced program ran `passes` identical passes; drop every kernel's dispatches of
+    the first `skip_passes` of them (warm-up: cold instruction caches, first-touch allocations)."""
     con = sqlite3.connect(db)
     cur = con.cursor()
     tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
@@ -15,10 +17,22 @@ def main(db, out):
     cols = [r[1] for r in cur.execute("pragma table_info(%s)" % disp)]
     scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
     name_col = "kernel_name" if "kernel_name" in scols else "display_name"
-    q = ("select s.%s, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), "
-         "max(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s order by 3 desc"
-         % (name_col, disp, sym, name_col))
-    rows = list(cur.execute(q))
+    if passes > 0 and skip_passes > 0:
+        per = {}
+        for name, start, dur in cur.execute("select s.%s, d.start, d.end - d.start from %s d join %s s on d.kernel_id = s.id "
+                                            "order by d.start" % (name_col, disp, sym)):
+            per.setdefault(name, []).append(dur)
+        rows = []
+        for name, durs in per.items():
+            if len(durs) % passes == 0:                      # a kernel of the repeated pass: drop the warm-up share
+                durs = durs[len(durs) // passes * skip_passes:]
+            rows.append((name, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs)))
+        rows.sort(key=lambda r: -r[2])
+    else:
+        q = ("select s.%s, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), "
+             "max(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s order by 3 desc"
+             % (name_col, disp, sym, name_col))
+        rows = list(cur.execute(q))
     total = sum(r[2] for r in rows) or 1
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
@@ -31,4 +45,6 @@ def main(db, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    a = sys.argv
+    main(a[1], a[2], int(a[a.index("--skip-passes") + 1]) if "--skip-passes" in a else 0,
+         int(a[a.index("--passes") + 1]) if "--passes" in a else 0)

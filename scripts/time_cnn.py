@@ -6,9 +6,14 @@ from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 net.set_profiling(True)
-for B in ([int(a) for a in sys.argv[1:]] or [102, 512]):
+args = sys.argv[1:]
+passes = 3
+if "--passes" in args:
+    passes = int(args[args.index("--passes") + 1])
+    del args[args.index("--passes"):args.index("--passes") + 2]
+for B in ([int(a) for a in args] or [102, 512]):
     x = torch.randint(0, 60, (B, 500, 500), dtype=torch.uint8, device=rt.tdev)
-    for _ in range(3):
+    for _ in range(passes):
         net.forward_device(x)
     rt.synchronize()
     ms = net.last_layer_ms()

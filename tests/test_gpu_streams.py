@@ -1,4 +1,4 @@
-"""Lanes (handle + stream pairs) on one GPU: CU-range streams and asynchronous batches give the same bits."""
+"""Lanes (handle + stream pairs) on one GPU: a second lane and asynchronous batches give the same bits."""
 import numpy as np
 import pytest
 
@@ -13,17 +13,16 @@ def _scene(g):
             "sphere_image": g["sphere_image"], "init_vp": g.get("init_vp")}
 
 
-def test_cu_range_lane_matches_default_lane():
-    """vpk_set_cu_range: a stream limited to 4 CUs per XCD computes the same results (the persistent kernels
-    size their grids from the share; no result depends on how many workgroups run)."""
-    import torch
+def test_second_lane_matches_default_lane():
+    """Two lanes (handle + stream) on one GPU compute the same results; a lane reports the stream it was given."""
     from vanishing_points_2017_amd import cnn, em as gem
     from vanishing_points_2017_amd.runtime import get_runtime
     names = [c for c in golden_cases() if not any(k.startswith("kw_") for k in load(c))][:4]
     gs = [load(n) for n in names]
     rt0 = get_runtime(0)
-    rt1 = get_runtime(0, "masked", cu_range=(2, 4))
+    rt1 = get_runtime(0, "second")
     assert rt1.handle.lib.vpk_get_stream(rt1.h) == rt1.stream.cuda_stream
+    rt1.handle.em_set_workgroups(2)            # four images queue on two workgroups: no result depends on that
     p = gem._params({})
     outs = []
     for rt in (rt0, rt1):
@@ -38,15 +37,6 @@ def test_cu_range_lane_matches_default_lane():
     y0 = cnn.Net(w, mean, device=0, runtime=rt0).forward(x)
     y1 = cnn.Net(w, mean, device=0, runtime=rt1).forward(x)
     assert np.array_equal(y0, y1)
-
-
-def test_bad_cu_range_is_rejected():
-    from vanishing_points_2017_amd import _lib
-    h = _lib.Handle(0)
-    with pytest.raises(_lib.VpkError):
-        h.set_cu_range(30, 8)          # 30 + 8 > 32 CUs per XCD
-    h.set_cu_range(0, 0)               # back to an unrestricted stream
-    h.close()
 
 
 def test_queued_batches_on_one_lane_are_independent():

@@ -27,7 +27,7 @@ class EmParams(ctypes.Structure):
 
 
 EXPORTS = [
-    "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_set_cu_range", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
+    "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_last_layer_ms",
     "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
@@ -59,7 +59,6 @@ def load():
     lib.vpk_em_flush.argtypes = [c_void]
     lib.vpk_horizon_batch.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, ctypes.c_int,
                                       ctypes.c_double, ctypes.c_double, c_void, c_void]
-    lib.vpk_set_cu_range.argtypes = [c_void, ctypes.c_int, ctypes.c_int]
     lib.vpk_get_stream.argtypes = [c_void]
     lib.vpk_get_stream.restype = ctypes.c_void_p
     lib.vpk_em_default_params.argtypes = [ctypes.POINTER(EmParams)]
@@ -125,11 +124,6 @@ class Handle(object):
         info = (ctypes.c_int32 * 4)()
         self.check(self.lib.vpk_device_info(self.h, info))
         return {"num_cu": info[0], "lds_per_block": info[1], "arch": info[2], "hbm_gib": info[3]}
-
-    def set_cu_range(self, first, count):
-        """Own stream limited to CU slots [first, first+count) of every XCD; returns the raw hipStream_t."""
-        self.check(self.lib.vpk_set_cu_range(self.h, int(first), int(count)))
-        return self.lib.vpk_get_stream(self.h)
 
     def em_set_workgroups(self, n):
         self.check(self.lib.vpk_em_set_workgroups(self.h, int(n)))

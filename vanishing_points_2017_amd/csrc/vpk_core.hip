@@ -1,8 +1,6 @@
 // vpk_core.hip -- handle lifetime, stream plumbing, error reporting for libvpk.so
 #include "vpk_internal.hpp"
 
-#include <hip/hip_ext.h>
-
 #include <string.h>
 
 int vpk_fail(vpk_handle* h, int code, const char* what) {
@@ -100,32 +98,6 @@ int vpk_set_stream(vpk_handle* h, void* hip_stream) {
     } else {
         h->stream = (hipStream_t)hip_stream;
     }
-    return VPK_OK;
-}
-
-int vpk_set_cu_range(vpk_handle* h, int first, int count) {
-    if (!h) return VPK_ERR_ARG;
-    const int xcds = 8, per_xcd = h->num_cu / xcds;
-    if (first < 0 || count < 0 || first + count > per_xcd)
-        return vpk_fail(h, VPK_ERR_ARG, "vpk_set_cu_range: range outside the CUs of an XCD");
-    VPK_HIP(h, hipSetDevice(h->device));
-    VPK_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->own_stream && h->stream) VPK_HIP(h, hipStreamDestroy(h->stream));
-    h->stream = nullptr;
-    h->own_stream = false;
-    if (count == 0) {
-        VPK_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    } else {
-        uint32_t mask[16] = {0};
-        for (int slot = first; slot < first + count; ++slot)
-            for (int x = 0; x < xcds; ++x) {
-                const int bit = slot * xcds + x;
-                mask[bit / 32] |= 1u << (bit % 32);
-            }
-        VPK_HIP(h, hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)((h->num_cu + 31) / 32), mask));
-    }
-    h->own_stream = true;
-    h->cu_share = count == 0 ? h->num_cu : count * xcds;
     return VPK_OK;
 }
 

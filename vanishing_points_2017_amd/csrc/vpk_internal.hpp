@@ -17,7 +17,7 @@ struct vpk_handle {
     bool own_stream = false;
     std::string err;
     int num_cu = 0;
-    int cu_share = 0;            // CUs this handle's stream may use (vpk_set_cu_range); = num_cu by default
+    int cu_share = 0;            // CUs this handle's launches are sized for (= num_cu)
     int em_max_workgroups = 0;   // vpk_em_set_workgroups (0 = no cap)
     int lds_per_block = 0;
     int arch = 0;

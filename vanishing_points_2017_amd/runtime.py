@@ -8,7 +8,7 @@ _runtimes = {}
 
 
 class Runtime(object):
-    def __init__(self, device=0, cu_range=None):
+    def __init__(self, device=0):
         import torch
         if not torch.cuda.is_available():
             raise _lib.VpkError("no GPU visible: the vanishing-point hot path runs on MI355X only "
@@ -16,14 +16,9 @@ class Runtime(object):
         self.torch = torch
         self.device = int(device)
         self.tdev = torch.device("cuda", self.device)
-        if cu_range is None:
-            with torch.cuda.device(self.device):
-                self.stream = torch.cuda.Stream(device=self.tdev)
-            self.handle = _lib.Handle(self.device, stream=self.stream.cuda_stream)
-        else:   # the library owns a stream limited to a share of the CUs; torch plumbing rides on the same one
-            self.handle = _lib.Handle(self.device)
-            raw = self.handle.set_cu_range(*cu_range)
-            self.stream = torch.cuda.ExternalStream(raw, device=self.tdev)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.tdev)
+        self.handle = _lib.Handle(self.device, stream=self.stream.cuda_stream)
         self.lib = self.handle.lib
         self.h = self.handle.h
 
@@ -41,11 +36,10 @@ class Runtime(object):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def get_runtime(device=0, lane="main", cu_range=None):
+def get_runtime(device=0, lane="main"):
     """Process-wide runtime of ``device``.  ``lane`` names an independent (handle, stream) pair on the
-    same GPU, e.g. one for the CNN and one for the EM so that consecutive batches overlap; ``cu_range`` =
-    (first, count) gives the lane CU slots [first, first+count) of every XCD (vpk_set_cu_range)."""
+    same GPU, e.g. one for the CNN and one for the EM so that consecutive batches overlap."""
     key = (int(device), lane)
     if key not in _runtimes:
-        _runtimes[key] = Runtime(int(device), cu_range=cu_range)
+        _runtimes[key] = Runtime(int(device))
     return _runtimes[key]
