@@ -337,12 +337,19 @@ def main():
         total_images = count * world * args.steps
         value = total_images / elapsed
         # ---- roofline of the dominant kernel (live HIP-event timings from this run) ----
-        traffic = {}
-        try:   # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)
-        except (OSError, ValueError):
-            pass
+        def newest_profile(suffix):
+            """profiles/rNN_<suffix> of the latest round that has one (measured with rocprofv3, scripts/profile_round.sh)."""
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+            if not files:
+                return {}, None
+            try:
+                with open(files[-1]) as fh:
+                    return json.load(fh), os.path.relpath(files[-1], ROOT)
+            except (OSError, ValueError):
+                return {}, None
+        traffic, traffic_src = newest_profile("pmc_traffic.json")   # HBM bytes per launch: --pmc FETCH_SIZE / WRITE_SIZE passes
+        mfma, mfma_src = newest_profile("pmc_mfma.json")            # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes
         m_avg = np.maximum(nvp, 1)
         evals = iters + 1 + 4                            # loop E-steps + initial + finalisation (:344,:398,:415 and the merge/prune ones: >= 4)
         # EM batch kernel (one launch per step): algorithmic bytes B_EM of SURVEY 8d,
@@ -354,7 +361,9 @@ def main():
         tc = traffic.get(key + "_conv") if key else None
         roof_em = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None}
+                   "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None, "traffic_source": traffic_src,
+                   "note": "achieved = modelled algorithmic bytes (SURVEY 8d B_EM) / kernel time measured on overlapped streams; "
+                           "traffic = HBM bytes per launch from the PMC passes"}
         name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])   # the layer with the most arithmetic (conv2)
         flop = cnn.Net.LAYER_FLOP[name] * count
         roof_cnn = {"kernel": "conv_gemm_dma_kernel(%s)" % name, "bound": "mfma",
@@ -363,6 +372,11 @@ def main():
                     "traffic": (tc["hbm_read_bytes"] + tc["hbm_write_bytes"]) if tc else None,
                     "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel"}
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
+        roof_cnn["traffic_source"] = traffic_src
+        pm = (mfma.get("bench_yud_102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)") if args.workload == "yud" else None
+        if pm:      # counter view of the same kernel inside the bench: fraction of SIMD-cycles with a busy matrix pipe, and the
+                    # shader clock it ran at (the 157.3 TF peak assumes 2.4 GHz; under this load the part clocks lower)
+            roof_cnn["pmc"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"], "source": mfma_src}
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step,
         # each EM stream one batch every n_lanes steps
         roof = roof_em if (em_ms / n_lanes >= cnn_ms * 1.5 or args.workload == "stress") else roof_cnn

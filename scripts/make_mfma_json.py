@@ -3,9 +3,10 @@
     python3 scripts/make_mfma_json.py <prof dir> <out json>
 
 Per kernel (averages over its dispatches): duration, SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipes were
-busy, summed over the SIMDs), GRBM_GUI_ACTIVE (cycles the GPU was active during the dispatch) and
-mfma_util = MFMA_BUSY / (GUI_ACTIVE x 256 CUs x 4 SIMDs) -- the gfx94x MfmaUtil formula (ROCm 7.2 ships no gfx950
-derived counters, MI355X_MICROARCH.md); plus the SQ wave-cycle split (wait / issue-stall / active)."""
+busy, summed over the 1024 SIMDs), GRBM_GUI_ACTIVE (active cycles, summed over the 8 XCDs: the value is 8 x the
+kernel's duration in shader cycles, which also gives the clock the kernel actually ran at) and
+mfma_util = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024 SIMDs), the fraction of SIMD-cycles with a busy matrix pipe (ROCm 7.2
+ships no gfx950 derived counters, MI355X_MICROARCH.md); plus the SQ wave-cycle split (wait / issue-stall / active)."""
 import json
 import os
 import sys
@@ -14,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_traffic_json import first_db, per_kernel   # noqa: E402
 
 SIMDS = 256 * 4
+XCDS = 8
 
 
 def short(name):
@@ -29,7 +31,7 @@ def short(name):
 
 def main(prof, out):
     res = {"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
-                   "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (own pass); mfma_util = MFMA_BUSY / (GUI_ACTIVE * 1024)"}
+                   "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (own pass); mfma_util = MFMA_BUSY / (GUI_ACTIVE / 8 XCDs * 1024 SIMDs); shader_clock = GUI_ACTIVE / 8 / duration"}
     for tag, label in (("cnn_mfma", "cnn_alone_B102"), ("yud_mfma", "bench_yud_102")):
         try:
             k = per_kernel(first_db(os.path.join(prof, tag)))
@@ -43,7 +45,8 @@ def main(prof, out):
             busy, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
             wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
             sec[s] = {"avg_ms": c["_ms"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
-                      "mfma_util": busy / (gui * SIMDS) if gui else None,
+                      "mfma_util": busy / (gui / XCDS * SIMDS) if gui else None,
+                      "shader_clock_ghz": gui / XCDS / (c["_ms"] * 1e6) if gui else None,
                       "wave_cycles_wait_frac": c.get("SQ_WAIT_ANY", 0.0) / wc,
                       "wave_cycles_issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                       "wave_cycles_active_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}

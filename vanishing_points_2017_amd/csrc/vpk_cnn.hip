@@ -92,8 +92,8 @@ constexpr int C1_OUT = 123, C1_POOL = 61;          // conv1 / pool1 output size 
 constexpr int C1_TR = (C1_POOL + C1_QR - 1) / C1_QR, C1_TC = (C1_POOL + C1_QC - 1) / C1_QC;   // 21 x 8 patches per image
 constexpr int C1_LD = 129;                         // row stride of the patch in LDS ([channel][column])
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE, bool C1FUSE = false>
-__global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE, bool C1FUSE = false, int NST = 3, int WPC = 3>
+__global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
                                                                      const unsigned* __restrict__ ktab,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(BN == 128, "the B-tile loader assumes 128 columns");
     static_assert(!C1FUSE || (BM == 96 && TN == 1 && !DENSE), "the fused conv1 tile is 96 channels x 128 columns");
-    constexpr int NST = 3;
+    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
     constexpr int STAGE_FLOATS = NST * BK * (BM + BN);
     constexpr int LDS_FLOATS = C1FUSE ? (96 * C1_LD > STAGE_FLOATS ? 96 * C1_LD : STAGE_FLOATS) : STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
@@ -224,16 +224,17 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = kt1 - kt0;
+    constexpr int AHEAD = NST - 1;                      // stages in flight ahead of the one being multiplied
     if (nk > 0) issue(kt0, 0);
-    if (nk > 1) issue(kt0 + 1, 1);
-    wait_stage(nk > 1);
+    if (AHEAD > 1 && nk > 1) issue(kt0 + 1, 1);
+    wait_stage(AHEAD > 1 && nk > 1);
     asm volatile("" : "+v"(nx));                        // the atomic's result has landed (it is older than stage 0)
     if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
         const int buf = t % NST;
-        if (t + 2 < nk) issue(kt0 + t + 2, (t + 2) % NST);
+        if (t + AHEAD < nk) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
             float af[TM], bf[TN];
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_gemm_dma_kernel(ConvDims
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        wait_stage(t + 2 < nk);                         // stage t+1 has landed (own pieces) ...
+        wait_stage(AHEAD > 1 && t + 2 < nk);            // stage t+1 has landed (own pieces) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // ... for every wave; stage t's buffer is free again
     }
@@ -617,10 +618,10 @@ __global__ void unpad_kernel(const float* __restrict__ in, float* __restrict__ o
 
 template <typename KernelT>
 void launch_dma(vpk_handle* h, KernelT kernel, const ConvDims& d, int BM, const float* in, const Layer& l, float* out,
-                int stride, int* counter) {
+                int stride, int* counter, int wpc = 3) {
     long long ntiles = (d.N + 127) / 128;
     long long total = (long long)d.groups * d.ksplit * ntiles * (d.Mp / BM);
-    long long blocks = std::min<long long>(total, 3ll * h->num_cu);     // three workgroups fit a CU (LDS)
+    long long blocks = std::min<long long>(total, (long long)wpc * h->num_cu);   // wpc workgroups fit a CU (LDS, registers)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, h->stream, d, in, l.wp, l.bias, l.ktab,
                        out, stride, counter, (int)total);
 }
@@ -693,7 +694,12 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     }
     tapunpad(1, R[R_POOL1], 96, 61, 61, 2);
     // conv2 + relu2
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(1), 128, R[R_POOL1], S->L[1], R[R_CONV2], 1, ctr + 1);
+    // (a 2-stage / 4-workgroups-per-CU build of the same kernel, NST = 2, WPC = 4, was measured in round 2: conv2 +2 %,
+    //  conv3 -3 %, conv5 -11 % (1436 tiles on 1024 workgroups) -- not used)
+    auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
+        launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
+    };
+    conv_main(1, R[R_POOL1], R[R_CONV2]);
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
     // norm2 + pool2 (fused), written with conv3's border
@@ -703,13 +709,13 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     tapunpad(3, R[R_POOL2], 256, 30, 30, 1);
     // conv3..5
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(2), 128, R[R_POOL2], S->L[2], R[R_CONV3], 1, ctr + 2);
+    conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
     launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(4), 128, R[R_CONV4], S->L[4], R[R_CONV5], 1, ctr + 4);
+    conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
     if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, R[R_CONV5],
