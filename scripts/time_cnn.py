@@ -6,6 +6,8 @@ from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 net.set_profiling(True)
+import os
+net.set_fusion(int(os.environ.get("VPK_FUSION", "1")))
 args = sys.argv[1:]
 passes = 3
 if "--passes" in args:

@@ -82,7 +82,7 @@ class Net(object):
 
     def set_fusion(self, on=True):
         """conv1 + norm1 + pool1 as one kernel (default) or as separate kernels."""
-        self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(bool(on))))
+        self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
     def set_profiling(self, on=True):
         self.rt.check(self.rt.lib.vpk_cnn_set_profiling(self.rt.h, int(bool(on))))

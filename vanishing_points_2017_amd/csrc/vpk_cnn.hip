@@ -91,6 +91,7 @@ constexpr int C1_QR = 3, C1_QC = 8;                // pooled outputs per patch
 constexpr int C1_OUT = 123, C1_POOL = 61;          // conv1 / pool1 output size (deploy.prototxt:9-55)
 constexpr int C1_TR = (C1_POOL + C1_QR - 1) / C1_QR, C1_TC = (C1_POOL + C1_QC - 1) / C1_QC;   // 21 x 8 patches per image
 constexpr int C1_LD = 129;                         // row stride of the patch in LDS ([channel][column])
+constexpr int C1_PH = 4, C1_PW = 125;              // conv1 reads its input as 4 x 4 stride-4 phase planes of 125 x 125 (prep_input_kernel)
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool DENSE, bool C1FUSE = false, int NST = 3, int WPC = 3>
 __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDims d, const float* __restrict__ in,
@@ -365,6 +366,184 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
     }   // tile loop
 }
 
+// --------------------------------------------------------------------------------------------
+// conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55) as a DIRECT convolution, one 512-thread workgroup per CU.
+//
+// conv1 is the odd layer: K = 121 only, so an implicit-GEMM tile spends more time on its im2col gather (256 LDS-DMA
+// instructions per tile), prologue and epilogue than on its 8 K stages (measured: matrix pipes 42 % busy).  Here
+//   * the whole weight panel (128 x 96, k-major) stays in LDS for the lifetime of the persistent workgroup,
+//   * a tile = a 7 x 17 patch of conv outputs (all 96 channels); its RAW input patch (16 stride-4 phase planes x 9 x 19
+//     pixels, 11 KB -- against 64 KB of im2col panel) is prefetched into registers under the previous tile's MFMAs,
+//   * the B operand is read straight out of the raw patch: address = (patch position of the lane's column) + (offset of
+//     tap k), the 32 tap offsets a lane needs live in registers,
+//   * 8 waves x 16 columns, v_mfma_f32_16x16x4_f32, 6 M tiles per wave (24 accumulator registers),
+//   * epilogue out of LDS: bias + ReLU -> patch [channel][column] -> LRN across channels in place -> 3x3/2 max pool
+//     (windows clipped like Caffe) -> 3 x 8 pooled outputs per channel, written with conv2's border.
+// Neighbouring patches share one conv row / column (1.24x the MFMA work); conv1's 0.59 GB blob (B = 102) never exists.
+// --------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int C1D_THREADS = 512;
+constexpr int C1D_ALD = 112;                          // row stride of the weight panel in LDS: the four k rows a wave reads
+                                                      // at once (k = 4s + lane/16) fall into disjoint bank quarters
+constexpr int C1D_PY = 9, C1D_PX = 19, C1D_PXL = 20;  // rows / columns of one phase of the raw patch; LDS row stride
+constexpr int C1D_XS = 16 * C1D_PY * C1D_PXL;         // floats per patch buffer
+constexpr int C1D_LD = 132;                           // row stride of the output patch [channel][column]: the four row groups
+                                                      // a wave writes at once (rows 4 apart) hit disjoint bank quarters
+
+// workgroup barrier that orders LDS traffic only: the pooled outputs' global stores stay in flight across it
+// (__syncthreads also waits for vmcnt(0), i.e. one HBM write round trip per tile)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                                      int OHp, int OWp, int opad, int* __restrict__ tile_counter,
+                                                                      int total_tiles) {
+    __shared__ __attribute__((aligned(16))) float As[128 * C1D_ALD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][C1D_XS];
+    __shared__ __attribute__((aligned(16))) float Cs[96][C1D_LD];
+    __shared__ int s_next[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    for (int idx = tid; idx < 128 * 96; idx += C1D_THREADS) As[(idx / 96) * C1D_ALD + idx % 96] = wp[idx];   // [Kp = 128][Mp = 96]
+    // this lane's column of the tile and the LDS offsets of the taps k = 4 s + g it feeds to the matrix cores
+    int col = wave * 16 + c16;
+    col = col < C1_PR * C1_PC ? col : C1_PR * C1_PC - 1;                 // columns 119..127 repeat the last position, unused
+    const int colbase = (col / C1_PC) * C1D_PXL + col % C1_PC;
+    int ko[32];
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+        const int k = 4 * s2 + g;
+        const int kh = k / 11, kw = k - kh * 11;
+        ko[s2] = k < 121 ? (((kh & 3) * 4 + (kw & 3)) * C1D_PY + (kh >> 2)) * C1D_PXL + (kw >> 2) : 0;   // rows 121..127 of the panel are 0
+    }
+    float bl[6][4];                                                      // bias of the 24 channels this lane's accumulators hold
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bl[i][r] = bias[16 * i + 4 * g + r];
+    constexpr int PRE = (16 * C1D_PY * C1D_PX + C1D_THREADS - 1) / C1D_THREADS;   // raw-patch floats per thread (6)
+    int pph[PRE], pyl[PRE], pxl[PRE], pdst[PRE];       // per-thread constants of the raw-patch copy: element u = (phase, row, column)
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int e = tid + u * C1D_THREADS;
+        const int p = e / (C1D_PY * C1D_PX), rem = e - p * (C1D_PY * C1D_PX);
+        pph[u] = p * C1_PW;                            // first row of phase plane p inside the image's 16 stacked planes
+        pyl[u] = rem / C1D_PX;
+        pxl[u] = rem % C1D_PX;
+        pdst[u] = e < 16 * C1D_PY * C1D_PX ? (p * C1D_PY + pyl[u]) * C1D_PXL + pxl[u] : -1;
+    }
+    auto patch_load = [&](int tile, float (&v)[PRE]) {
+        const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
+        const float* base = in + (size_t)b * 16 * C1_PW * C1_PW;
+        const int y0 = (C1_PR - 1) * pr, x0 = (C1_PC - 1) * pc;
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {                // overhang is clamped (those taps only reach conv outputs that no
+            const int y = y0 + pyl[u], x = x0 + pxl[u];   //  pooling window uses)
+            const int yy = pph[u] + (y < C1_PW ? y : C1_PW - 1), xx = x < C1_PW ? x : C1_PW - 1;
+            v[u] = pdst[u] >= 0 ? base[(size_t)yy * C1_PW + xx] : 0.f;
+        }
+    };
+    auto patch_store = [&](int buf, const float (&v)[PRE]) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (pdst[u] >= 0) Xs[buf][pdst[u]] = v[u];
+    };
+    // dynamic tile queue (CUs held by other streams' kernels make static shares uneven); the index of the tile after
+    // next is fetched one tile ahead, so the atomic's round trip is never waited for
+    int tile = blockIdx.x;
+    float pre[PRE];
+    if (tile < total_tiles) { patch_load(tile, pre); patch_store(0, pre); }
+    if (tid == 0) s_next[0] = atomicAdd(tile_counter, 1) + (int)gridDim.x;
+    __syncthreads();
+    int next = s_next[0];
+    for (int it = 0; tile < total_tiles; ++it) {
+        const int buf = it & 1;
+        int nx = 0;
+        if (tid == 0) nx = atomicAdd(tile_counter, 1);            // consumed at the end of the tile: its round trip is never waited for
+        if (next < total_tiles) patch_load(next, pre);              // in flight under the MFMAs below
+        f32x4 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xs = &Xs[buf][colbase];
+        const float* as = &As[g * C1D_ALD + c16];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) {
+            const float bv = xs[ko[s2]];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[4 * s2 * C1D_ALD + 16 * i], bv, acc[i], 0, 0, 0);
+        }
+        if (next < total_tiles) patch_store(buf ^ 1, pre);          // that buffer was last read several barriers ago
+        // ---- epilogue: bias + ReLU -> LDS patch -> LRN in place -> max pool -> store ----
+        const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
+        const int ccol = wave * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                           // accumulator register r holds row 4 (lane / 16) + r
+                const float v = acc[i][r] + bl[i][r];
+                Cs[16 * i + 4 * g + r][ccol] = v > 0.f ? v : 0.f;
+            }
+        lds_barrier();
+        {   // LRN across channels (deploy.prototxt:34-44): four threads per column, 24 channels each.  All 28 raw values
+            // (24 + a halo of 2 on each side) are read before anything is written: no read-after-write chain through LDS,
+            // and the 24 rsqrt / sqrt chains are independent.
+            const int p = tid & 127, c0 = (tid >> 7) * 24;
+            float raw[28];
+#pragma unroll
+            for (int k = 0; k < 28; ++k) {
+                const int c = c0 - 2 + k;
+                raw[k] = (c >= 0 && c < 96) ? Cs[c < 0 ? 0 : (c > 95 ? 95 : c)][p] : 0.f;
+            }
+            lds_barrier();                                          // every raw value has been read
+            const float an = 1e-4f / 5.f;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const float sc = 1.f + an * (raw[k] * raw[k] + raw[k + 1] * raw[k + 1] + raw[k + 2] * raw[k + 2] +
+                                             raw[k + 3] * raw[k + 3] + raw[k + 4] * raw[k + 4]);
+                const float rr = __builtin_amdgcn_rsqf(sc);           // v_rsq_f32 / v_sqrt_f32 (1 ulp; sc >= 1): the IEEE-exact
+                Cs[c0 + k][p] = raw[k + 2] * (rr * __builtin_amdgcn_sqrtf(rr));   // library forms cost ~25 VALU instructions each
+            }
+        }
+        lds_barrier();
+        if (tid < 96 * C1_QR) {     // 3x3 / stride 2 max pool: one thread per (channel, pooled row) = 8 outputs from 3 x 17 values;
+                                    // the column maxima are shared by neighbouring windows (Caffe clips windows at the blob's edge)
+            const int k = tid / C1_QR, py = tid - k * C1_QR;
+            const int ph = C1_QR * pr + py;
+            const int rows = C1_OUT - (C1_PR - 1) * pr - 2 * py;    // valid rows of this window band (>= 3 away from the border)
+            const int cols = C1_OUT - (C1_PC - 1) * pc;             // valid columns of the patch
+            if (ph < C1_POOL) {
+                const float NEG = -3.402823466e38f;
+                const float* c = &Cs[k][2 * py * C1_PC];
+                float cm[C1_PC];
+#pragma unroll
+                for (int q = 0; q < C1_PC; ++q) {
+                    float m = c[q];
+                    const float v1 = c[C1_PC + q], v2 = c[2 * C1_PC + q];
+                    m = (rows > 1 && v1 > m) ? v1 : m;
+                    m = (rows > 2 && v2 > m) ? v2 : m;
+                    cm[q] = q < cols ? m : NEG;
+                }
+                float* o = out + ((size_t)b * 96 + k) * OHp * OWp + (size_t)(ph + opad) * OWp + C1_QC * pc + opad;
+#pragma unroll
+                for (int px = 0; px < C1_QC; ++px) {
+                    float m = cm[2 * px];
+                    m = cm[2 * px + 1] > m ? cm[2 * px + 1] : m;
+                    m = cm[2 * px + 2] > m ? cm[2 * px + 2] : m;
+                    if (C1_QC * pc + px < C1_POOL) o[px] = m;
+                }
+            }
+        }
+        if (tid == 0) s_next[(it + 1) & 1] = nx + (int)gridDim.x;
+        lds_barrier();                                              // Cs is free; the next raw patch and tile index are visible
+        tile = next;
+        next = s_next[(it + 1) & 1];
+    }
+}
+
 // conv1 input: float(uint8 raster) - mean (evaluation.py:35), written as the 16 stride-4 phase planes
 //   P[py][px][Y][X] = x[4Y + py][4X + px]   (125 x 125 each)
 // so that conv1 (11 x 11, stride 4) is a stride-1 gather for the DMA kernel: tap (kh, kw) of output (oh, ow)
@@ -373,7 +552,6 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
 // 2.76 -> 2.57 ms at B = 512, unchanged at B = 102.  With its MFMAs and stores removed conv1 still takes
 // 0.36 of its 0.58 ms: with only 8 K-stages per tile it is bound by the issue rate of the 4-byte gather DMAs
 // (about one per 40-60 cycles per CU), which a wider (16-byte, row-tiled) loader would relieve.
-constexpr int C1_PH = 4, C1_PW = 125;     // phases per axis, phase-plane width/height (500 / 4)
 __global__ void prep_input_kernel(const unsigned char* __restrict__ sphere, const float* __restrict__ mean,
                                   float* __restrict__ out, int plane) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;       // pixel within the image
@@ -535,7 +713,7 @@ struct vpk_cnn_state {
     size_t act_bytes = 0;
     int act_batch = 0;
     // optional per-layer timing (HIP events on the handle's stream)
-    bool fuse_conv1 = true;  // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion)
+    int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
     bool profiling = false;
     hipEvent_t ev[14] = {};
     bool ev_ready = false;
@@ -684,10 +862,16 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     } else {
         // conv1 + relu1 + norm1 + pool1 in one kernel: 21 x 8 patches of 7 x 17 conv outputs per image, straight into
         // pool1's planes (with conv2's border of 2); the conv1 blob only exists when a caller taps it
-        ConvDims df = dims(0);
-        df.N = batch * C1_TR * C1_TC * 128;               // one 128-column tile per patch
-        df.OHp = 65; df.OWp = 65; df.opad = 2;
-        launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false, true>, df, 96, R[R_IN], S->L[0], R[R_POOL1], 1, ctr + 0);
+        if (S->fuse_conv1 == 2) {                         // the implicit-GEMM kernel with the fused epilogue (kept for comparison)
+            ConvDims df = dims(0);
+            df.N = batch * C1_TR * C1_TC * 128;           // one 128-column tile per patch
+            df.OHp = 65; df.OWp = 65; df.opad = 2;
+            launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false, true>, df, 96, R[R_IN], S->L[0], R[R_POOL1], 1, ctr + 0);
+        } else {
+            const int total = batch * C1_TR * C1_TC;
+            hipLaunchKernelGGL(conv1_direct_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1D_THREADS), 0, st, R[R_IN],
+                               S->L[0].wp, S->L[0].bias, R[R_POOL1], 65, 65, 2, ctr + 0, total);
+        }
         mark();
         mark();
         mark();
@@ -762,7 +946,7 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
 
 int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
-    h->cnn->fuse_conv1 = on != 0;
+    h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 2 ? 1 : on);
     return VPK_OK;
 }
 
