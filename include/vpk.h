@@ -144,6 +144,15 @@ int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
                       double alpha, uint8_t* out);
 
+/* ---- front end: line segment detection (HOST code, host pointers) -------------------------------------------- */
+/* replaces: lsdpython.lsd.detect_line_segments(image) as called by detect_lsd_lines (evaluation.py:227-251; the
+ * detector itself is an un-vendored submodule of the reference, .gitmodules:1-3 -- parity unpinned, see
+ * csrc/vpk_lsd.cpp).  image [host]: height x width fp64 grey levels 0..255, row-major; scale: Gaussian sub-sampling
+ * factor (0.8 = LSD's default).  out [host]: up to max_segments rows of 7 doubles (x1, y1, x2, y2, width, p,
+ * -log10(NFA)) in pixel coordinates of the input image; *n_out = number of segments found (if it exceeds
+ * max_segments only the first max_segments were written: call again with a larger buffer).  No GPU involved. */
+int vpk_lsd_detect(const double* image, int width, int height, double scale, double* out, int max_segments, int* n_out);
+
 /* ---- EM refinement (vp_localisation.py:168-450) ------------------------------------------------ */
 /* replaces: run_em / run_em_single -> expectation_maximisation (evaluation.py:295-354) for a
  * batch of images.  One workgroup runs the whole EM of one image; images are independent.

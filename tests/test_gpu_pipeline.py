@@ -80,3 +80,38 @@ def test_horizon_batch_matches_host_selection():
         assert np.array_equal(np.asarray(ref[5]).ravel(), np.asarray(g_[5]).ravel())
         for a, b in zip(ref[:5], g_[:5]):
             assert np.allclose(np.asarray(a, dtype=float), b, rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_image_files_through_the_whole_call_surface(tmp_path):
+    """example.py's flow (example.py:30-39) from image FILES: get_data_list -> create_data_pickles (this package's
+    front end: Pillow, LSD, normalisation, GPU raster; target_size 640) -> run_cnn -> run_em, reference pickle schema."""
+    from PIL import Image
+    from test_frontend import _render
+    from vanishing_points_2017_amd import cnn, evaluation
+    src, dst = tmp_path / "images", tmp_path / "results"
+    src.mkdir(); dst.mkdir()
+    rs = np.random.RandomState(3)
+    for k in range(2):                                  # strokes towards two vanishing points, rendered at 1280 x 960
+        segs = []
+        for vp in ((2000.0, 300.0), (-900.0, 500.0)):
+            for _ in range(14):
+                x, y = rs.uniform(100, 1180), rs.uniform(100, 860)
+                d = np.array([vp[0] - x, vp[1] - y]); d /= np.linalg.norm(d)
+                ln = rs.uniform(120, 300)
+                segs.append((x, y, x + ln * d[0], y + ln * d[1]))
+        img = _render(segs, 960, 1280, width=4.0).astype(np.uint8)
+        Image.fromarray(np.repeat(img[:, :, None], 3, 2)).save(str(src / ("scene%d.png" % k)))
+    dataset = evaluation.get_data_list(str(src), str(dst), 'default_net', "", "0", update=True)
+    assert len(dataset['image_files']) == 2
+    evaluation.create_data_pickles(dataset, update=True, cnn_input_size=500, target_size=640)
+    evaluation.run_cnn(dataset, None, None, None, net=cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0)))
+    evaluation.run_em(dataset)
+    for f in dataset['pickle_files']:
+        d = evaluation._load_pickle(f)
+        assert d['lines']['image'].shape == (480, 640, 3)                      # resized to fit 640
+        seg = d['lines']['line_segments']
+        assert seg.shape[0] >= 40 and np.abs(seg).max() <= 1.0                # two edges per stroke, normalised coordinates
+        assert d['sphere_image'].shape == (500, 500) and d['sphere_image'].max() > 0
+        assert d['cnn_prediction'].shape == (20, 20)
+        res = d['EM_result']
+        assert res is not None and res['vp'] is not None and res['vp_assoc'].shape[0] == seg.shape[0]

@@ -23,6 +23,7 @@ UNITS = {
     "vpk_cnn.hip": [],
     "vpk_raster.hip": [],
     "vpk_horizon.hip": ["-ffp-contract=off"],
+    "vpk_lsd.cpp": ["-ffp-contract=off"],      # host code: the front end's line segment detector
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result"]
@@ -50,7 +51,7 @@ def build(force=False, verbose=True):
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             raise RuntimeError("missing source " + path)
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         fresh = os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), deps_mtime)
         if fresh and not force:

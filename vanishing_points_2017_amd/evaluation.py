@@ -105,16 +105,13 @@ def get_data_list(source_folder, destination_folder, name, cnn_model_root, cnn_m
 
 
 def create_data_pickles(dataset, update=False, cnn_input_size=250, target_size=None, line_detector=None):
-    """evaluation.py:121-186.  OUT OF SCOPE for the kernels: it needs an LSD detector (the reference's
-    `lsdpython` submodule is empty and not vendored) and an image reader.  With a ``line_detector``
-    callable (image_file, target_size) -> (image_rgb, segments N x 4 in the reference's normalised
-    coordinates) it builds the same pickles, rasterising on the GPU."""
-    if line_detector is None:
-        missing = [f for f in dataset["pickle_files"] if not os.path.isfile(f)]
-        if missing or update:
-            raise RuntimeError("create_data_pickles needs precomputed line segments: LSD (lsdpython) is not "
-                               "vendored with the reference; pass line_detector=... or provide the pickles")
-        return
+    """evaluation.py:121-186.  ``line_detector`` (image_file, target_size) -> (image_rgb, segments N x 4 in the
+    reference's normalised coordinates) defaults to this package's front end (frontend.line_detector: the
+    reference's `lsdpython` submodule is empty and ImageMagick is an external program, so both are stand-ins --
+    frontend.py says what is pinned and what is not); the pickles are the reference's, rasterised on the GPU."""
+    if line_detector is None:       # this package's own front end (frontend.py: Pillow + the LSD of csrc/vpk_lsd.cpp)
+        from . import frontend
+        line_detector = frontend.line_detector
     for image_file, data_file in zip(dataset["image_files"], dataset["pickle_files"]):
         if os.path.isfile(data_file) and not update:
             continue
@@ -127,6 +124,18 @@ def create_data_pickles(dataset, update=False, cnn_input_size=250, target_size=N
                  "image": image_rgb, "line_segments": segs, "lines": lines}
         sphere_image = get_sphere_image(datum['lines'], size=cnn_input_size, alpha=0.1)   # :175
         _dump_pickle({'lines': datum, 'sphere_image': sphere_image}, data_file)
+
+
+def create_data_dict_single(image_rgb, cnn_input_size=250):
+    """evaluation.py:188-224."""
+    from . import frontend
+    return frontend.create_data_dict_single(image_rgb, cnn_input_size)
+
+
+def detect_lsd_lines(image):
+    """evaluation.py:227-251."""
+    from . import frontend
+    return frontend.detect_lsd_lines(image)
 
 
 def run_cnn(dataset, model_def, model_weights, mean_file, gpu=0, net=None):
