@@ -292,8 +292,8 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
             for (int k = 0; k < 48; ++k) {
                 const float v4 = k + 2 < 48 ? Cs[c0 + k + 2][p] : (k + 2 == 48 ? e0 : e1);
                 const float sc = 1.f + an * (v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4);
-                const float r = rsqrtf(sc);
-                Cs[c0 + k][p] = v2 * (r * sqrtf(r));                // sc^-0.75
+                const float r = __builtin_amdgcn_rsqf(sc);
+                Cs[c0 + k][p] = v2 * (r * __builtin_amdgcn_sqrtf(r));   // sc^-0.75
                 v0 = v1; v1 = v2; v2 = v3; v3 = v4;
             }
         }
@@ -637,7 +637,10 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_tiled_kernel(const float* __
             const float v4 = patch[k + 4][p];
             const float sc = 1.f + an * (v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3 + v4 * v4);
             float pw_;
-            if (beta == 0.75f) { const float r = rsqrtf(sc); pw_ = r * sqrtf(r); }
+            if (beta == 0.75f) {                         // v_rsq_f32 / v_sqrt_f32 (1 ulp, sc >= 1); the IEEE-exact library
+                const float r = __builtin_amdgcn_rsqf(sc);   // forms expand to ~25 VALU instructions each
+                pw_ = r * __builtin_amdgcn_sqrtf(r);
+            }
             else pw_ = powf(sc, -beta);
             patch[k + 2][p] = v2 * pw_;                  // plane k+2 holds channel c0+k; its raw value lives in v2
             v0 = v1; v1 = v2; v2 = v3; v3 = v4;
