@@ -60,6 +60,8 @@ template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]) {
 }
 VPK_DEV void sched_fence() {}
 VPK_DEV void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
+VPK_DEV long long __double_as_longlong(double v) { long long r; memcpy(&r, &v, 8); return r; }
+VPK_DEV double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
 VPK_DEV long long clock_ticks() { return 0; }
 constexpr double CLOCK_US = 0.01;
 VPK_DEV int atomic_add_int(int* p, int v) { int o = *p; *p += v; return o; }

@@ -184,15 +184,15 @@ int sim_cluster2(int n, const double* ldist, int* labels_out, unsigned* flags_ou
     std::vector<int> member(n), csize(n);
     g_sh.flags = 0;
     const int ld = n | 1;
-    if (n <= CLUSTER_LDS_MAX && (long long)n * ld + n <= WT_DOUBLES) {   // same choice as the kernel
+    if (n <= CLUSTER_LDS_MAX && cluster_lds_doubles(n) <= WT_DOUBLES) {   // same choice as the kernel
         double* DL = WT();
         for (int a = 0; a < n; ++a)
             for (int b = 0; b < n; ++b) {
                 const double v = D[(size_t)a * n + b];
                 DL[a * ld + b] = (a == b || !(v + D[(size_t)b * n + a] != 0.0)) ? -1.0 : v;
             }
-        int* lmember = reinterpret_cast<int*>(DL + (size_t)n * ld);
-        cluster2_lds(n, ld, DL, lmember, lmember + n);
+        cluster2_lds(n);
+        const int* lmember = cluster_lds_labels(DL, n);
         for (int q = 0; q < n; ++q) member[q] = lmember[q];
     } else {
         cluster2(g_sh, n, D.data(), member.data(), csize.data());

@@ -127,3 +127,30 @@ def test_suspended_and_resumed_run_is_bit_identical(name):
     assert a["status"] == b["status"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"]
     for k in ("vp", "sigma", "counts", "counts_weighted", "vp_assoc", "l"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_cluster2_row_cache_against_sklearn_many_sets():
+    """The one-wave clustering keeps a nearest-neighbour cache per row instead of rescanning all pairs at every merge:
+    40 random line sets (5..75 lines, the LDS path) must give sklearn's labels, with no tie flagged."""
+    import warnings
+    import sklearn.cluster as cluster
+    rs = np.random.RandomState(123)
+    for _ in range(40):
+        n = int(rs.randint(5, 76))
+        ang = rs.uniform(0, np.pi, n)
+        if rs.rand() < 0.5:                                  # two tight bundles plus scatter: realistic VP line sets
+            ang[: n // 2] = rs.normal(0.3, 0.02, n // 2)
+            ang[n // 2: 3 * n // 4] = rs.normal(1.7, 0.05, 3 * n // 4 - n // 2)
+        lp = np.stack([np.cos(ang), np.sin(ang), np.zeros(n), np.zeros(n)], 1) * rs.uniform(0.1, 1, (n, 1))
+        rows = np.repeat(np.arange(n), n).reshape(n, n)
+        ld = 1 - em.pair_cosangle(lp, 2, rows, rows.T)
+        np.fill_diagonal(ld, 0)
+        model = cluster.AgglomerativeClustering(linkage="average", connectivity=ld, n_clusters=2, metric="precomputed")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model.fit_predict(ld)
+        labels, flags = simlib.cluster2(ld)
+        if flags == 0:
+            assert np.array_equal(labels, model.labels_), n
+        else:
+            assert flags & 1                                   # an exact tie: sklearn's heap order decides, flagged

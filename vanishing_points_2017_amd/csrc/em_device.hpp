@@ -1453,46 +1453,68 @@ VPK_DEVFN void cluster2(Shared&, int n, gdp D, gip member, gip csize) {
     block_sync();
 }
 
-// Same algorithm for small sets (the usual case: the lines of one VP), run by ONE wave out of LDS so
-// that a merge costs no workgroup barrier: D is an n x ld matrix in LDS (ld odd), the candidate pairs
-// (a > b, row-major) are dealt to the lanes, the active set is a 128-bit mask in registers.
-// Caller: all threads, D already holds the distances with -1 for "no edge"; member/csize in LDS.
+// Same algorithm for small sets (the usual case: the lines of one VP; <= 72 lines in the YUD-shape bench), run by ONE
+// wave out of LDS so that a merge costs no workgroup barrier.  D is an n x ld matrix in LDS (ld odd, -1 = no edge; a
+// merged-away slot's row and column are set to -1, so the search needs no activity test per entry).  Per merge the
+// wave walks the active rows a with lanes over the columns b < a (consecutive LDS words, no index decoding), every
+// lane keeps its own best (distance, position), and ONE cross-lane arg-min ends the search -- a cross-lane
+// reduction of a double + index costs ~1000 cycles on this part (scripts/ubench/wave_reduce.hip), as much as walking
+// 30 rows, so the design minimises reductions, not LDS reads.  (Round 1 decoded a triangular pair index per entry:
+// ~10 us per merge; a per-row nearest-neighbour cache with a reduction per rescanned row was no faster.)
+// The matrix is the head of the LDS panel (WT()); behind it: member / csize [n] ints each.
 constexpr int CLUSTER_LDS_MAX = 128;
-VPK_DEV void tri_decode(int idx, int& a, int& b) {            // idx = a (a - 1) / 2 + b, 0 <= b < a
-    a = (int)((1.0 + sqrt(1.0 + 8.0 * (double)idx)) * 0.5);
-    while (a > 1 && a * (a - 1) / 2 > idx) --a;
-    while ((a + 1) * a / 2 <= idx) ++a;
-    b = idx - a * (a - 1) / 2;
+VPK_DEV long long cluster_lds_doubles(int n) { return (long long)n * (n | 1) + (long long)n + 4; }
+VPK_DEV int* cluster_lds_labels(double* D, int n) {
+    return reinterpret_cast<int*>(D + (size_t)n * (n | 1));
 }
-VPK_DEVFN void cluster2_lds(int n, int ld, double* D, int* member, int* csize) {
+VPK_DEVFN void cluster2_lds(int n) {
     Shared& sh = SH();
+    // the matrix sits at the start of the LDS panel; deriving the pointer from the LDS symbol HERE (not taking it as
+    // an argument of this non-inlined function) is what makes the accesses ds_read / ds_write instead of flat_*
+    double* D = WT();
+    const int ld = n | 1;
+    int* member = cluster_lds_labels(D, n);
+    int* csize = member + n;
     for (int a = tid(); a < n; a += nthreads()) { member[a] = a; csize[a] = 1; }
     block_sync();
     if (wave_id() == 0) {
         unsigned long long act[2];
         act[0] = n >= 64 ? ~0ull : ((1ull << n) - 1);
         act[1] = n > 64 ? (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1)) : 0ull;
-        const int npairs = n * (n - 1) / 2;
         int last_slot = -1;
         bool tie_seen = false, disconnected = false;
         for (int t = 0; t < n - 2; ++t) {
-            double bv = 1e300;
+            // Branch-free search, four rows per trip (their LDS reads are in flight together).  Distances are >= 0, so
+            // their bit patterns order like unsigned integers, and "no edge" (-1.0: sign bit set) is larger than every
+            // distance: one 64-bit integer compare per entry, no validity test.
+            typedef unsigned long long u64;
+            const u64 NONE = 0x7fe0000000000000ull;              // above every finite distance, below -1.0's pattern
+            u64 bk = NONE;
             int bi = 0x7fffffff;
             int ties = 0;
-            int a, b;
-            tri_decode(lane(), a, b);
-            for (int idx = lane(); idx < npairs; idx += WAVE) {
-                const bool on = ((act[a >> 6] >> (a & 63)) & 1ull) && ((act[b >> 6] >> (b & 63)) & 1ull);
-                if (on) {
-                    const double v = D[a * ld + b];
-                    if (!(v < 0)) {
-                        if (v < bv) { bv = v; bi = a * ld + b; ties = 0; }
-                        else if (v == bv) ties = 1;
+            for (int c0 = 0; c0 < n; c0 += WAVE) {
+                const int bq = c0 + lane();
+                for (int a0 = (c0 > 0 ? c0 : 1); a0 < n; a0 += 4) {
+                    u64 k[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int a = a0 + u;
+                        const bool in = a < n && bq < a;
+                        k[u] = in ? __double_as_longlong(D[(in ? a : 0) * ld + (in ? bq : 0)]) : ~0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pos = (a0 + u) * ld + bq;
+                        const bool eq = k[u] == bk && k[u] < NONE;
+                        const bool lt = k[u] < bk;
+                        ties = lt ? 0 : (eq ? 1 : ties);
+                        bi = (lt || (eq && pos < bi)) ? pos : bi;     // equal distances: the smallest position
+                        bk = lt ? k[u] : bk;
                     }
                 }
-                b += WAVE;
-                while (b >= a) { b -= a; ++a; }
             }
+            double bv = bk < NONE ? __longlong_as_double((long long)bk) : 1e300;
+            if (!(bk < NONE)) bi = 0x7fffffff;
             const double myv = bv;
             wave_argmin(bv, bi);
             if (bi == 0x7fffffff) { disconnected = true; break; }
@@ -1500,16 +1522,19 @@ VPK_DEVFN void cluster2_lds(int n, int ld, double* D, int* member, int* csize) {
             const int ma = bi / ld, mb = bi - ma * ld;         // ma > mb; the merged cluster lives in slot ma
             const int na = csize[ma], nb = csize[mb];
             for (int cidx = lane(); cidx < n; cidx += WAVE) {
-                if (cidx == ma || cidx == mb || !((act[cidx >> 6] >> (cidx & 63)) & 1ull)) continue;
+                if (cidx == ma || cidx == mb) continue;
                 const double da = D[ma * ld + cidx], db = D[mb * ld + cidx];
                 double nv;
                 if (da >= 0 && db >= 0)
                     nv = (na * da + nb * db) / (double)(na + nb);  // average_merge
                 else
                     nv = da >= 0 ? da : db;                        // only one side connected (or none: -1)
-                D[ma * ld + cidx] = nv;
+                D[ma * ld + cidx] = nv;                            // (dead slots hold -1 in every row: they stay -1)
                 D[cidx * ld + ma] = nv;
+                D[mb * ld + cidx] = -1.0;                          // slot mb leaves the search
+                D[cidx * ld + mb] = -1.0;
             }
+            if (lane() == 0) { D[ma * ld + mb] = -1.0; D[mb * ld + ma] = -1.0; }
             for (int q = lane(); q < n; q += WAVE)
                 if (member[q] == mb) member[q] = ma;
             wave_sync();
@@ -1614,16 +1639,29 @@ VPK_DEVFN void split_vp(EmCtx& c) {
     gip member = c.idx + N;          // idx has room for 3N ints
     gip csize = c.idx + 2 * N;
     const int ld = nw | 1;
-    const bool in_lds = nw <= CLUSTER_LDS_MAX && (long long)nw * ld + nw <= c.wt_doubles;
+    const bool in_lds = nw <= CLUSTER_LDS_MAX && cluster_lds_doubles(nw) + 3 * nw <= c.wt_doubles;
     double* DL = WT();
-    for (int p = tid(); p < nw * nw; p += nthreads()) {       // Ldist (:568-572)
+    // Ldist (:568-572): 1 - cos(clip(2 acos |cos angle|, -pi/2, pi/2)) for every pair of the set's lines.  The lines'
+    // direction vectors and norms are staged in LDS once (not two dependent global loads per pair), and for 2 phi <
+    // pi/2 the value is 1 - (2 c^2 - 1) = 2 (1 - c)(1 + c) without acos / cos (as cos9_of_cos does for the similarity:
+    // within 2e-16 of the library chain); the clipped branch is numpy's 1 - cos(pi/2) = 1 - 6.123e-17.
+    double* dirs = in_lds ? DL + cluster_lds_doubles(nw) : DL;   // [nw][vx, vy, norm]: behind the LDS matrix, or alone
+    for (int a = tid(); a < nw; a += nthreads()) {
+        cgdp q = c.lp + 4 * (size_t)c.idx[a];
+        const double vx = q[0] - q[2], vy = q[1] - q[3];      // lines_points_cosangle :716-719
+        dirs[3 * a] = vx; dirs[3 * a + 1] = vy; dirs[3 * a + 2] = norm2(vx, vy);
+    }
+    block_sync();
+    for (int p = tid(); p < nw * nw; p += nthreads()) {
         int a = p / nw, b = p % nw;
         double v = 0.0;
         if (a != b) {
-            cgdp qa = c.lp + 4 * (size_t)c.idx[a];
-            cgdp qb = c.lp + 4 * (size_t)c.idx[b];
-            double la[4] = {qa[0], qa[1], qa[2], qa[3]}, lb[4] = {qb[0], qb[1], qb[2], qb[3]};
-            v = 1 - lines_cosangle(la, lb, 2.0);
+            const double cc = clip(fabs(dot2(dirs[3 * a], dirs[3 * a + 1], dirs[3 * b], dirs[3 * b + 1]) /
+                                        (dirs[3 * a + 2] * dirs[3 * b + 2])), -1.0, 1.0);
+            const double COS_PI_4 = 0.70710678118654757;      // cos(pi/4): 2 phi >= pi/2 below it
+            if (cc != cc) v = cc;
+            else if (!(cc > COS_PI_4)) v = 1 - 6.123233995736766e-17;
+            else v = 2 * ((1.0 - cc) * (1.0 + cc));
         }
         // (Ldist is bitwise symmetric, so sklearn's edge test D + D^T != 0 is v + v != 0)
         if (in_lds) DL[a * ld + b] = (a == b || !(v + v != 0.0)) ? -1.0 : v;
@@ -1631,9 +1669,8 @@ VPK_DEVFN void split_vp(EmCtx& c) {
     }
     block_sync();
     if (in_lds) {
-        int* lmember = reinterpret_cast<int*>(DL + (size_t)nw * ld);
-        int* lcsize = lmember + nw;
-        cluster2_lds(nw, ld, DL, lmember, lcsize);
+        cluster2_lds(nw);
+        const int* lmember = cluster_lds_labels(DL, nw);
         for (int q = tid(); q < nw; q += nthreads()) member[q] = lmember[q];
         block_sync();
     } else {

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(EM_BOUND) void cluster2_kernel(int n, double* D, in
     if (tid() == 0) sh.flags = 0;
     block_sync();
     const int ld = n | 1;
-    if (n <= CLUSTER_LDS_MAX && (long long)n * ld + n <= WT_DOUBLES) {   // same choice as split_vp
+    if (n <= CLUSTER_LDS_MAX && cluster_lds_doubles(n) <= WT_DOUBLES) {   // same choice as split_vp
         double* DL = WT();
         for (int p = tid(); p < n * n; p += nthreads()) {
             const int a = p / n, b = p % n;
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(EM_BOUND) void cluster2_kernel(int n, double* D, in
             DL[a * ld + b] = (a == b || !(v + D[(size_t)b * n + a] != 0.0)) ? -1.0 : v;
         }
         block_sync();
-        int* lmember = reinterpret_cast<int*>(DL + (size_t)n * ld);
-        cluster2_lds(n, ld, DL, lmember, lmember + n);
+        cluster2_lds(n);
+        const int* lmember = cluster_lds_labels(DL, n);
         for (int q = tid(); q < n; q += nthreads()) member[q] = lmember[q];
         block_sync();
     } else {

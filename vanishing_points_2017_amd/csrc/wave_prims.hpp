@@ -57,10 +57,27 @@ VPK_DEV double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Cross-lane moves inside a row of 16 lanes by DPP (row_ror:n, one VALU instruction, no LDS crossbar); a rotation
+// serves as well as a butterfly for associative + commutative reductions.  The two cross-row steps (16, 32) stay on
+// __shfl_xor.  Used for the exact reductions only (integer sums, lexicographic minima): their result does not
+// depend on the order of the operations.  (__shfl_xor = ds_bpermute costs ~100 cycles per dword and step: a 64-lane
+// arg-min of a double + index took ~2000 cycles, which made the one-wave clustering reduction-bound.)
+template <int N> VPK_DEV int row_ror_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false);
+}
+template <int N> VPK_DEV double row_ror_f64(double v) {
+    const int lo = row_ror_i32<N>(__double2loint(v)), hi = row_ror_i32<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// After the four in-row steps every lane of a row holds its row's result; the four rows are combined through
+// v_readlane (SGPR reads of lanes 0 / 16 / 32 / 48): the result is wave-uniform and costs no LDS-crossbar trip.
 VPK_DEV int wave_sum_int(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += row_ror_i32<8>(v);
+    v += row_ror_i32<4>(v);
+    v += row_ror_i32<2>(v);
+    v += row_ror_i32<1>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 // NaN-propagating max (numpy.max semantics): any NaN lane makes the result NaN
 VPK_DEV double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
@@ -104,15 +121,26 @@ template <int G> VPK_DEV int group_max_int(int v) {
     return v;
 }
 // lexicographic (value, index) minimum; NaN values never win
+VPK_DEV void argmin_take(double& v, int& idx, double u, int j) {
+    const bool take = (u < v) || (u == v && j < idx) || (v != v && u == u);
+    v = take ? u : v;
+    idx = take ? j : idx;
+}
+VPK_DEV double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 VPK_DEV void wave_argmin(double& v, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double u = __shfl_xor(v, o);
-        int j = __shfl_xor(idx, o);
-        bool take = (u < v) || (u == v && j < idx) || (v != v && u == u);
-        v = take ? u : v;
-        idx = take ? j : idx;
-    }
+    argmin_take(v, idx, row_ror_f64<8>(v), row_ror_i32<8>(idx));
+    argmin_take(v, idx, row_ror_f64<4>(v), row_ror_i32<4>(idx));
+    argmin_take(v, idx, row_ror_f64<2>(v), row_ror_i32<2>(idx));
+    argmin_take(v, idx, row_ror_f64<1>(v), row_ror_i32<1>(idx));
+    double bv = readlane_f64(v, 0);
+    int bi = __builtin_amdgcn_readlane(idx, 0);
+    argmin_take(bv, bi, readlane_f64(v, 16), __builtin_amdgcn_readlane(idx, 16));
+    argmin_take(bv, bi, readlane_f64(v, 32), __builtin_amdgcn_readlane(idx, 32));
+    argmin_take(bv, bi, readlane_f64(v, 48), __builtin_amdgcn_readlane(idx, 48));
+    v = bv;
+    idx = bi;
 }
 // lanes of this wave for which pred holds (bit i = lane i), and helpers for ordered compaction
 VPK_DEV unsigned long long wave_ballot(bool pred) { return __ballot(pred); }
