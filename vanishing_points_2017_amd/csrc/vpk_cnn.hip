@@ -158,8 +158,14 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
         bbase = in + (size_t)b * d.IC * d.Hp * d.Wp;
         boff = (unsigned)(oh * d.Wp + ow) * 4u;
     } else if (DENSE) {
+        // dense layers: the activation rows are K-contiguous, so the B tile is fetched as 16-byte pieces ALONG K --
+        // one piece = 4 consecutive k of one column; a DMA instruction = one k-quad x 64 consecutive columns.  (4-byte
+        // pieces, one k row x 64 columns per instruction, touch 64 cache lines for 256 bytes: the texture-address
+        // path then takes as long as the stage's MFMAs.)  The tile lands in LDS as [k quad][column][4].
         bbase = in;
-        boff = (unsigned)n * (unsigned)d.K * 4u;
+        int nd = nt * BN + (wave & 1) * 64 + lane;
+        nd = nd < d.N ? nd : d.N - 1;
+        boff = (unsigned)nd * (unsigned)d.K * 4u;
     } else {
         const int b_first = (nt * BN) / ohw;          // first image of the tile (scalar)
         const int b = n / ohw;
@@ -189,18 +195,23 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
             if (idx0 < A_F4)
                 dma16(aoff[r], abase, __builtin_amdgcn_readfirstlane(as_base + (unsigned)((buf * BK * BM + idx0 * 4) * 4)));
         }
+        if (DENSE) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                            // this wave's two k quads (of four), its half of the columns
+                const int kq = (wave >> 1) * 2 + q;
+                dma16(boff, bbase + k0 + 4 * kq, __builtin_amdgcn_readfirstlane(
+                          bs_base + (unsigned)((buf * BK * BN + (kq * BN + (wave & 1) * 64) * 4) * 4)));
+            }
+            return;
+        }
         const int kb = k0 + kset * 8;
         unsigned e[8];
-        if (!DENSE) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = ktab[kb + q];        // wave-uniform byte offsets: scalar loads
-        }
+        for (int q = 0; q < 8; ++q) e[q] = ktab[kb + q];            // wave-uniform byte offsets: scalar loads
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const char* src = DENSE ? (const char*)(bbase + kb + q) : (const char*)bbase + e[q];
-            dma4(boff, src, __builtin_amdgcn_readfirstlane(
+        for (int q = 0; q < 8; ++q)
+            dma4(boff, (const char*)bbase + e[q], __builtin_amdgcn_readfirstlane(
                                 bs_base + (unsigned)(((buf * BK + kset * 8 + q) * BN + (wave & 1) * 64) * 4)));
-        }
     };
     // DMA instructions one thread issues per stage (waves whose A piece falls outside issue one less)
     constexpr int A_FULL = A_F4 / CONV_THREADS;                    // pieces every wave issues
@@ -208,9 +219,10 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
     auto wait_stage = [&](bool keep_one_in_flight) {
         // wait until only the newest stage's DMA (if any) is still outstanding for this wave
         const bool extra = A_PARTIAL && (A_FULL * CONV_THREADS + wave * 64 < A_F4);
+        constexpr int B_PER = DENSE ? 2 : 8;                       // B-tile DMA instructions per thread and stage
         if (!keep_one_in_flight) wait_vmcnt<0>();
-        else if (extra) wait_vmcnt<A_FULL + 1 + 8>();
-        else wait_vmcnt<A_FULL + 8>();
+        else if (extra) wait_vmcnt<A_FULL + 1 + B_PER>();
+        else wait_vmcnt<A_FULL + B_PER>();
     };
 
     const int arow = wm * TM * 32 + (lane & 31);
@@ -242,7 +254,9 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = As[buf][k2 + khalf][arow + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][k2 + khalf][bcol + j * 32];
+            for (int j = 0; j < TN; ++j)
+                bf[j] = DENSE ? (&Bs[buf][0][0])[(((k2 + khalf) >> 2) * BN + bcol + j * 32) * 4 + ((k2 + khalf) & 3)]
+                              : Bs[buf][k2 + khalf][bcol + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
