@@ -21,6 +21,7 @@ XCDS = 8
 def short(name):
     for tag, s in (("ILi2ELi2ELi2ELi2ELb0ELb0", "conv_gemm_dma<2,2,2,2> (conv2/3/5)"),
                    ("ILi1ELi4ELi3ELi1ELb0ELb1", "conv_gemm_dma<1,4,3,1,fused> (conv1+norm1+pool1)"),
+                   ("conv1_direct_kernel", "conv1_direct_kernel (conv1+norm1+pool1)"),
                    ("ILi1ELi4ELi3ELi1ELb0ELb0", "conv_gemm_dma<1,4,3,1> (conv4)"),
                    ("ILi2ELi2ELi2ELi2ELb1ELb0", "conv_gemm_dma<2,2,2,2,dense> (fc6/7/8)"),
                    ("em_batch_kernel", "em_batch_kernel"), ("lrn5_pool3s2", "lrn5_pool3s2_tiled (norm2+pool2)")):
