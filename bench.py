@@ -377,6 +377,13 @@ def main():
         if pm:      # counter view of the same kernel inside the bench: fraction of SIMD-cycles with a busy matrix pipe, and the
                     # shader clock it ran at (the 157.3 TF peak assumes 2.4 GHz; under this load the part clocks lower)
             roof_cnn["pmc"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"], "source": mfma_src}
+            pa = (mfma.get("cnn_alone_B102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)")
+            if pa and count == 102:     # the same kernel without the EM beside it (profiled run of the CNN alone, 12 timed passes)
+                flop3 = sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
+                roof_cnn["alone"] = {"achieved": flop3 / (pa["avg_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                     "frac": flop3 / (pa["avg_ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                     "mfma_util": pa["mfma_util"], "shader_clock_ghz": pa["shader_clock_ghz"],
+                                     "note": "average over the conv2 / conv3 / conv5 launches of the kernel, CNN alone"}
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step,
         # each EM stream one batch every n_lanes steps
         roof = roof_em if (em_ms / n_lanes >= cnn_ms * 1.5 or args.workload == "stress") else roof_cnn
