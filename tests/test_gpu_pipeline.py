@@ -115,3 +115,26 @@ def test_image_files_through_the_whole_call_surface(tmp_path):
         assert d['cnn_prediction'].shape == (20, 20)
         res = d['EM_result']
         assert res is not None and res['vp'] is not None and res['vp_assoc'].shape[0] == seg.shape[0]
+
+
+@pytest.mark.parametrize("mode", ["lanes", "slice", "serial"])
+def test_bench_modes_produce_a_valid_line(mode):
+    """bench.py end to end (small batch): one JSON line with the contract's fields, every image refined, and the EM
+    kernel's results on the first scenes equal to the reference's stored results -- in each scheduling mode."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--images", "12",
+                        "--no-cpu-baseline", "--em-mode", mode], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "parity", "ranks_seen"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0
+    assert line["em_stats"]["ok_images"] == 12
+    assert line["parity"]["images"] == 12 and line["parity"]["all_criteria"] == 12
+    assert line["roofline"]["bound"] in ("mfma", "hbm") and 0 < line["roofline"]["frac"] < 1
