@@ -164,13 +164,17 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     device = args.gpu
+    backend = os.environ.get("VPK_DIST_BACKEND", "nccl")      # "gloo": ranks may share a GPU (tests on a one-GPU box)
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        device = local_rank
+        device = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(device)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
     if rank == 0:    # one rank writes the input pickles; the others read them after the barrier
         dataset = synthetic_dataset(name, args.result_dir, args.count, args.update_datafiles or args.update_datalist)
     if dist is not None:
@@ -189,7 +193,7 @@ def main(argv=None):
     start = 25 if (args.yud or args.ecd) else 0                              # :69
     t0 = time.time()
     tdev = None
-    if dist is not None:
+    if dist is not None and backend == "nccl":
         import torch
         tdev = torch.device("cuda", device)
     auc, errors, _ = run_sharded(dataset, rank, world, dist, device=device, start=start, run_em=args.run_em,
