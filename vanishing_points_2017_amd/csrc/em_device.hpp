@@ -448,7 +448,6 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 // :230) in ONE pass over the pairs: the closest distance is shared by both.  One wave per row,
 // lanes over columns (coalesced lsim stores).  Also lines_angles (:765-776).
 VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
-    Shared& sh = SH();
     const int N = c.N;
     // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
     double* ks = SCRATCH() + wave_id() * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank

@@ -247,7 +247,6 @@ __global__ void em_rotate_kernel(int* ctr, int cap_waiting) {
 __global__ __launch_bounds__(EM_BOUND) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
                                                               double* lsim_out, double* lscore_out,
                                                               double* langle_out) {
-    VPK_SHARED_DECL;
     EmCtx c;
     c.N = n; c.lp = (cgdp)lp; c.wt_doubles = WT_DOUBLES;
     c.prm.use_weights = 1;
