@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--em-wgs", type=int, default=-1,
                     help="workgroups (CUs) per EM launch; default: images/3 for yud (the launch lasts as long as its "
                          "slowest image either way, and the CNN keeps the other CUs), one per image for stress")
+    ap.add_argument("--cnn-fusion", type=int, default=1, choices=[0, 1, 2],
+                    help="conv1 + norm1 + pool1: 1 = direct-convolution kernel (default), 2 = implicit-GEMM kernel with the fused "
+                         "epilogue, 0 = separate kernels")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +240,7 @@ def main():
     mean = cnn.synthetic_mean(0)
     net = cnn.Net(weights, mean, device=local_rank, runtime=rt_cnn)
     net.set_profiling(True)
+    net.set_fusion(args.cnn_fusion)
     params = gem._params(kw)
     d = gem.upload_batch(rt, scenes)                     # inputs resident in HBM before the timed region
     l_pristine = d["l"].clone()
