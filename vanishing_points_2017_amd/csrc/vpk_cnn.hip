@@ -396,11 +396,15 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
 // Neighbouring patches share one conv row / column (1.24x the MFMA work); conv1's 0.59 GB blob (B = 102) never exists.
 // --------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x2 lds_cf32x2;
+typedef __attribute__((address_space(3))) const float lds_cfloat;
 constexpr int C1D_THREADS = 512;
-constexpr int C1D_ALD = 112;                          // row stride of the weight panel in LDS: the four k rows a wave reads
+constexpr int C1D_ALD = 96;                           // row stride of the weight panel in LDS: the four k rows a wave reads
                                                       // at once (k = 4s + lane/16) fall into disjoint bank quarters
 constexpr int C1D_PY = 9, C1D_PX = 19, C1D_PXL = 20;  // rows / columns of one phase of the raw patch; LDS row stride
 constexpr int C1D_XS = 16 * C1D_PY * C1D_PXL;         // floats per patch buffer
+constexpr int C1D_KS = 31;                            // K steps of 4 taps: 121 taps -> 124 (rows 121..127 of the packed panel are 0)
 constexpr int C1D_LD = 132;                           // row stride of the output patch [channel][column]: the four row groups
                                                       // a wave writes at once (rows 4 apart) hit disjoint bank quarters
 
@@ -411,152 +415,246 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+#ifdef C1D_TIME
+__device__ long long c1d_dbg[256 * 8 * 8];
+#define C1D_T(i) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; }
+#else
+#define C1D_T(i)
+#endif
 __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                                       int OHp, int OWp, int opad, int* __restrict__ tile_counter,
                                                                       int total_tiles) {
     __shared__ __attribute__((aligned(16))) float As[128 * C1D_ALD];
-    __shared__ __attribute__((aligned(16))) float Xs[2][C1D_XS];
-    __shared__ __attribute__((aligned(16))) float Cs[96][C1D_LD];
+    __shared__ __attribute__((aligned(16))) float Xs[C1D_XS];
+    __shared__ __attribute__((aligned(16))) float Cs[96 + 4][C1D_LD];  // channel c in row c + 2; rows 0, 1, 98, 99 stay 0 (LRN halo)
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    for (int idx = tid; idx < 128 * 96; idx += C1D_THREADS) As[(idx / 96) * C1D_ALD + idx % 96] = wp[idx];   // [Kp = 128][Mp = 96]
-    // this lane's column of the tile and the LDS offsets of the taps k = 4 s + g it feeds to the matrix cores
+    if (tid < C1D_LD) Cs[0][tid] = Cs[1][tid] = Cs[98][tid] = Cs[99][tid] = 0.f;
+    for (int idx = tid; idx < 128 * 96; idx += C1D_THREADS) {            // global [Kp = 128][Mp = 96] -> LDS [k][m % 16][m / 16]
+        const int k = idx / 96, m = idx - k * 96;
+        As[k * C1D_ALD + (m & 15) * 6 + (m >> 4)] = wp[idx];
+    }
+    // A operands: in K step s2 this lane feeds row k = 4 s2 + g, channels 16 i + c16 (i = 0..5) = six consecutive floats,
+    // read as three 8-byte words at compile-time offsets from three base registers.  (The bases are made opaque: the
+    // compiler would otherwise fuse the reads into ds_read2 forms, whose 8-bit offsets need a new base register -- one
+    // VALU add, which costs matrix-pipe time here -- in every step.)
+    lds_cf32x2* a0 = (lds_cf32x2*)&As[g * C1D_ALD + c16 * 6];
+    lds_cf32x2* a1 = a0 + 1;
+    lds_cf32x2* a2 = a0 + 2;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+    // B operands: this lane's column of the tile and the LDS address of tap k = 4 s2 + g for it
     int col = wave * 16 + c16;
     col = col < C1_PR * C1_PC ? col : C1_PR * C1_PC - 1;                 // columns 119..127 repeat the last position, unused
     const int colbase = (col / C1_PC) * C1D_PXL + col % C1_PC;
-    int ko[32];
+    lds_cfloat* kb[C1D_KS];
 #pragma unroll
-    for (int s2 = 0; s2 < 32; ++s2) {
+    for (int s2 = 0; s2 < C1D_KS; ++s2) {
         const int k = 4 * s2 + g;
         const int kh = k / 11, kw = k - kh * 11;
-        ko[s2] = k < 121 ? (((kh & 3) * 4 + (kw & 3)) * C1D_PY + (kh >> 2)) * C1D_PXL + (kw >> 2) : 0;   // rows 121..127 of the panel are 0
+        kb[s2] = (lds_cfloat*)&Xs[colbase + (k < 121 ? (((kh & 3) * 4 + (kw & 3)) * C1D_PY + (kh >> 2)) * C1D_PXL + (kw >> 2)
+                                                      : 0)];           // rows 121..127 of the panel are 0
     }
-    float bl[6][4];                                                      // bias of the 24 channels this lane's accumulators hold
-#pragma unroll
+    f32x4 bl[6];                                                         // bias of the 24 channels this lane's accumulators hold:
+#pragma unroll                                                           //  the C operand of a tile's first MFMAs
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bl[i][r] = bias[16 * i + 4 * g + r];
     constexpr int PRE = (16 * C1D_PY * C1D_PX + C1D_THREADS - 1) / C1D_THREADS;   // raw-patch floats per thread (6)
-    int pph[PRE], pyl[PRE], pxl[PRE], pdst[PRE];       // per-thread constants of the raw-patch copy: element u = (phase, row, column)
+    constexpr int PRE_LAST = 16 * C1D_PY * C1D_PX - (PRE - 1) * C1D_THREADS;      // threads that hold a sixth one
+    // per-thread constants of the raw-patch copy, element u = (phase p, row, column): offset from the patch origin inside
+    // the image's 16 stacked phase planes, LDS index, and (row << 8 | column) for the clamped loads of border patches
+    int poff[PRE], pdst[PRE], pyx[PRE];
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const int e = tid + u * C1D_THREADS;
-        const int p = e / (C1D_PY * C1D_PX), rem = e - p * (C1D_PY * C1D_PX);
-        pph[u] = p * C1_PW;                            // first row of phase plane p inside the image's 16 stacked planes
-        pyl[u] = rem / C1D_PX;
-        pxl[u] = rem % C1D_PX;
-        pdst[u] = e < 16 * C1D_PY * C1D_PX ? (p * C1D_PY + pyl[u]) * C1D_PXL + pxl[u] : -1;
+        const int ph = e / (C1D_PY * C1D_PX), rem = e - ph * (C1D_PY * C1D_PX);
+        const int py = rem / C1D_PX, px = rem - py * C1D_PX;
+        poff[u] = (ph * C1_PW + py) * C1_PW + px;
+        pdst[u] = (ph * C1D_PY + py) * C1D_PXL + px;
+        pyx[u] = (ph << 16) | (py << 8) | px;
     }
     auto patch_load = [&](int tile, float (&v)[PRE]) {
         const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
-        const float* base = in + (size_t)b * 16 * C1_PW * C1_PW;
         const int y0 = (C1_PR - 1) * pr, x0 = (C1_PC - 1) * pc;
+        const float* img = in + (size_t)b * 16 * C1_PW * C1_PW;
+        if (pr < C1_TR - 1 && pc < C1_TC - 1) {        // the patch lies inside the planes: scalar base + per-thread offset
+            const float* base = img + y0 * C1_PW + x0;
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {                // overhang is clamped (those taps only reach conv outputs that no
-            const int y = y0 + pyl[u], x = x0 + pxl[u];   //  pooling window uses)
-            const int yy = pph[u] + (y < C1_PW ? y : C1_PW - 1), xx = x < C1_PW ? x : C1_PW - 1;
-            v[u] = pdst[u] >= 0 ? base[(size_t)yy * C1_PW + xx] : 0.f;
+            for (int u = 0; u < PRE; ++u) v[u] = (u < PRE - 1 || tid < PRE_LAST) ? base[poff[u]] : 0.f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {            // overhang is clamped (those taps only reach conv outputs that no
+                const int y = y0 + ((pyx[u] >> 8) & 255), x = x0 + (pyx[u] & 255);   //  pooling window uses)
+                const int yy = (pyx[u] >> 16) * C1_PW + (y < C1_PW ? y : C1_PW - 1), xx = x < C1_PW ? x : C1_PW - 1;
+                v[u] = (u < PRE - 1 || tid < PRE_LAST) ? img[yy * C1_PW + xx] : 0.f;
+            }
         }
     };
-    auto patch_store = [&](int buf, const float (&v)[PRE]) {
+    auto patch_store = [&](const float (&v)[PRE]) {
 #pragma unroll
         for (int u = 0; u < PRE; ++u)
-            if (pdst[u] >= 0) Xs[buf][pdst[u]] = v[u];
+            if (u < PRE - 1 || tid < PRE_LAST) Xs[pdst[u]] = v[u];
     };
     // dynamic tile queue (CUs held by other streams' kernels make static shares uneven); the index of the tile after
     // next is fetched one tile ahead, so the atomic's round trip is never waited for
     int tile = blockIdx.x;
     float pre[PRE];
-    if (tile < total_tiles) { patch_load(tile, pre); patch_store(0, pre); }
+    if (tile < total_tiles) { patch_load(tile, pre); patch_store(pre); }
     if (tid == 0) s_next[0] = atomicAdd(tile_counter, 1) + (int)gridDim.x;
     __syncthreads();
-    int next = s_next[0];
+    int next = __builtin_amdgcn_readfirstlane(s_next[0]);
+    // Software pipeline across tiles: the LRN and the pooling of tile i-1 are issued between the MFMA steps of tile i, so
+    // that per tile only "accumulators -> Cs" and "Cs -> LRN inputs" stand alone between barriers.  f32 MFMAs run at the
+    // packed-f32 vector rate and do NOT overlap with VALU work of either wave of the SIMD (measured: a phase costs the
+    // MFMA cycles of both waves PLUS their VALU cycles), so the epilogue is written for instruction count: packed f32
+    // math, v_max3 / v_med3, unconditional halo reads, bias as the accumulators' initial value.
+    const int lp = tid & 127, lc0 = (tid >> 7) * 24;                 // LRN: this thread's column and its first channel
+    const int pk = tid < 96 * C1_QR ? tid / C1_QR : 95, ppy = tid % C1_QR;   // pooling: (channel, pooled row of the patch)
+    const float* pool_src = &Cs[pk + 2][2 * ppy * C1_PC];
+    f32x2 raw2[14];                                                  // ReLU'd conv outputs of the PREVIOUS tile: 24 channels + halo
+#pragma unroll
+    for (int k = 0; k < 14; ++k) raw2[k] = f32x2{0.f, 0.f};
+    int ptile = -1;                                                  // the tile whose epilogue is pending
+    // LRN across channels (deploy.prototxt:34-44), in place: out = v * (1 + alpha / 5 * sum of the 5 squares)^-0.75
+    f32x2 sqa, sqb;                                                  // rolling squares of raw[2j .. 2j+3] and their pair sums
+    float psa, psb;
+    auto lrn_squares = [&]() {
+#pragma clang fp contract(off)
+        sqa = raw2[0] * raw2[0]; psa = sqa[0] + sqa[1];
+        sqb = raw2[1] * raw2[1]; psb = sqb[0] + sqb[1];
+    };
+    auto lrn_two = [&](int j) {                                      // channels lc0 + 2 j, lc0 + 2 j + 1 (window = raw[2j .. 2j+5])
+#pragma clang fp contract(off)     // the same roundings in the main loop and in the drain copy of this code (a tile's bits must
+                                   // not depend on which of the two it went through)
+        const f32x2 sqc = raw2[j + 2] * raw2[j + 2];
+        const float c = psb + sqc[0];
+        f32x2 w = {c + psa, (c + sqa[1]) + sqc[1]};
+        const f32x2 sc = __builtin_elementwise_fma(w, f32x2{1e-4f / 5.f, 1e-4f / 5.f}, f32x2{1.f, 1.f});
+        const float r0 = __builtin_amdgcn_rsqf(sc[0]), r1 = __builtin_amdgcn_rsqf(sc[1]);   // v_rsq_f32 / v_sqrt_f32: 1 ulp, sc >= 1
+        const f32x2 y = raw2[j + 1] * (f32x2{r0, r1} * f32x2{__builtin_amdgcn_sqrtf(r0), __builtin_amdgcn_sqrtf(r1)});
+        Cs[lc0 + 2 * j + 2][lp] = y[0];
+        Cs[lc0 + 2 * j + 3][lp] = y[1];
+        sqa = sqb; psa = psb; sqb = sqc; psb = sqc[0] + sqc[1];
+    };
+    // 3x3 / stride 2 max pool: one thread per (channel, pooled row) = 8 outputs from 3 x 17 values; the column maxima are
+    // shared by neighbouring windows.  Caffe clips windows at the blob's edge: positions beyond it hold 0 here (see the
+    // v_med3 below) and every real value is >= 0 after the ReLU, so the plain maximum equals the clipped window's.
+    float cm[C1_PC], pv[2][3];
+    auto pool_fetch = [&](int q) {
+        pv[q & 1][0] = pool_src[q]; pv[q & 1][1] = pool_src[C1_PC + q]; pv[q & 1][2] = pool_src[2 * C1_PC + q];
+    };
+    auto pool_col = [&](int q) { cm[q] = __builtin_fmaxf(__builtin_fmaxf(pv[q & 1][0], pv[q & 1][1]), pv[q & 1][2]); };
+    auto pool_out = [&](int t) {
+        const int pc = t % C1_TC, pr = (t / C1_TC) % C1_TR, b = t / (C1_TC * C1_TR);
+        const int ph = C1_QR * pr + ppy;
+        if (tid < 96 * C1_QR && ph < C1_POOL) {
+            float* o = out + ((size_t)b * 96 + pk) * OHp * OWp + (size_t)(ph + opad) * OWp + C1_QC * pc + opad;
+#pragma unroll
+            for (int px = 0; px < C1_QC; ++px)
+                if (C1_QC * pc + px < C1_POOL) o[px] = __builtin_fmaxf(__builtin_fmaxf(cm[2 * px], cm[2 * px + 1]), cm[2 * px + 2]);
+        }
+    };
+    const int ccol = wave * 16 + c16;                                // this lane's column of the patch = position (crow, cc17)
+    const int crow = ccol / C1_PC, cc17 = ccol - crow * C1_PC;
+#ifdef C1D_TIME
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; tile < total_tiles; ++it) {
-        const int buf = it & 1;
         int nx = 0;
         if (tid == 0) nx = atomicAdd(tile_counter, 1);            // consumed at the end of the tile: its round trip is never waited for
         if (next < total_tiles) patch_load(next, pre);              // in flight under the MFMAs below
         f32x4 acc[6];
+        // The operands of K step s + 1 are requested before the MFMAs of step s are issued (the scheduling barriers keep
+        // the compiler from sinking the LDS reads back down to their first use, which leaves one LDS round trip exposed
+        // in front of every pair of MFMAs).
+        f32x2 av[2][3];
+        float bv[2];
+        auto operands = [&](int s2) {
+            bv[s2 & 1] = *kb[s2];
+            av[s2 & 1][0] = a0[2 * s2 * C1D_ALD]; av[s2 & 1][1] = a1[2 * s2 * C1D_ALD]; av[s2 & 1][2] = a2[2 * s2 * C1D_ALD];
+        };
+        operands(0);
+        lrn_squares();
+        // ---- first half of the K loop, with the previous tile's LRN (on the first tile: of zeros, unused) ----
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* xs = &Xs[buf][colbase];
-        const float* as = &As[g * C1D_ALD + c16];
-#pragma unroll
-        for (int s2 = 0; s2 < 32; ++s2) {
-            const float bv = xs[ko[s2]];
+        for (int s2 = 0; s2 < 16; ++s2) {
+            operands(s2 + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[4 * s2 * C1D_ALD + 16 * i], bv, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2 & 1][i >> 1][i & 1], bv[s2 & 1], s2 ? acc[i] : bl[i], 0, 0, 0);
+            if (s2 < 12) lrn_two(s2);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (next < total_tiles) patch_store(buf ^ 1, pre);          // that buffer was last read several barriers ago
-        // ---- epilogue: bias + ReLU -> LDS patch -> LRN in place -> max pool -> store ----
-        const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
-        const int ccol = wave * 16 + c16;
+        C1D_T(0)
+        lds_barrier();                                              // the normalised patch is complete
+        C1D_T(1)
+        // ---- second half, with the previous tile's pooling (its LDS reads one step ahead of their use) ----
+        pool_fetch(0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int s2 = 16; s2 < C1D_KS; ++s2) {
+            if (s2 + 1 < C1D_KS) operands(s2 + 1);
+            if (s2 - 15 < C1_PC) pool_fetch(s2 - 15);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                           // accumulator register r holds row 4 (lane / 16) + r
-                const float v = acc[i][r] + bl[i][r];
-                Cs[16 * i + 4 * g + r][ccol] = v > 0.f ? v : 0.f;
-            }
+            for (int i = 0; i < 6; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2 & 1][i >> 1][i & 1], bv[s2 & 1], acc[i], 0, 0, 0);
+            pool_col(s2 - 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = C1D_KS - 15; q < C1_PC; ++q) pool_fetch(q);
+#pragma unroll
+        for (int q = C1D_KS - 16; q < C1_PC; ++q) pool_col(q);
+        if (ptile >= 0) pool_out(ptile);
+        C1D_T(2)
+        lds_barrier();                                              // Cs and the raw patch are free
+        C1D_T(3)
+        if (next < total_tiles) patch_store(pre);
+        // ---- ReLU -> LDS patch [channel][column] (bias is already in); positions outside the conv blob become 0 ----
+        {
+            const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR;
+            const bool inside = ccol < C1_PR * C1_PC && (C1_PR - 1) * pr + crow < C1_OUT && (C1_PC - 1) * pc + cc17 < C1_OUT;
+            const float cap = inside ? 3.402823466e38f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                         // accumulator register r holds row 4 (lane / 16) + r
+                    Cs[16 * i + 4 * g + r + 2][ccol] = __builtin_amdgcn_fmed3f(acc[i][r], 0.f, cap);
+        }
+        C1D_T(4)
         lds_barrier();
-        {   // LRN across channels (deploy.prototxt:34-44): four threads per column, 24 channels each.  All 28 raw values
-            // (24 + a halo of 2 on each side) are read before anything is written: no read-after-write chain through LDS,
-            // and the 24 rsqrt / sqrt chains are independent.
-            const int p = tid & 127, c0 = (tid >> 7) * 24;
-            float raw[28];
+        C1D_T(5)
 #pragma unroll
-            for (int k = 0; k < 28; ++k) {
-                const int c = c0 - 2 + k;
-                raw[k] = (c >= 0 && c < 96) ? Cs[c < 0 ? 0 : (c > 95 ? 95 : c)][p] : 0.f;
-            }
-            lds_barrier();                                          // every raw value has been read
-            const float an = 1e-4f / 5.f;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                const float sc = 1.f + an * (raw[k] * raw[k] + raw[k + 1] * raw[k + 1] + raw[k + 2] * raw[k + 2] +
-                                             raw[k + 3] * raw[k + 3] + raw[k + 4] * raw[k + 4]);
-                const float rr = __builtin_amdgcn_rsqf(sc);           // v_rsq_f32 / v_sqrt_f32 (1 ulp; sc >= 1): the IEEE-exact
-                Cs[c0 + k][p] = raw[k + 2] * (rr * __builtin_amdgcn_sqrtf(rr));   // library forms cost ~25 VALU instructions each
-            }
-        }
-        lds_barrier();
-        if (tid < 96 * C1_QR) {     // 3x3 / stride 2 max pool: one thread per (channel, pooled row) = 8 outputs from 3 x 17 values;
-                                    // the column maxima are shared by neighbouring windows (Caffe clips windows at the blob's edge)
-            const int k = tid / C1_QR, py = tid - k * C1_QR;
-            const int ph = C1_QR * pr + py;
-            const int rows = C1_OUT - (C1_PR - 1) * pr - 2 * py;    // valid rows of this window band (>= 3 away from the border)
-            const int cols = C1_OUT - (C1_PC - 1) * pc;             // valid columns of the patch
-            if (ph < C1_POOL) {
-                const float NEG = -3.402823466e38f;
-                const float* c = &Cs[k][2 * py * C1_PC];
-                float cm[C1_PC];
-#pragma unroll
-                for (int q = 0; q < C1_PC; ++q) {
-                    float m = c[q];
-                    const float v1 = c[C1_PC + q], v2 = c[2 * C1_PC + q];
-                    m = (rows > 1 && v1 > m) ? v1 : m;
-                    m = (rows > 2 && v2 > m) ? v2 : m;
-                    cm[q] = q < cols ? m : NEG;
-                }
-                float* o = out + ((size_t)b * 96 + k) * OHp * OWp + (size_t)(ph + opad) * OWp + C1_QC * pc + opad;
-#pragma unroll
-                for (int px = 0; px < C1_QC; ++px) {
-                    float m = cm[2 * px];
-                    m = cm[2 * px + 1] > m ? cm[2 * px + 1] : m;
-                    m = cm[2 * px + 2] > m ? cm[2 * px + 2] : m;
-                    if (C1_QC * pc + px < C1_POOL) o[px] = m;
-                }
-            }
-        }
+        for (int k = 0; k < 14; ++k)                                // all read before anything is written in place; rows 0, 1, 98, 99
+            raw2[k] = f32x2{Cs[lc0 + 2 * k][lp], Cs[lc0 + 2 * k + 1][lp]};   //  are the zero halo
         if (tid == 0) s_next[(it + 1) & 1] = nx + (int)gridDim.x;
-        lds_barrier();                                              // Cs is free; the next raw patch and tile index are visible
+        C1D_T(6)
+        lds_barrier();                                              // every raw value has been read; next tile index visible
+        C1D_T(7)
+        ptile = tile;
         tile = next;
-        next = s_next[(it + 1) & 1];
+        next = __builtin_amdgcn_readfirstlane(s_next[(it + 1) & 1]);
     }
+    if (ptile >= 0) {                                               // drain: the last tile's epilogue
+        lrn_squares();
+#pragma unroll
+        for (int j = 0; j < 12; ++j) lrn_two(j);
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < C1_PC; ++q) { pool_fetch(q); pool_col(q); }
+        pool_out(ptile);
+    }
+#ifdef C1D_TIME
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 8; ++i) c1d_dbg[(blockIdx.x * 8 + wave) * 8 + i] = tacc[i];
+#endif
 }
+#ifdef C1D_TIME
+extern "C" int vpk_dbg_c1d(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c1d_dbg), sizeof(long long) * 256 * 8 * 8); }
+#endif
 
 // conv1 input: float(uint8 raster) - mean (evaluation.py:35), written as the 16 stride-4 phase planes
 //   P[py][px][Y][X] = x[4Y + py][4X + px]   (125 x 125 each)
