@@ -248,20 +248,30 @@ __global__ __launch_bounds__(CONV_THREADS, WPC) void conv_gemm_dma_kernel(ConvDi
     for (int t = 0; t < nk; ++t) {
         const int buf = t % NST;
         if (t + AHEAD < nk) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
+        // operands of k step k2 + 2 are requested before the MFMAs of step k2 are issued (left to itself the compiler
+        // puts each step's LDS reads right in front of their use: one exposed LDS round trip per step and wave)
+        float af[2][TM], bf[2][TN];
+        auto operands = [&](int k2) {
+            const int o = (k2 >> 1) & 1;
 #pragma unroll
-        for (int k2 = 0; k2 < BK; k2 += 2) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][k2 + khalf][arow + i * 32];
+            for (int i = 0; i < TM; ++i) af[o][i] = As[buf][k2 + khalf][arow + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = DENSE ? (&Bs[buf][0][0])[(((k2 + khalf) >> 2) * BN + bcol + j * 32) * 4 + ((k2 + khalf) & 3)]
-                              : Bs[buf][k2 + khalf][bcol + j * 32];
+                bf[o][j] = DENSE ? (&Bs[buf][0][0])[(((k2 + khalf) >> 2) * BN + bcol + j * 32) * 4 + ((k2 + khalf) & 3)]
+                                 : Bs[buf][k2 + khalf][bcol + j * 32];
+        };
+        operands(0);
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+            if (k2 + 2 < BK) operands(k2 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const int o = (k2 >> 1) & 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[o][i], bf[o][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         wait_stage(AHEAD > 1 && t + 2 < nk);            // stage t+1 has landed (own pieces) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
