@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--em-wgs", type=int, default=-1,
                     help="workgroups (CUs) per EM launch; default: images/3 for yud (the launch lasts as long as its "
                          "slowest image either way, and the CNN keeps the other CUs), one per image for stress")
+    ap.add_argument("--cnn-precision", type=int, default=0, choices=[0, 1],
+                    help="0: native f32 matrix instructions (default); 1: conv2..5 as six bf16 matrix products per f32 "
+                         "product (vpk_cnn_set_precision, same error class; reported as its own dtype)")
     ap.add_argument("--cnn-fusion", type=int, default=1, choices=[0, 1, 2],
                     help="conv1 + norm1 + pool1: 1 = direct-convolution kernel (default), 2 = implicit-GEMM kernel with the fused "
                          "epilogue, 0 = separate kernels")
@@ -241,6 +244,7 @@ def main():
     net = cnn.Net(weights, mean, device=local_rank, runtime=rt_cnn)
     net.set_profiling(True)
     net.set_fusion(args.cnn_fusion)
+    net.set_precision(args.cnn_precision)
     params = gem._params(kw)
     d = gem.upload_batch(rt, scenes)                     # inputs resident in HBM before the timed region
     l_pristine = d["l"].clone()

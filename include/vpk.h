@@ -129,6 +129,11 @@ int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* 
 /* conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55) run as ONE kernel by default (the 96 x 123 x 123 conv1 blob is
  * never written); on = 0 selects the separate conv1 and LRN/pool kernels (also used whenever tap 0 is requested). */
 int vpk_cnn_set_fusion(vpk_handle* h, int on);
+/* Arithmetic of conv2..conv5 (the reference runs Caffe in fp32, deploy.prototxt:56-174):
+ *   0 (default)  f32-input matrix instructions (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 FMA chain
+ *   1            every f32 operand as the exact sum of three bf16 pieces, six bf16 matrix products per f32 product
+ *                (everything above 2^-24 of the product), f32 accumulation -- same error class, see DESIGN.md */
+int vpk_cnn_set_precision(vpk_handle* h, int mode);
 
 /* per-layer device time of the last vpk_cnn_forward (single chunk), from HIP events recorded on
  * the handle's stream between the layers: ms[13] = conv1, norm1, pool1, conv2, norm2, pool2, conv3,

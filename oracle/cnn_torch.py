@@ -17,14 +17,15 @@ LAYERS = ["conv1", "conv2", "conv3", "conv4", "conv5", "fc6", "fc7", "fc8"]
 TAPS = ["conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "conv5", "pool5", "fc6", "fc7", "fc8"]
 
 
-def forward(weights, mean, sphere_u8, want_taps=False, threads=None):
+def forward(weights, mean, sphere_u8, want_taps=False, threads=None, dtype=np.float32):
     """weights: {name: (W, b)} in Caffe layout; mean: (500,500) f32; sphere_u8: (B,500,500) uint8.
-    Returns (B,20,20) float32 [, taps dict]."""
+    Returns (B,20,20) [, taps dict] in `dtype` (float32 like Caffe; float64 = the exact-arithmetic yardstick the
+    two GPU precisions are measured against)."""
     if threads:
         torch.set_num_threads(threads)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype)))
     w = {k: (t(v[0]), t(v[1])) for k, v in weights.items()}
-    x = t(sphere_u8.astype(np.float32)) - t(mean.astype(np.float32))[None]      # evaluation.py:35
+    x = t(sphere_u8) - t(mean)[None]                                            # evaluation.py:35
     x = x[:, None]
     taps = {}
     with torch.no_grad():

@@ -8,6 +8,7 @@ net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 net.set_profiling(True)
 import os
 net.set_fusion(int(os.environ.get("VPK_FUSION", "1")))
+net.set_precision(int(os.environ.get("VPK_PRECISION", "0")))
 args = sys.argv[1:]
 passes = 3
 if "--passes" in args:

@@ -78,3 +78,30 @@ def test_fused_first_stage_equals_separate_kernels(net_and_ref):
         assert np.abs(pool_f - pool_s).max() <= 2e-5 * (1 + np.abs(pool_s).max()), mode
         assert np.abs(out_f - out_s).max() <= 2e-6, mode
     net.set_fusion(1)
+
+
+def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
+    """vpk_cnn_set_precision(1): conv2..5 as six bf16 matrix products per f32 product (cnn_split_gemm.hpp).  Both
+    precisions are measured against the SAME net evaluated in float64: the split path's error must be of the size of
+    the native f32 path's (f32 accumulation noise), at every tap and at the output."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=3)])
+    ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
+    net = cnn.Net(w, mean)
+    try:
+        for tap in (2, 4, 5, 6, 8):                            # conv2, conv3, conv4, conv5, fc6
+            want = taps[cnn_torch.TAPS[tap]]
+            err = []
+            for mode in (0, 1):
+                net.set_precision(mode)
+                out, got = net.forward(sphere, tap=tap)
+                err.append((np.abs(got.reshape(want.shape) - want).max(), np.abs(out - ref).max()))
+            scale = np.abs(want).max()
+            assert err[0][0] <= 2e-5 * scale and err[1][0] <= 2e-5 * scale, (cnn_torch.TAPS[tap], err, scale)
+            assert err[1][0] <= 3.0 * err[0][0] + 1e-7 * scale, (cnn_torch.TAPS[tap], err)
+            assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
+    finally:
+        net.set_precision(0)

@@ -11,14 +11,16 @@
 // are of the same size.
 //
 // Data layout (chosen for the matrix cores, not inherited from the f32 path):
-//   activations  [piece 0..2][image][y][x][channel] bf16, planes carry the convolution's zero border (split_nhwc_kernel
-//                writes them from the f32 NCHW planes); K order = (kh, kw, channel), so a K16 step = 16 consecutive
-//                channels of one tap = 32 contiguous bytes per pixel and piece;
+//   activations  [image][y][x][channel / 16][piece 0..2][16 channels] bf16, with the convolution's zero border
+//                (split_nhwc_kernel writes them from the f32 NCHW planes); K order = (kh, kw, channel), so a K16 step = 16
+//                consecutive channels of one tap = 96 contiguous bytes per pixel (all three pieces): the gather touches
+//                1.5 cache lines per pixel instead of 3 half-used ones;
 //   weights      pre-split and pre-permuted on the host into MFMA fragment order:
 //                [group][k16 step][32-row block][piece][lane][8 bf16]  (1 KB = one A operand of v_mfma_f32_32x32x16_bf16);
 //   LDS stage    a list of 1 KB fragments, A blocks first then B blocks, each exactly as the MFMA wants it in registers:
-//                every fragment is written by ONE global_load_lds_dwordx4 (lane l brings the 16 bytes lane l will later
-//                read back with one conflict-free ds_read_b128).
+//                an A fragment is written by ONE global_load_lds_dwordx4 (lane l brings the 16 bytes lane l will later read
+//                back with one conflict-free ds_read_b128); a block of 32 columns arrives as [column][piece][k half] (3 KB,
+//                three DMA instructions of 64 consecutive 16-byte chunks) and is read back with a 96-byte lane stride.
 // Tile = (WAVES_M * TM * 32) x 256 outputs, 8 waves (WAVES_M x 4 in N... see below), three stages in flight.
 #ifndef VPK_CNN_SPLIT_GEMM_HPP_
 #define VPK_CNN_SPLIT_GEMM_HPP_
@@ -29,12 +31,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct SplitDims {
     int B, Cg, Ctot, Hp, Wp;        // input: channels per group / in total; padded plane
     int OC, OH, OW, groups;         // OC = output channels per group
-    int KW, csteps, ksteps;         // kernel width; K16 steps per tap (Cg / 16); K16 steps in total (KH * KW * csteps)
+    int KW, ntaps, csteps, ksteps;  // kernel width; KH * KW; K16 steps per tap (Cg / 16); K16 steps in total (ntaps * csteps)
     int mblocks;                    // 32-row blocks per group in the packed weights
     int N;                          // B * OH * OW
     int relu;
     int OHp, OWp, opad;             // f32 NCHW output planes
-    long long plane_bytes;          // distance between two pieces of the activations, bytes
 };
 
 constexpr int SG_THREADS = 512;
@@ -54,7 +55,7 @@ __device__ __forceinline__ void split3(float x, unsigned short& p0, unsigned sho
 // f32 NCHW planes (with their zero border) -> three bf16 NHWC pieces.  One workgroup per (image, row): the row's C x Wp
 // values are transposed through LDS so that both sides are coalesced.
 __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C,
-                                                         int Hp, int Wp, long long plane_elems) {
+                                                         int Hp, int Wp) {
     extern __shared__ float sn_tile[];                   // [C][Wp + 1]
     const int y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ld = Wp + 1;
@@ -64,22 +65,27 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
     }
     __syncthreads();
     const int C2 = C >> 1;
-    unsigned* o0 = reinterpret_cast<unsigned*>(out + ((size_t)b * Hp + y) * Wp * C);
-    unsigned* o1 = reinterpret_cast<unsigned*>(out + plane_elems + ((size_t)b * Hp + y) * Wp * C);
-    unsigned* o2 = reinterpret_cast<unsigned*>(out + 2 * plane_elems + ((size_t)b * Hp + y) * Wp * C);
+    unsigned* o = reinterpret_cast<unsigned*>(out + ((size_t)b * Hp + y) * Wp * C * 3);
     for (int idx = tid; idx < Wp * C2; idx += 256) {
         const int x = idx / C2, c = (idx - x * C2) * 2;
         unsigned short a0, a1, a2, b0, b1, b2;
         split3(sn_tile[c * ld + x], a0, a1, a2);
         split3(sn_tile[(c + 1) * ld + x], b0, b1, b2);
-        o0[idx] = (unsigned)a0 | ((unsigned)b0 << 16);
-        o1[idx] = (unsigned)a1 | ((unsigned)b1 << 16);
-        o2[idx] = (unsigned)a2 | ((unsigned)b2 << 16);
+        const int base = (((x * (C >> 4) + (c >> 4)) * 3) * 16 + (c & 15)) >> 1;     // in 4-byte words
+        o[base] = (unsigned)a0 | ((unsigned)b0 << 16);
+        o[base + 8] = (unsigned)a1 | ((unsigned)b1 << 16);
+        o[base + 16] = (unsigned)a2 | ((unsigned)b2 << 16);
     }
 }
 
-template <int WAVES_M, int TM>
-__global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDims d, const unsigned short* __restrict__ act,
+#ifdef SG_TIME
+__device__ long long sg_dbg[256 * 8 * 8];
+#define SG_T(i) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; }
+#else
+#define SG_T(i)
+#endif
+template <int WAVES_M, int TM, int NST = 3, int WPE = 2>
+__global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitDims d, const unsigned short* __restrict__ act,
                                                                         const unsigned short* __restrict__ wfrag,
                                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                                         int* __restrict__ tile_counter, int total_tiles) {
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
     constexpr int NB = SG_BN / 32;                       // 32-column blocks per tile
     constexpr int NA = MB * 3, NBF = NB * 3;             // fragments per stage
     constexpr int STAGE_BYTES = (NA + NBF) * 1024;
-    constexpr int NST = 3;
-    static_assert(NST * STAGE_BYTES <= 160 * 1024 - 64, "three stages must fit the CU's LDS");
-    extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
+    static_assert(NST * STAGE_BYTES <= 160 * 1024 - 64, "the stages must fit the CU's LDS");
+    constexpr int AHEAD = NST - 1;
+    __shared__ __attribute__((aligned(16))) unsigned char sg_lds[NST * STAGE_BYTES];
     __shared__ int s_next[2];
 
     const int tid = threadIdx.x;
@@ -105,6 +111,9 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
     // A fragments of a stage are dealt round-robin to the waves: fragment f (block f / 3, piece f % 3) to wave f % 8
     const int na_mine = (NA - wave + 7) / 8;             // wave-uniform
     int parity = 0;
+#ifdef SG_TIME
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
         int nx = 0;
         if (tid == 0)
@@ -113,32 +122,49 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
         const int mt = bid % mtiles; bid /= mtiles;
         const int nt = bid % ntiles;
         const int g = bid / ntiles;
-        // ---- B gather: this wave brings column block `wave` (32 columns x 16 channels x 3 pieces per stage) ----
-        int n = nt * SG_BN + wave * 32 + (lane & 31);
-        n = n < d.N ? n : d.N - 1;                       // tail columns re-read the last valid one
-        const int b = n / ohw, r = n - b * ohw;
-        const int oh = r / d.OW, ow = r - oh * d.OW;
-        const unsigned boff = (unsigned)(((b * d.Hp + oh) * d.Wp + ow) * d.Ctot) * 2u + (unsigned)(lane >> 5) * 16u;
-        const unsigned char* bgrp = reinterpret_cast<const unsigned char*>(act) + (size_t)g * d.Cg * 2;
+        SG_T(6)
+        // ---- B gather: this wave brings column block `wave` (32 columns x 96 bytes per stage) as 192 chunks of 16 bytes;
+        //      chunk index = column * 6 + piece * 2 + k half, lane l of instruction q brings chunk 64 q + l ----
+        unsigned boff[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int chunk = q * 64 + lane;
+            const int col = chunk / 6, part = chunk - col * 6;
+            int n = nt * SG_BN + wave * 32 + col;
+            n = n < d.N ? n : d.N - 1;                   // tail columns re-read the last valid one
+            const int b = n / ohw, r = n - b * ohw;
+            const int oh = r / d.OW, ow = r - oh * d.OW;
+            boff[q] = (unsigned)(((b * d.Hp + oh) * d.Wp + ow) * d.Ctot) * 6u + (unsigned)part * 16u;
+        }
+        const unsigned char* bgrp = reinterpret_cast<const unsigned char*>(act) + (size_t)g * d.Cg * 6;
         // ---- A fragments: contiguous 1 KB pieces of the packed weights ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB) * 3 * 1024;
         const unsigned aoff = (unsigned)lane * 16u;
-        auto issue = [&](int s, int buf) {
-            const unsigned stage = lds0 + (unsigned)(buf * STAGE_BYTES);
-            const unsigned char* wst = wgrp + (size_t)s * d.mblocks * 3 * 1024;
+        // Stages are issued in order, so the (channel group, kh, kw) of the next one is carried along instead of being
+        // recomputed: two integer divisions by run-time divisors per stage cost more than the stage's DMA instructions.
+        // K16 steps run over the taps first, then over the channel groups (consecutive stages re-read the same 96 bytes
+        // per pixel, shifted by one pixel / one row).
+        int i_kw = 0, i_kh = 0, i_c0 = 0, i_buf = 0;
+        const unsigned char* i_w = wgrp;
+        const size_t wstep = (size_t)d.mblocks * 3 * 1024;
+        auto issue = [&]() {
+            const unsigned stage = lds0 + (unsigned)(i_buf * STAGE_BYTES);
 #pragma unroll
             for (int q = 0; q < (NA + 7) / 8; ++q) {
                 const int f = wave + 8 * q;               // wave-uniform
-                if (f < NA) dma16(aoff, wst + (size_t)f * 1024, __builtin_amdgcn_readfirstlane(stage + (unsigned)f * 1024u));
+                if (f < NA) dma16(aoff, i_w + (size_t)f * 1024, __builtin_amdgcn_readfirstlane(stage + (unsigned)f * 1024u));
             }
-            const int tap = s / d.csteps, c0 = (s - tap * d.csteps) * 16;
-            const int kh = tap / d.KW, kw = tap - kh * d.KW;
-            const unsigned char* bst = bgrp + ((size_t)(kh * d.Wp + kw) * d.Ctot + c0) * 2;
+            const unsigned char* bst = bgrp + ((size_t)(i_kh * d.Wp + i_kw) * d.Ctot + i_c0) * 6;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                dma16(boff, bst + (size_t)p * d.plane_bytes,
-                      __builtin_amdgcn_readfirstlane(stage + (unsigned)((NA + wave * 3 + p) * 1024)));
+            for (int q = 0; q < 3; ++q)
+                dma16(boff[q], bst, __builtin_amdgcn_readfirstlane(stage + (unsigned)((NA + wave * 3 + q) * 1024)));
+            i_w += wstep;
+            i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;
+            if (++i_kw == d.KW) {
+                i_kw = 0;
+                if (++i_kh == d.KW) { i_kh = 0; i_c0 += 16; }
+            }
         };
         auto wait_stage = [&](bool keep_one_in_flight) {   // until only the newest stage's DMA (if any) is outstanding
             if (!keep_one_in_flight) wait_vmcnt<0>();
@@ -154,16 +180,19 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         const int nk = d.ksteps;
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        wait_stage(nk > 1);
+        issue();
+        if (AHEAD > 1 && nk > 1) issue();
+        wait_stage(AHEAD > 1 && nk > 1);
         asm volatile("" : "+v"(nx));                     // the atomic's result has landed (it is older than stage 0)
         if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        SG_T(0)
+        int buf = NST - 1;
         for (int t = 0; t < nk; ++t) {
-            const int buf = t % NST;
-            if (t + 2 < nk) issue(t + 2, (t + 2) % NST);
+            buf = buf + 1 == NST ? 0 : buf + 1;
+            if (t + AHEAD < nk) issue();
+            SG_T(1)
             const unsigned char* stage = sg_lds + buf * STAGE_BYTES;
             bf16x8 af[TM][3], bfr[TN][3];
 #pragma unroll
@@ -173,7 +202,8 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
                     af[i][p] = *reinterpret_cast<const bf16x8*>(stage + ((wm * TM + i) * 3 + p) * 1024 + lane * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bfr[j][p] = *reinterpret_cast<const bf16x8*>(stage + (NA + (wn * TN + j) * 3 + p) * 1024 + lane * 16);
+                    bfr[j][p] = *reinterpret_cast<const bf16x8*>(stage + (NA + (wn * TN + j) * 3) * 1024 +
+                                                                 ((lane & 31) * 6 + p * 2 + (lane >> 5)) * 16);
             }
             // the six partial products, smallest first
 #pragma unroll
@@ -187,9 +217,12 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
                 }
-            wait_stage(t + 2 < nk);                      // stage t + 1 has landed (own pieces) ...
+            SG_T(2)
+            wait_stage(AHEAD > 1 && t + 2 < nk);         // stage t + 1 has landed (own pieces) ...
+            SG_T(3)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // ... for every wave; stage t's buffer is free again
+            SG_T(4)
         }
         // ---- epilogue: bias + ReLU, f32 NCHW planes (accumulator register 4 q + e = row 8 q + 4 (lane / 32) + e) ----
         const int khalf = lane >> 5;
@@ -219,9 +252,17 @@ __global__ __launch_bounds__(SG_THREADS, 2) void conv_gemm_split_kernel(SplitDim
                     }
                 }
         }
+        SG_T(5)
         tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
         parity ^= 1;
     }
+#ifdef SG_TIME
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 8; ++i) sg_dbg[(blockIdx.x * 8 + wave) * 8 + i] = tacc[i];
+#endif
 }
+#ifdef SG_TIME
+extern "C" int vpk_dbg_sg(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg_dbg), sizeof(long long) * 256 * 8 * 8); }
+#endif
 
 #endif

@@ -16,6 +16,7 @@
 #include "vpk_internal.hpp"
 
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -818,11 +819,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     wp[idx] = (m < OC && k < K) ? w[((size_t)g * OC + m) * K + k] : 0.f;
 }
 
+#include "cnn_split_gemm.hpp"
+
 struct Layer {
     ConvDims d;
     float* wp = nullptr;     // packed weights
     float* bias = nullptr;
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
+    unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
+    SplitDims sd;
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -838,6 +843,7 @@ struct vpk_cnn_state {
     size_t act_bytes = 0;
     int act_batch = 0;
     // optional per-layer timing (HIP events on the handle's stream)
+    int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
     int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
     bool profiling = false;
     hipEvent_t ev[14] = {};
@@ -851,6 +857,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.wp) (void)hipFree(l.wp);
         if (l.bias) (void)hipFree(l.bias);
         if (l.ktab) (void)hipFree(l.ktab);
+        if (l.wsplit) (void)hipFree(l.wsplit);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
@@ -883,7 +890,7 @@ const int KSPLIT[8] = {1, 1, 1, 1, 1, 24, 16, 32};
 // so an image's planes sit at the same address for every batch size <= capacity and the zero borders
 // written at allocation time stay valid.  Nothing is reused between layers (17.6 MB per image; 288 GB
 // of HBM3E makes ping-pong buffers unnecessary, and the borders must not be overwritten).
-enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_COUNT };
+enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_SPLIT, R_COUNT };
 constexpr size_t CTR_FLOATS = 64;   // tile-queue counters of the 8 GEMM launches, behind the regions
 constexpr size_t REGION_FLOATS[R_COUNT] = {
     500ull * 500,            // fp32 input (raster - mean)
@@ -897,6 +904,7 @@ constexpr size_t REGION_FLOATS[R_COUNT] = {
     256ull * 225,            // pool5 = fc6 input
     4096, 4096,              // fc6 / fc7 outputs
     24ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
+    96ull * 65 * 65 * 3 / 2, // the current conv layer's input as three bf16 NHWC pieces (largest: pool1)
 };
 constexpr size_t arena_floats_per_image() {
     size_t t = 0;
@@ -1005,7 +1013,28 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // conv2 + relu2
     // (a 2-stage / 4-workgroups-per-CU build of the same kernel, NST = 2, WPC = 4, was measured in round 2: conv2 +2 %,
     //  conv3 -3 %, conv5 -11 % (1436 tiles on 1024 workgroups) -- not used)
+    // precision 1: the layer's input planes are split into three bf16 NHWC pieces, the GEMM runs on the bf16 matrix cores
+    auto conv_split = [&](int li, const float* src, float* dst) {
+        const Layer& l = S->L[li];
+        SplitDims sd = l.sd;
+        sd.B = batch;
+        sd.N = batch * sd.OH * sd.OW;
+        unsigned short* sp = reinterpret_cast<unsigned short*>(R[R_SPLIT]);
+        hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)sd.Hp, (unsigned)batch), dim3(256),
+                           (size_t)sd.Ctot * (sd.Wp + 1) * sizeof(float), st, src, sp, sd.Ctot, sd.Hp, sd.Wp);
+        const int ntiles = (sd.N + SG_BN - 1) / SG_BN;
+        if (sd.OC == 192) {
+            const int total = sd.groups * ntiles * (sd.mblocks / 6);
+            hipLaunchKernelGGL((conv_gemm_split_kernel<2, 3>), dim3((unsigned)std::min(total, h->num_cu)), dim3(SG_THREADS), 0, st,
+                               sd, sp, l.wsplit, l.bias, dst, ctr + li, total);
+        } else {
+            const int total = sd.groups * ntiles * (sd.mblocks / 4);
+            hipLaunchKernelGGL((conv_gemm_split_kernel<2, 2>), dim3((unsigned)std::min(total, h->num_cu)), dim3(SG_THREADS), 0, st,
+                               sd, sp, l.wsplit, l.bias, dst, ctr + li, total);
+        }
+    };
     auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
+        if (S->precision == 1) return conv_split(li, src, dst);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
     conv_main(1, R[R_POOL1], R[R_CONV2]);
@@ -1021,7 +1050,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
+    if (S->precision == 1) conv_split(3, R[R_CONV3], R[R_CONV4]);
+    else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
     conv_main(4, R[R_CONV4], R[R_CONV5]);
@@ -1072,6 +1102,13 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
 int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
     h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 2 ? 1 : on);
+    return VPK_OK;
+}
+
+int vpk_cnn_set_precision(vpk_handle* h, int mode) {
+    if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_precision before vpk_cnn_load");
+    if (mode != 0 && mode != 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_precision: mode must be 0 or 1");
+    h->cnn->precision = mode;
     return VPK_OK;
 }
 
@@ -1128,6 +1165,39 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             }
             VPK_HIP(h, hipMalloc((void**)&l.ktab, tab.size() * sizeof(unsigned)));
             VPK_HIP(h, hipMemcpy(l.ktab, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
+        if (li >= 1 && li <= 4) {   // three bf16 pieces of every weight, in the A-fragment order of v_mfma_f32_32x32x16_bf16
+            SplitDims& sd = l.sd;
+            const int blk = t.OC == 192 ? 6 : 4;                      // 32-row blocks per tile
+            sd.B = 0; sd.Cg = t.IC; sd.Ctot = t.IC * t.G; sd.Hp = d.Hp; sd.Wp = d.Wp; sd.OC = t.OC; sd.OH = t.OH; sd.OW = t.OW;
+            sd.groups = t.G; sd.KW = t.KH; sd.ntaps = t.KH * t.KH; sd.csteps = t.IC / 16; sd.ksteps = sd.ntaps * sd.csteps;
+            sd.mblocks = (t.OC / 32 + blk - 1) / blk * blk; sd.N = 0; sd.relu = 1; sd.OHp = d.OHp; sd.OWp = d.OWp; sd.opad = d.opad;
+            const size_t frag = (size_t)t.G * sd.ksteps * sd.mblocks * 3;
+            std::vector<unsigned short> pk(frag * 512, 0);
+            const float* wsrc = blobs[2 * li];
+            for (int g = 0; g < t.G; ++g)
+                for (int s_ = 0; s_ < sd.ksteps; ++s_)
+                    for (int mb = 0; mb < sd.mblocks; ++mb)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int m = mb * 32 + (ln & 31);
+                                const int tap = s_ % sd.ntaps, c = (s_ / sd.ntaps) * 16 + 8 * (ln >> 5) + e;   // step = (channel group, tap)
+                                float w = 0.f;
+                                if (m < t.OC) w = wsrc[((size_t)(g * t.OC + m) * t.IC + c) * t.KH * t.KH + tap];
+                                unsigned b0, b1, b2;
+                                float r1, r2;
+                                memcpy(&b0, &w, 4); b0 &= 0xffff0000u;
+                                float f0; memcpy(&f0, &b0, 4); r1 = w - f0;
+                                memcpy(&b1, &r1, 4); b1 &= 0xffff0000u;
+                                float f1; memcpy(&f1, &b1, 4); r2 = r1 - f1;
+                                memcpy(&b2, &r2, 4);
+                                const size_t base = ((((size_t)g * sd.ksteps + s_) * sd.mblocks + mb) * 3) * 512 + (size_t)ln * 8 + e;
+                                pk[base] = (unsigned short)(b0 >> 16);
+                                pk[base + 512] = (unsigned short)(b1 >> 16);
+                                pk[base + 1024] = (unsigned short)(b2 >> 16);
+                            }
+            VPK_HIP(h, hipMalloc((void**)&l.wsplit, pk.size() * sizeof(unsigned short)));
+            VPK_HIP(h, hipMemcpy(l.wsplit, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         }
         VPK_HIP(h, hipMalloc((void**)&l.bias, (size_t)t.G * t.OC * sizeof(float)));
         VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
