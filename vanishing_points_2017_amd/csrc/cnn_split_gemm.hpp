@@ -26,7 +26,7 @@
 #define VPK_CNN_SPLIT_GEMM_HPP_
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct SplitDims {
     int B, Cg, Ctot, Hp, Wp;        // input: channels per group / in total; padded plane
@@ -38,7 +38,6 @@ struct SplitDims {
     int OHp, OWp, opad;             // f32 NCHW output planes
 };
 
-constexpr int SG_THREADS = 512;
 constexpr int SG_BN = 256;          // columns per tile: 8 blocks of 32
 
 // f32 -> three bf16 pieces (truncation; exact: the three add up to x)
@@ -84,12 +83,14 @@ __device__ long long sg_dbg[256 * 8 * 8];
 #else
 #define SG_T(i)
 #endif
-template <int WAVES_M, int TM, int NST = 3, int WPE = 2>
-__global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitDims d, const unsigned short* __restrict__ act,
+// SPLIT_OUT: the result goes straight into the NEXT convolution's input format (three bf16 pieces, channels innermost)
+// instead of f32 NCHW planes.
+template <int WAVES_M, int WAVES_N, int TM, int NST, int WPE, bool SPLIT_OUT = false>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WPE) void conv_gemm_split_kernel(SplitDims d, const unsigned short* __restrict__ act,
                                                                         const unsigned short* __restrict__ wfrag,
-                                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                                        const float* __restrict__ bias, void* __restrict__ out_,
                                                                         int* __restrict__ tile_counter, int total_tiles) {
-    constexpr int WAVES_N = 8 / WAVES_M;
+    constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int TN = SG_BN / 32 / WAVES_N;
     constexpr int MB = WAVES_M * TM;                     // 32-row blocks per tile
     constexpr int NB = SG_BN / 32;                       // 32-column blocks per tile
@@ -108,8 +109,10 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
     const int mtiles = d.mblocks / MB;
     const int ntiles = (d.N + SG_BN - 1) / SG_BN;
     const int ohw = d.OH * d.OW;
-    // A fragments of a stage are dealt round-robin to the waves: fragment f (block f / 3, piece f % 3) to wave f % 8
-    const int na_mine = (NA - wave + 7) / 8;             // wave-uniform
+    // A fragments of a stage are dealt round-robin to the waves (fragment f = block f / 3, piece f % 3, to wave f % NWAVES);
+    // every wave brings NB / NWAVES column blocks
+    constexpr int CB = NB / NWAVES;                      // column blocks per wave
+    const int na_mine = (NA - wave + NWAVES - 1) / NWAVES;   // wave-uniform
     int parity = 0;
 #ifdef SG_TIME
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_amdgcn_s_memtime();
@@ -125,12 +128,12 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
         SG_T(6)
         // ---- B gather: this wave brings column block `wave` (32 columns x 96 bytes per stage) as 192 chunks of 16 bytes;
         //      chunk index = column * 6 + piece * 2 + k half, lane l of instruction q brings chunk 64 q + l ----
-        unsigned boff[3];
+        unsigned boff[3 * CB];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 3 * CB; ++q) {
             const int chunk = q * 64 + lane;
-            const int col = chunk / 6, part = chunk - col * 6;
-            int n = nt * SG_BN + wave * 32 + col;
+            const int col = chunk / 6, part = chunk - col * 6;   // col: 0 .. 32 CB - 1 (this wave's blocks are adjacent)
+            int n = nt * SG_BN + wave * CB * 32 + col;
             n = n < d.N ? n : d.N - 1;                   // tail columns re-read the last valid one
             const int b = n / ohw, r = n - b * ohw;
             const int oh = r / d.OW, ow = r - oh * d.OW;
@@ -140,7 +143,9 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
         // ---- A fragments: contiguous 1 KB pieces of the packed weights ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB) * 3 * 1024;
-        const unsigned aoff = (unsigned)lane * 16u;
+        unsigned aoff[(NA + NWAVES - 1) / NWAVES];        // fragment f = wave + NWAVES q of the stage, this lane's 16 bytes
+#pragma unroll
+        for (int q = 0; q < (NA + NWAVES - 1) / NWAVES; ++q) aoff[q] = (unsigned)((wave + NWAVES * q) * 1024 + lane * 16);
         // Stages are issued in order, so the (channel group, kh, kw) of the next one is carried along instead of being
         // recomputed: two integer divisions by run-time divisors per stage cost more than the stage's DMA instructions.
         // K16 steps run over the taps first, then over the channel groups (consecutive stages re-read the same 96 bytes
@@ -151,14 +156,14 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
         auto issue = [&]() {
             const unsigned stage = lds0 + (unsigned)(i_buf * STAGE_BYTES);
 #pragma unroll
-            for (int q = 0; q < (NA + 7) / 8; ++q) {
-                const int f = wave + 8 * q;               // wave-uniform
-                if (f < NA) dma16(aoff, i_w + (size_t)f * 1024, __builtin_amdgcn_readfirstlane(stage + (unsigned)f * 1024u));
+            for (int q = 0; q < (NA + NWAVES - 1) / NWAVES; ++q) {
+                const int f = wave + NWAVES * q;          // wave-uniform
+                if (f < NA) dma16(aoff[q], i_w, __builtin_amdgcn_readfirstlane(stage + (unsigned)f * 1024u));
             }
             const unsigned char* bst = bgrp + ((size_t)(i_kh * d.Wp + i_kw) * d.Ctot + i_c0) * 6;
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                dma16(boff[q], bst, __builtin_amdgcn_readfirstlane(stage + (unsigned)((NA + wave * 3 + q) * 1024)));
+            for (int q = 0; q < 3 * CB; ++q)
+                dma16(boff[q], bst, __builtin_amdgcn_readfirstlane(stage + (unsigned)((NA + wave * 3 * CB + q) * 1024)));
             i_w += wstep;
             i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;
             if (++i_kw == d.KW) {
@@ -168,9 +173,11 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
         };
         auto wait_stage = [&](bool keep_one_in_flight) {   // until only the newest stage's DMA (if any) is outstanding
             if (!keep_one_in_flight) wait_vmcnt<0>();
-            else if (na_mine == 1) wait_vmcnt<4>();
-            else if (na_mine == 2) wait_vmcnt<5>();
-            else wait_vmcnt<6>();
+            else if (na_mine == 1) wait_vmcnt<3 * CB + 1>();
+            else if (na_mine == 2) wait_vmcnt<3 * CB + 2>();
+            else if (na_mine == 3) wait_vmcnt<3 * CB + 3>();
+            else if (na_mine == 4) wait_vmcnt<3 * CB + 4>();
+            else wait_vmcnt<3 * CB + 5>();
         };
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -194,29 +201,30 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
             if (t + AHEAD < nk) issue();
             SG_T(1)
             const unsigned char* stage = sg_lds + buf * STAGE_BYTES;
-            bf16x8 af[TM][3], bfr[TN][3];
+            bf16x8 af[TM][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     af[i][p] = *reinterpret_cast<const bf16x8*>(stage + ((wm * TM + i) * 3 + p) * 1024 + lane * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bfr[j][p] = *reinterpret_cast<const bf16x8*>(stage + (NA + (wn * TN + j) * 3) * 1024 +
-                                                                 ((lane & 31) * 6 + p * 2 + (lane >> 5)) * 16);
-            }
-            // the six partial products, smallest first
+            for (int j = 0; j < TN; ++j) {
+                bf16x8 bfr[3];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int p = 0; p < 3; ++p)
+                    bfr[p] = *reinterpret_cast<const bf16x8*>(stage + (NA + (wn * TN + j) * 3) * 1024 +
+                                                              ((lane & 31) * 6 + p * 2 + (lane >> 5)) * 16);
+                // the six partial products, smallest first
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[0], acc[i][j], 0, 0, 0);
                 }
+            }
             SG_T(2)
             wait_stage(AHEAD > 1 && t + 2 < nk);         // stage t + 1 has landed (own pieces) ...
             SG_T(3)
@@ -233,22 +241,39 @@ __global__ __launch_bounds__(SG_THREADS, WPE) void conv_gemm_split_kernel(SplitD
             if (nn >= d.N) continue;
             const int bb = nn / ohw, rr = nn - bb * ohw;
             const int yy = rr / d.OW, xx = rr - yy * d.OW;
-            float* ocol = out + ((size_t)bb * d.groups + g) * d.OC * oplane + (size_t)(yy + d.opad) * d.OWp + xx + d.opad;
+            float* ocol = reinterpret_cast<float*>(out_) + ((size_t)bb * d.groups + g) * d.OC * oplane +
+                          (size_t)(yy + d.opad) * d.OWp + xx + d.opad;
+            unsigned short* opix = reinterpret_cast<unsigned short*>(out_) +
+                                   ((size_t)(bb * d.OHp + yy + d.opad) * d.OWp + xx + d.opad) * (size_t)(d.groups * d.OC) * 3;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m0 = __builtin_amdgcn_readfirstlane((mt * MB + wm * TM + i) * 32 + 8 * q);
                     if (m0 >= d.OC) continue;
-                    const float* bp = bias + g * d.OC + m0;          // wave-uniform: scalar load of 8 floats
-                    float bl[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bl[e] = bp[e];
+                    const f32x4v bl = *reinterpret_cast<const f32x4v*>(bias + g * d.OC + m0 + 4 * khalf);   // this lane's 4 rows
+                    float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][4 * q + e] + (khalf ? bl[4 + e] : bl[e]);
-                        if (d.relu) v = v > 0.f ? v : 0.f;
-                        ocol[(m0 + 4 * khalf + e) * oplane] = v;
+                        v[e] = acc[i][j][4 * q + e] + bl[e];
+                        if (d.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    if (SPLIT_OUT) {
+                        const int oc = g * d.OC + m0 + 4 * khalf;       // 4 consecutive channels of one 16-channel group
+                        unsigned short pc[3][4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split3(v[e], pc[0][e], pc[1][e], pc[2][e]);
+                        unsigned short* o = opix + (oc >> 4) * 48 + (oc & 15);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            uint2 w2;
+                            w2.x = (unsigned)pc[p][0] | ((unsigned)pc[p][1] << 16);
+                            w2.y = (unsigned)pc[p][2] | ((unsigned)pc[p][3] << 16);
+                            *reinterpret_cast<uint2*>(o + p * 16) = w2;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ocol[(m0 + 4 * khalf + e) * oplane] = v[e];
                     }
                 }
         }

@@ -843,6 +843,7 @@ struct vpk_cnn_state {
     size_t act_bytes = 0;
     int act_batch = 0;
     // optional per-layer timing (HIP events on the handle's stream)
+    int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
     int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
     bool profiling = false;
@@ -890,7 +891,7 @@ const int KSPLIT[8] = {1, 1, 1, 1, 1, 24, 16, 32};
 // so an image's planes sit at the same address for every batch size <= capacity and the zero borders
 // written at allocation time stay valid.  Nothing is reused between layers (17.6 MB per image; 288 GB
 // of HBM3E makes ping-pong buffers unnecessary, and the borders must not be overwritten).
-enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_SPLIT, R_COUNT };
+enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_SPLIT, R_SPLIT4, R_SPLIT5, R_COUNT };
 constexpr size_t CTR_FLOATS = 64;   // tile-queue counters of the 8 GEMM launches, behind the regions
 constexpr size_t REGION_FLOATS[R_COUNT] = {
     500ull * 500,            // fp32 input (raster - mean)
@@ -905,6 +906,8 @@ constexpr size_t REGION_FLOATS[R_COUNT] = {
     4096, 4096,              // fc6 / fc7 outputs
     24ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
     96ull * 65 * 65 * 3 / 2, // the current conv layer's input as three bf16 NHWC pieces (largest: pool1)
+    384ull * 32 * 32 * 3 / 2, // conv4's / conv5's input in that format, written by the previous layer's epilogue (interior
+    384ull * 32 * 32 * 3 / 2, //  only: the zero border comes from the arena's allocation)
 };
 constexpr size_t arena_floats_per_image() {
     size_t t = 0;
@@ -1014,27 +1017,41 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // (a 2-stage / 4-workgroups-per-CU build of the same kernel, NST = 2, WPC = 4, was measured in round 2: conv2 +2 %,
     //  conv3 -3 %, conv5 -11 % (1436 tiles on 1024 workgroups) -- not used)
     // precision 1: the layer's input planes are split into three bf16 NHWC pieces, the GEMM runs on the bf16 matrix cores
-    auto conv_split = [&](int li, const float* src, float* dst) {
+    // src_split: the input already is in split format (written by the previous layer); dst_split: write that format
+    auto conv_split = [&](int li, const float* src, const unsigned short* src_split, void* dst, bool dst_split) {
         const Layer& l = S->L[li];
         SplitDims sd = l.sd;
         sd.B = batch;
         sd.N = batch * sd.OH * sd.OW;
-        unsigned short* sp = reinterpret_cast<unsigned short*>(R[R_SPLIT]);
-        hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)sd.Hp, (unsigned)batch), dim3(256),
-                           (size_t)sd.Ctot * (sd.Wp + 1) * sizeof(float), st, src, sp, sd.Ctot, sd.Hp, sd.Wp);
+        const unsigned short* sp = src_split;
+        if (!sp) {
+            unsigned short* cv = reinterpret_cast<unsigned short*>(R[R_SPLIT]);
+            hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)sd.Hp, (unsigned)batch), dim3(256),
+                               (size_t)sd.Ctot * (sd.Wp + 1) * sizeof(float), st, src, cv, sd.Ctot, sd.Hp, sd.Wp);
+            sp = cv;
+        }
         const int ntiles = (sd.N + SG_BN - 1) / SG_BN;
+        // measured at B = 102 (ms incl. the split pass): conv2 1.10 / conv3 0.82 with two 4-wave workgroups per CU, 1.21 / 0.90
+        // with one 8-wave workgroup; conv5 (718 tiles) 0.53 with 8 waves, 0.62 with 4
+        const int variant = S->split_variant == 0 ? (li <= 2 ? 1 : 0) : S->split_variant - 1;
+        auto go = [&](auto kernel, int blk, int threads, int per_cu) {
+            const int total = sd.groups * ntiles * (sd.mblocks / blk);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)std::min(total, per_cu * h->num_cu)), dim3(threads), 0, st, sd, sp, l.wsplit,
+                               l.bias, dst, ctr + li, total);
+        };
         if (sd.OC == 192) {
-            const int total = sd.groups * ntiles * (sd.mblocks / 6);
-            hipLaunchKernelGGL((conv_gemm_split_kernel<2, 3>), dim3((unsigned)std::min(total, h->num_cu)), dim3(SG_THREADS), 0, st,
-                               sd, sp, l.wsplit, l.bias, dst, ctr + li, total);
+            if (dst_split) go(conv_gemm_split_kernel<2, 4, 3, 3, 2, true>, 6, 512, 1);
+            else go(conv_gemm_split_kernel<2, 4, 3, 3, 2, false>, 6, 512, 1);
+        } else if (variant == 1) {      // two independent 4-wave workgroups per CU, two stages each
+            if (dst_split) go(conv_gemm_split_kernel<2, 2, 2, 2, 2, true>, 4, 256, 2);
+            else go(conv_gemm_split_kernel<2, 2, 2, 2, 2, false>, 4, 256, 2);
         } else {
-            const int total = sd.groups * ntiles * (sd.mblocks / 4);
-            hipLaunchKernelGGL((conv_gemm_split_kernel<2, 2>), dim3((unsigned)std::min(total, h->num_cu)), dim3(SG_THREADS), 0, st,
-                               sd, sp, l.wsplit, l.bias, dst, ctr + li, total);
+            if (dst_split) go(conv_gemm_split_kernel<2, 4, 2, 3, 2, true>, 4, 512, 1);
+            else go(conv_gemm_split_kernel<2, 4, 2, 3, 2, false>, 4, 512, 1);
         }
     };
     auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
-        if (S->precision == 1) return conv_split(li, src, dst);
+        if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
     conv_main(1, R[R_POOL1], R[R_CONV2]);
@@ -1046,15 +1063,22 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     mark();
     tapunpad(3, R[R_POOL2], 256, 30, 30, 1);
-    // conv3..5
-    conv_main(2, R[R_POOL2], R[R_CONV3]);
+    // conv3..5.  In split precision conv3 and conv4 hand their result to the next layer in its input format (unless a
+    // caller taps the f32 blob)
+    const bool chain = S->precision == 1 && tap != 4 && tap != 5;
+    unsigned short* s4 = reinterpret_cast<unsigned short*>(R[R_SPLIT4]);
+    unsigned short* s5 = reinterpret_cast<unsigned short*>(R[R_SPLIT5]);
+    if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
+    else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    if (S->precision == 1) conv_split(3, R[R_CONV3], R[R_CONV4]);
+    if (chain) conv_split(3, nullptr, s4, s5, true);
+    else if (S->precision == 1) conv_split(3, R[R_CONV3], nullptr, R[R_CONV4], false);
     else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    conv_main(4, R[R_CONV4], R[R_CONV5]);
+    if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
+    else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
     if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
     hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, R[R_CONV5],
@@ -1107,8 +1131,9 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on) {
 
 int vpk_cnn_set_precision(vpk_handle* h, int mode) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_precision before vpk_cnn_load");
-    if (mode != 0 && mode != 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_precision: mode must be 0 or 1");
-    h->cnn->precision = mode;
+    if (mode < 0 || mode > 3) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_precision: mode must be 0 or 1");
+    h->cnn->precision = mode ? 1 : 0;
+    h->cnn->split_variant = mode > 1 ? mode - 1 : 0;   // 2, 3: force one tiling for every layer (development)
     return VPK_OK;
 }
 
