@@ -50,6 +50,8 @@ template <int G> VPK_DEV int group_sum_int(int v) { return v; }
 template <int G> VPK_DEV double group_max(double v) { return v; }
 template <int G> VPK_DEV int group_max_int(int v) { return v; }
 VPK_DEV void wave_argmin(double&, int&) {}
+constexpr int ROWG = 1;
+VPK_DEV void row16_argmin(double&, int&) {}
 VPK_DEV unsigned long long wave_ballot(bool pred) { return pred ? 1ull : 0ull; }
 VPK_DEV unsigned long long lanes_below() { return 0ull; }
 VPK_DEV int popcount64(unsigned long long m) { return __builtin_popcountll(m); }

@@ -83,6 +83,7 @@ struct EmCtx {
     vpk_em_params prm;
     // per-slot global scratch
     gdp lsim;     // N x ld
+    gdp pdist;    // N x ld : closest distance of every pair of segments (setup scratch)
     gdp den;      // N   : 1 + bias * lweight[k] * sum_j lsim[j][k]
     gdp lweight;  // N
     gdp langle;   // N
@@ -107,7 +108,7 @@ struct EmCtx {
 VPK_DEV void bind_scratch(EmCtx& c, double* base_, const EmLayout& L, bool do_split) {
     gdp base = (gdp)base_;
     c.ldn = L.ldn; c.ld = L.ld; c.mcap = L.mcap;
-    c.lsim = base + L.lsim; c.den = base + L.den; c.lweight = base + L.lweight;
+    c.lsim = base + L.lsim; c.pdist = base + L.pdist; c.den = base + L.den; c.lweight = base + L.lweight;
     c.langle = base + L.langle; c.lscore = base + L.lscore; c.lvsq = base + L.lvsq;
     c.pvl = base + L.pvl; c.w = base + L.w; c.wsrc = base + L.wsrc; c.drow = base + L.drow;
     c.cl = do_split ? base + L.cl : (gdp) nullptr;
@@ -445,10 +446,154 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 }
 
 // calc_lsim (vp_localisation.py:87-108, sigma=1 at :178) and line_rating_knn (:34-84, k2=4 at
-// :230) in ONE pass over the pairs: the closest distance is shared by both.  One wave per row,
-// lanes over columns (coalesced lsim stores).  Also lines_angles (:765-776).
+// :230) from ONE evaluation of every pair: the closest distance is shared by both.  Also lines_angles (:765-776).
+//
+// With weights (want_lsim) every UNORDERED pair is evaluated once, like the reference does (:102-108 compute
+// lines_similarity(lp[i], lp[j]) for j < i and :95-97 mirror it): pass 1, one wave per row i, lanes over the
+// columns j < i, writes the similarity and the distance to (i, j) and (j, i); pass 2, one wave per row, sums the
+// row in the order the one-pass version did (so rowsum keeps its bits) and rates the line from its distance row.
+// The pair functions are symmetric bit for bit (tests/test_gpu_em.py asserts lsim == lsim.T), so nothing moves.
+// Without weights only the distances matter and the one-pass version below runs (every ordered pair, no matrix).
 VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
     const int N = c.N;
+    if (want_lsim) {
+        // Row i has i pairs and row N - 1 - i has N - 1 - i: a wave takes the two together, N - 1 pairs for every
+        // wave (whole trips of 2 x 64 pairs; row by row the short rows leave most lanes idle at N ~ 100..400).
+        for (int r = wave_id(); 2 * r < N; r += nwaves()) {
+            const int i0 = r, i1 = N - 1 - r;                      // i0 <= i1
+            const int len = i0 == i1 ? i0 : i0 + i1;
+            double a0[4], a1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a0[q] = c.lp[4 * (size_t)i0 + q]; a1[q] = c.lp[4 * (size_t)i1 + q]; }
+            const LineGeom g0 = line_geom(a0), g1 = line_geom(a1);
+            // two independent pairs per lane per trip: the per-pair arithmetic is one long dependent fp64 chain
+            // (divisions, square roots, exp), so the second pair fills its issue bubbles
+            auto one = [&](int t, double& d, double& sim) {
+                const bool first = t < i0;
+                const int j = t < len ? (first ? t : t - i0) : 0;
+                const LineGeom& ga = first ? g0 : g1;              // pair (i, j): a = line i, b = line j < i (:102-106)
+                double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2], c.lp[4 * (size_t)j + 3]};
+                const LineGeom gb = line_geom(b);
+                d = line_distance_closest(ga, gb);
+                sim = lines_cosangle(ga, gb, 9.0) * proximity(d, ga.nv, gb.nv, 1.0);
+            };
+            auto put = [&](int t, double d, double sim) {
+                if (t >= len) return;
+                const int i = t < i0 ? i0 : i1, j = t < i0 ? t : t - i0;
+                c.lsim[(size_t)i * c.ld + j] = sim;
+                c.lsim[(size_t)j * c.ld + i] = sim;
+                c.pdist[(size_t)i * c.ld + j] = d;
+                c.pdist[(size_t)j * c.ld + i] = d;
+            };
+            for (int t = lane(); t < len; t += 2 * WAVE) {
+                double d0, s0, d1, s1;
+                one(t, d0, s0);
+                one(t + WAVE, d1, s1);
+                put(t, d0, s0);
+                put(t + WAVE, d1, s1);
+            }
+            if (lane() == 0) {
+                c.lsim[(size_t)i0 * c.ld + i0] = 0.0;              // :104 (the row's own entry stays 0)
+                c.pdist[(size_t)i0 * c.ld + i0] = 4.0;             // :82
+                c.lsim[(size_t)i1 * c.ld + i1] = 0.0;
+                c.pdist[(size_t)i1 * c.ld + i1] = 4.0;
+            }
+        }
+        block_sync();
+        // pass 2a: row sums, one wave per row, each lane adds its columns in ascending order and the wave reduces --
+        // the order the one-pass version used (lsim is symmetric: row sum == column sum, :522)
+        for (int i = wave_id(); i < N; i += nwaves()) {
+            cgdp srow = c.lsim + (size_t)i * c.ld;
+            double rsum = 0.0;
+            for (int j = lane(); j < N; j += WAVE) rsum += srow[j];
+            rsum = wave_sum(rsum);
+            if (lane() == 0) c.rowsum[i] = rsum;
+        }
+        // pass 2b: line_rating_knn from the stored distance rows, ROWG lanes per row and WAVE / ROWG rows per wave at a
+        // time: the k1 selection rounds (a lexicographic minimum over the group and a pop) and the serial tail are
+        // per-row costs that a whole wave per row paid ~14 us for; a 16-lane minimum is four DPP steps.
+        constexpr int RPW = WAVE / ROWG;
+        const int grp = lane() / ROWG, gl = lane() % ROWG;
+        const int k1 = N < KNN1 ? N : KNN1;
+        const int k2 = N < KNN2 ? N : KNN2;
+        double* ks = SCRATCH() + (wave_id() * RPW + grp) * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank
+        for (int base = wave_id() * RPW; base < N; base += nwaves() * RPW) {
+            const int i = base + grp;
+            const bool valid = i < N;
+            const int ii = valid ? i : 0;
+            double td[KNN1];
+            int tj[KNN1];
+#pragma unroll
+            for (int q = 0; q < KNN1; ++q) { td[q] = 1e300; tj[q] = 0x7fffffff; }
+            cgdp drow = c.pdist + (size_t)ii * c.ld;
+            for (int j0 = gl; j0 < N; j0 += 4 * ROWG) {            // four loads in flight
+                double dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dv[u] = (j0 + u * ROWG < N) ? drow[j0 + u * ROWG] : 1e300;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double nd = dv[u];
+                    int nj = (j0 + u * ROWG < N) ? j0 + u * ROWG : 0x7fffffff;
+#pragma unroll
+                    for (int q = 0; q < KNN1; ++q) {
+                        const bool lt = (nd < td[q]) || (nd == td[q] && nj < tj[q]);
+                        const double od = td[q];
+                        const int oj = tj[q];
+                        td[q] = lt ? nd : od;
+                        tj[q] = lt ? nj : oj;
+                        nd = lt ? od : nd;
+                        nj = lt ? oj : nj;
+                    }
+                }
+            }
+            for (int r = 0; r < k1; ++r) {                          // k1 nearest overall, by (distance, index)
+                double bd = td[0];
+                int bj = tj[0];
+                row16_argmin(bd, bj);
+                if (tj[0] == bj && td[0] == bd) {                   // the winning lane pops its head
+#pragma unroll
+                    for (int q = 0; q + 1 < KNN1; ++q) { td[q] = td[q + 1]; tj[q] = tj[q + 1]; }
+                    td[KNN1 - 1] = 1e300;
+                    tj[KNN1 - 1] = 0x7fffffff;
+                }
+                if (gl == 0) { ks[r] = (double)bj; ks[KNN1 + r] = bd; }
+            }
+            wave_sync();
+            double a[4] = {c.lp[4 * (size_t)ii], c.lp[4 * (size_t)ii + 1], c.lp[4 * (size_t)ii + 2], c.lp[4 * (size_t)ii + 3]};
+            const double len_a = norm2(a[0] - a[2], a[1] - a[3]);
+            for (int q = gl; q < k1; q += ROWG) {
+                int j = (int)ks[q];
+                j = (valid && j >= 0 && j < N) ? j : 0;
+                double b[4] = {c.lp[4 * (size_t)j], c.lp[4 * (size_t)j + 1], c.lp[4 * (size_t)j + 2], c.lp[4 * (size_t)j + 3]};
+                ks[2 * KNN1 + q] = lines_cosangle(a, b, 9.0);                          // :55
+                ks[3 * KNN1 + q] = proximity(ks[KNN1 + q], len_a, line_length(b), 1.0);  // :65
+            }
+            wave_sync();
+            // np.argsort(cosphi)[::-1][0:k2] (:57-59): descending, ties -> later position first
+            for (int q = gl; q < k1; q += ROWG) {
+                const double cq = ks[2 * KNN1 + q];
+                int rank = 0;
+                for (int p = 0; p < k1; ++p) {
+                    const double cp = ks[2 * KNN1 + p];
+                    rank += (cp > cq) || (cp == cq && p > q);
+                }
+                if (rank < k2) ks[4 * KNN1 + rank] = ks[3 * KNN1 + q] * cq;                 // :66
+            }
+            wave_sync();
+            if (gl == 0 && valid) {
+                double sum = 0.0;
+                for (int r = 0; r < k2; ++r) sum += ks[4 * KNN1 + r];                       // :68, in rank order
+                c.lscore[i] = sum / k2;                                                 // :70
+                double vx = a[0] - a[2], vy = a[1] - a[3];                              // lines_angles (:765-776)
+                double nr = norm2(vx, vy);
+                double phi = fabs(acos(clip(vx / nr, -1.0, 1.0)));
+                c.langle[i] = phi > PI_D / 2 ? PI_D - phi : phi;
+            }
+            wave_sync();
+        }
+        block_sync();
+        return;
+    }
     // per-wave kNN scratch carved from the partial-sum buffer: [k1] idx(as double), dist, cos, prox
     double* ks = SCRATCH() + wave_id() * (4 * KNN1 + KNN2);   // idx, dist, cos, prox per neighbour + term by rank
     const int k1 = N < KNN1 ? N : KNN1;

@@ -3,6 +3,7 @@
 // One "slot" = the private working set of one image while its workgroup runs.  Sized for the
 // largest image of the batch; with 288 GB of HBM3E a few thousand slots of N = 1000 fit at once.
 //   lsim   N x ld   fp64   (the dominant stream: read once per E-step)
+//   pdist  N x ld   fp64   (closest distances of the line pairs; written and read once, by the setup)
 //   lvsq / pvl / w  mcap x ldn fp64 ([vp][line]: lines contiguous -> coalesced per-line threads)
 //   wsrc   N x mcap fp64   ([line][vp]: VPs contiguous -> wave-uniform broadcast in the smoother)
 #ifndef VPK_EM_LAYOUT_HPP_
@@ -14,7 +15,7 @@ namespace vpk {
 
 struct EmLayout {
     int ldn, ld, mcap, nwaves;
-    size_t lsim, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, part, cl, assoc, idx;
+    size_t lsim, pdist, den, lweight, langle, lscore, rowsum, lvsq, pvl, w, wsrc, drow, part, cl, assoc, idx;
     size_t lcopy, lpcopy, state;
     size_t total_doubles;
 };
@@ -51,6 +52,7 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     size_t o = 0;
     const size_t n = (size_t)L.ldn;
     L.lsim = o;    o += use_weights ? n * n : 8;
+    L.pdist = o;   o += use_weights ? n * n : 8;       // pair distances (setup only: the kNN rating reads rows of it)
     L.den = o;     o += n;
     L.lweight = o; o += n;
     L.langle = o;  o += n;

@@ -129,6 +129,14 @@ VPK_DEV void argmin_take(double& v, int& idx, double u, int j) {
 VPK_DEV double readlane_f64(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+// the same over one DPP row of 16 lanes (ROWG): four rotate steps, result in every lane of the row
+constexpr int ROWG = 16;
+VPK_DEV void row16_argmin(double& v, int& idx) {
+    argmin_take(v, idx, row_ror_f64<8>(v), row_ror_i32<8>(idx));
+    argmin_take(v, idx, row_ror_f64<4>(v), row_ror_i32<4>(idx));
+    argmin_take(v, idx, row_ror_f64<2>(v), row_ror_i32<2>(idx));
+    argmin_take(v, idx, row_ror_f64<1>(v), row_ror_i32<1>(idx));
+}
 VPK_DEV void wave_argmin(double& v, int& idx) {
     argmin_take(v, idx, row_ror_f64<8>(v), row_ror_i32<8>(idx));
     argmin_take(v, idx, row_ror_f64<4>(v), row_ror_i32<4>(idx));
