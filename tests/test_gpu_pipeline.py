@@ -138,6 +138,10 @@ def test_bench_modes_produce_a_valid_line(mode):
     assert line["em_stats"]["ok_images"] == 12
     assert line["parity"]["images"] == 12 and line["parity"]["all_criteria"] == 12
     assert line["roofline"]["bound"] in ("mfma", "hbm") and 0 < line["roofline"]["frac"] < 1
+    assert line["dtype"].startswith("f32 (CNN, MFMA)")      # the headline run uses the native f32 matrix path ...
+    if mode == "lanes":                                      # ... and the split-precision path is reported beside it
+        alt = line["alt_precision"]
+        assert alt["value"] > 0 and alt["steps"] == 3 and "bf16" in alt["cnn"]
 
 
 def test_sharded_benchmark_two_ranks_on_one_gpu(tmp_path):
