@@ -1,11 +1,11 @@
 // cnn_split_gemm.hpp -- f32-accurate implicit-GEMM convolution on the bf16 matrix cores (included by vpk_cnn.hip).
 //
 // gfx950 has no TF32-like mode: f32-input MFMA runs at 1/16 of the bf16 rate.  An f32 number is EXACTLY the sum of three
-// bf16 numbers (8 + 8 + 8 significand bits, obtained by truncation: x1 = hi16(x), x2 = hi16(x - x1), x3 = x - x1 - x2), a
+// bf16 numbers (8 + 8 + 8 significand bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2, rounding to nearest), a
 // product of two bf16 numbers is exact in f32, and the bf16 MFMA accumulates in f32.  So
 //     a * b = sum_{i,j} a_i b_j      (9 exact partial products)
-// and the six products with i + j <= 4 carry everything above 2^-24 |a b| -- the size of the single rounding an f32 FMA
-// makes anyway; the three dropped ones are below 2^-31 |a b|.  Six bf16 MFMAs per f32 MFMA-equivalent = 6/16 of the time
+// and the six products with i + j <= 4 carry everything but a_2 b_3 + a_3 b_2 + a_3 b_3 <= 2^-24 |a b| -- the size of the
+// single rounding an f32 FMA makes anyway (tests/test_split_precision_math.py).  Six bf16 MFMAs per f32 MFMA-equivalent = 6/16 of the time
 // of the native f32 matrix path.  (cuBLAS ships the same idea as "BF16x9" FP32 emulation; "x6" drops the terms that are
 // below the accumulator's own rounding.)  tests/test_gpu_cnn.py compares both paths with an fp64 oracle: their errors
 // are of the same size.
@@ -40,11 +40,17 @@ struct SplitDims {
 
 constexpr int SG_BN = 256;          // columns per tile: 8 blocks of 32
 
-// f32 -> three bf16 pieces (truncation; exact: the three add up to x)
+// f32 -> three bf16 pieces, each the round-to-nearest-even bf16 of what is left: x - p0 and (x - p0) - p1 are exact in
+// f32 and the last remainder has at most 8 significant bits, so p0 + p1 + p2 == x exactly.  Rounding (not truncating)
+// keeps |p1| <= 2^-8 |x| and |p2| <= 2^-16 |x|, which bounds the dropped products at 2^-24 |a b|.
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    const unsigned b = __float_as_uint(x);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+}
 __device__ __forceinline__ void split3(float x, unsigned short& p0, unsigned short& p1, unsigned short& p2) {
-    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
+    const unsigned b0 = bf16_rne_bits(x);
     const float r1 = x - __uint_as_float(b0);
-    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    const unsigned b1 = bf16_rne_bits(r1);
     const float r2 = r1 - __uint_as_float(b1);
     p0 = (unsigned short)(b0 >> 16);
     p1 = (unsigned short)(b1 >> 16);

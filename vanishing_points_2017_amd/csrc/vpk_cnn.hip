@@ -1209,13 +1209,14 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                                 const int tap = s_ % sd.ntaps, c = (s_ / sd.ntaps) * 16 + 8 * (ln >> 5) + e;   // step = (channel group, tap)
                                 float w = 0.f;
                                 if (m < t.OC) w = wsrc[((size_t)(g * t.OC + m) * t.IC + c) * t.KH * t.KH + tap];
-                                unsigned b0, b1, b2;
-                                float r1, r2;
-                                memcpy(&b0, &w, 4); b0 &= 0xffff0000u;
-                                float f0; memcpy(&f0, &b0, 4); r1 = w - f0;
-                                memcpy(&b1, &r1, 4); b1 &= 0xffff0000u;
-                                float f1; memcpy(&f1, &b1, 4); r2 = r1 - f1;
-                                memcpy(&b2, &r2, 4);
+                                auto rne = [](float x) { unsigned b; memcpy(&b, &x, 4); return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u; };
+                                const unsigned b0 = rne(w);                 // the same three pieces as split3() on the device
+                                float f0; memcpy(&f0, &b0, 4);
+                                const float r1 = w - f0;
+                                const unsigned b1 = rne(r1);
+                                float f1; memcpy(&f1, &b1, 4);
+                                const float r2 = r1 - f1;
+                                unsigned b2; memcpy(&b2, &r2, 4);
                                 const size_t base = ((((size_t)g * sd.ksteps + s_) * sd.mblocks + mb) * 3) * 512 + (size_t)ln * 8 + e;
                                 pk[base] = (unsigned short)(b0 >> 16);
                                 pk[base + 512] = (unsigned short)(b1 >> 16);
