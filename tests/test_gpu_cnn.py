@@ -56,11 +56,16 @@ def test_bench_batch_against_the_oracle(batch):
     sphere = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=batch)])
     ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
     net = cnn.Net(w, mean)
-    for tap in (1, 2, 7, 8):                               # pool1, conv2, pool5, fc6
-        out, got = net.forward(sphere, tap=tap)
-        want = taps[cnn_torch.TAPS[tap]].reshape(got.shape)
-        assert np.abs(got - want).max() <= 2e-4 * (1.0 + np.abs(want).max()), cnn_torch.TAPS[tap]
-        assert np.abs(out - ref).max() <= 2e-5
+    try:
+        for mode in (0, 1):                                # native f32 matrix path; split-bf16 convolutions (other tiles:
+            net.set_precision(mode)                        #  256-column tiles, 4- and 8-wave workgroups, chained epilogues)
+            for tap in (1, 2, 7, 8):                       # pool1, conv2, pool5, fc6
+                out, got = net.forward(sphere, tap=tap)
+                want = taps[cnn_torch.TAPS[tap]].reshape(got.shape)
+                assert np.abs(got - want).max() <= 2e-4 * (1.0 + np.abs(want).max()), (mode, cnn_torch.TAPS[tap])
+                assert np.abs(out - ref).max() <= 2e-5, mode
+    finally:
+        net.set_precision(0)
     assert np.abs(ref - 0.5).max() > 1e-3                  # the response maps are not a constant
 
 
