@@ -5,14 +5,14 @@
 // product of two bf16 numbers is exact in f32, and the bf16 MFMA accumulates in f32.  So
 //     a * b = sum_{i,j} a_i b_j      (9 exact partial products)
 // and the six products with i + j <= 4 carry everything but a_2 b_3 + a_3 b_2 + a_3 b_3 <= 2^-24 |a b| -- the size of the
-// single rounding an f32 FMA makes anyway (tests/test_split_precision_math.py).  Six bf16 MFMAs per f32 MFMA-equivalent = 6/16 of the time
-// of the native f32 matrix path.  (cuBLAS ships the same idea as "BF16x9" FP32 emulation; "x6" drops the terms that are
+// single rounding an f32 FMA makes anyway (tests/test_split_precision_math.py).  Six bf16 MFMAs per f32 MFMA-equivalent
+// = 6/16 of the matrix-pipe time of the native f32 path.  (cuBLAS ships the same idea as "BF16x9" FP32 emulation; "x6" drops the terms that are
 // below the accumulator's own rounding.)  tests/test_gpu_cnn.py compares both paths with an fp64 oracle: their errors
 // are of the same size.
 //
 // Data layout (chosen for the matrix cores, not inherited from the f32 path):
 //   activations  [image][y][x][channel / 16][piece 0..2][16 channels] bf16, with the convolution's zero border
-//                (split_nhwc_kernel writes them from the f32 NCHW planes); K order = (kh, kw, channel), so a K16 step = 16
+//                (split_nhwc_kernel writes them from the f32 NCHW planes); K steps = (channel group, kh, kw), so a K16 step = 16
 //                consecutive channels of one tap = 96 contiguous bytes per pixel (all three pieces): the gather touches
 //                1.5 cache lines per pixel instead of 3 half-used ones;
 //   weights      pre-split and pre-permuted on the host into MFMA fragment order:
@@ -21,7 +21,9 @@
 //                an A fragment is written by ONE global_load_lds_dwordx4 (lane l brings the 16 bytes lane l will later read
 //                back with one conflict-free ds_read_b128); a block of 32 columns arrives as [column][piece][k half] (3 KB,
 //                three DMA instructions of 64 consecutive 16-byte chunks) and is read back with a 96-byte lane stride.
-// Tile = (WAVES_M * TM * 32) x 256 outputs, 8 waves (WAVES_M x 4 in N... see below), three stages in flight.
+// Tile = (WAVES_M * TM * 32) x 256 outputs: WAVES_M x WAVES_N waves (8 with three stages in flight and one workgroup per
+// CU, or 4 with two stages and two workgroups per CU), each wave TM x (8 / WAVES_N) blocks of 32 x 32.  K16 steps run over
+// the taps first, then over the channel groups.
 #ifndef VPK_CNN_SPLIT_GEMM_HPP_
 #define VPK_CNN_SPLIT_GEMM_HPP_
 
