@@ -182,6 +182,21 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
                  double* counts_out, double* counts_w_out, int32_t* num_vp_out, int64_t* assoc_out,
                  int32_t* iterations_out, int32_t* status_out, uint32_t* flags_out,
                  double* metric_out, double* trace_out);
+/* EM_result['distribution'] (vp_localisation.py:441: the probability_functions.PDF of the LAST calc_probabilities call,
+ * probability_functions.py:99-120) of every image of the NEXT vpk_em_batch call (the setting is consumed by that call; a
+ * NULL argument clears it).  Device buffers, rows beyond an image's VP count are zero:
+ *   p_v B x max_vp (PDF.v), angles B x max_vp x 2 (PDF.angles: alpha, beta), p_l sum(N) (PDF.l),
+ *   p_lv sum(N) x max_vp (PDF.lv, [line][vp]), p_vl sum(N) x max_vp (PDF.vl transposed to [line][vp]),
+ *   lvsq sum(N) x max_vp (PDF.lvsq).  Not available together with time-sliced launches. */
+typedef struct vpk_em_dist_out {
+    double* p_v;
+    double* angles;
+    double* p_l;
+    double* p_lv;
+    double* p_vl;
+    double* lvsq;
+} vpk_em_dist_out;
+int vpk_em_set_distribution_out(vpk_handle* h, const vpk_em_dist_out* d);
 /* bytes of device workspace the next vpk_em_batch with these sizes will hold (informational) */
 size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const vpk_em_params* p,
                               int n_init);

@@ -15,9 +15,10 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    # one reference run per file; auc.npz and the whole-config result tables (full_c<config>.npz) are other schemas
+    # one reference run per file; auc.npz, the whole-config result tables (full_c<config>.npz) and the final
+    # distributions (dist_<case>.npz, a companion of <case>.npz) are other schemas
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
-                  if f.endswith(".npz") and f not in ("auc.npz", "frontend.npz") and not f.startswith("full_c"))
+                  if f.endswith(".npz") and f not in ("auc.npz", "frontend.npz") and not f.startswith(("full_c", "dist_")))
 
 
 @pytest.fixture(scope="session")

@@ -227,3 +227,37 @@ def test_edge_cases_in_one_ragged_batch():
     assert got["status"] == 0 and got["iterations"] == ref["iterations"]
     assert np.array_equal(got["vp_assoc"], ref["vp_assoc"])
     assert abserr(got["vp"], ref["vp"]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_n12", "clean3_n60", "yud_n120", "yud_n250", "nosplit_n150"])
+def test_distribution_matches_the_reference(name):
+    """EM_result['distribution'] (vp_localisation.py:441): the PDF tuple of the reference's last calc_probabilities call
+    (tests/golden/dist_<case>.npz, oracle/make_dist_golden.py) against vpk_em_set_distribution_out -- same shapes
+    (probability_functions.py:120), values to the accuracy the E-step unit tests hold after a whole run."""
+    import os
+    from conftest import GOLDEN
+    from vanishing_points_2017_amd import em as gem, vp_localisation
+    from vanishing_points_2017_amd.probability_functions import PDF
+    g = load(name)
+    want = dict(np.load(os.path.join(GOLDEN, "dist_" + name + ".npz")))
+    kw = {k: v for k, v in em_kwargs(g).items() if k != "init_vp"}
+    res = gem.em_batch([_scene(g)], want_distribution=True, **kw)[0]
+    check_em_result(res, g)
+    p = res["distribution"]
+    assert isinstance(p, PDF)
+    for field, key in (("v", "p_v"), ("lv", "p_lv"), ("vl", "p_vl"), ("l", "p_l"), ("lvsq", "lvsq"), ("angles", "angles")):
+        assert getattr(p, field).shape == want[key].shape, field
+    # observed: angles 4e-13, p_v 4e-13 (relative), lvsq 2e-13, p_lv 2e-11 of its maximum, p_l 7e-11 (relative), p_vl 2e-12
+    assert abserr(p.angles, want["angles"]) <= 1e-10
+    assert relerr(p.v, want["p_v"]) <= 1e-10
+    assert abserr(p.lvsq, want["lvsq"]) <= 1e-10
+    scale = np.abs(want["p_lv"]).max()
+    assert abserr(p.lv, want["p_lv"]) <= 1e-9 * scale
+    assert relerr(p.l, want["p_l"]) <= 1e-8
+    assert abserr(p.vl, want["p_vl"]) <= 1e-9                        # posteriors in [0, 1]
+    assert np.allclose(p.vl.sum(axis=0)[p.l > 1e-12], 1.0, atol=1e-9)   # calc_pvl: columns sum to one
+    # without the request the key stays None (and the drop-in surface returns the tuple when asked)
+    assert gem.em_batch([_scene(g)], **kw)[0]["distribution"] is None
+    r2 = vp_localisation.expectation_maximisation(g["l"].copy(), g["lp"].copy(), g["cnn_response"],
+                                                  sphere_image=g["sphere_image"], return_distribution=True, **kw)
+    assert isinstance(r2["distribution"], PDF) and np.array_equal(r2["distribution"].vl, p.vl)

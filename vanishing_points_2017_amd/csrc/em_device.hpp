@@ -1893,6 +1893,13 @@ struct EmOut {
     double* trace;    // (num_iter + 1) x TRACE_COLS or null
     int max_vp;
     double* dbg = nullptr;   // test hook: per iteration [M, s[0..MAXM), cur[0..3 MAXM)] before the E-step
+    // EM_result['distribution'] (vpk_em_set_distribution_out), all null or all set
+    double* d_pv = nullptr;      // max_vp
+    double* d_angles = nullptr;  // max_vp x 2
+    double* d_pl = nullptr;      // N
+    double* d_plv = nullptr;     // N x max_vp
+    double* d_pvl = nullptr;     // N x max_vp
+    double* d_lvsq = nullptr;    // N x max_vp
 };
 
 VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
@@ -1916,6 +1923,39 @@ VPK_DEVFN void write_result(EmCtx& c, EmOut& o, int status, int iterations) {
         if (o.metric)
             for (int m = 0; m < o.max_vp; ++m)
                 o.metric[(size_t)n * o.max_vp + m] = m < M ? c.w[(size_t)m * c.ldn + n] : 0.0;
+    }
+    if (o.d_pv) {
+        // The PDF of the last calc_probabilities call (vp_localisation.py:415/:430 -> :441): lvsq and p_vl are where the last
+        // E-step left them, p_lv and p_l are re-evaluated from lvsq with the E-step's expressions (it keeps their
+        // product with p_v only), the angles from the VPs with the prior's (probability_functions.py:252-259).
+        for (int m = tid(); m < o.max_vp; m += nthreads()) {
+            const bool ok = m < M;
+            double alpha = 0.0, beta = 0.0;
+            if (ok) {
+                const double x0 = sh.nxt[3 * m], x1 = sh.nxt[3 * m + 1];
+                beta = asin(x1);
+                double inner = x0 / cos(beta);
+                inner = inner < 1 ? inner : (is_nan(inner) ? inner : 1.0);
+                inner = inner > -1 ? inner : (is_nan(inner) ? inner : -1.0);
+                alpha = asin(inner);
+            }
+            o.d_pv[m] = ok ? sh.pv[m] : 0.0;
+            o.d_angles[2 * m] = alpha;
+            o.d_angles[2 * m + 1] = beta;
+        }
+        for (int n = tid(); n < N; n += nthreads()) {
+            double pl = 0.0;
+            for (int m = 0; m < o.max_vp; ++m) {
+                const bool ok = m < M;
+                const double lv = ok ? c.lvsq[(size_t)m * c.ldn + n] : 0.0;
+                const double plv = ok ? exp_underflow(-(lv / (2 * sh.s[m]))) * sh.k2[m] : 0.0;   // calc_plv :137-145
+                if (ok) pl += plv * sh.pv[m];
+                o.d_lvsq[(size_t)n * o.max_vp + m] = lv;
+                o.d_plv[(size_t)n * o.max_vp + m] = plv;
+                o.d_pvl[(size_t)n * o.max_vp + m] = ok ? c.pvl[(size_t)m * c.ldn + n] : 0.0;
+            }
+            o.d_pl[n] = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;                                   // :116-117
+        }
     }
     block_sync();
     if (tid() == 0) {

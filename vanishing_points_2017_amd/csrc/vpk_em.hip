@@ -60,6 +60,7 @@ struct EmBatchArgs {
     double* metric_out;
     double* trace_out;
     int wt_doubles;
+    vpk_em_dist_out dist;       // all null = not requested
 };
 
 // ---- time-sliced launches (vpk_em_set_time_slice) ------------------------------------------------
@@ -189,6 +190,14 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
             o.flags = a.flags_out + img;
             o.metric = a.metric_out ? a.metric_out + (size_t)off * a.max_vp : nullptr;
             o.trace = a.trace_out ? a.trace_out + (size_t)img * (a.prm.num_iter + 1) * TRACE_COLS : nullptr;
+            if (a.dist.p_v) {
+                o.d_pv = a.dist.p_v + (size_t)img * a.max_vp;
+                o.d_angles = a.dist.angles + (size_t)img * a.max_vp * 2;
+                o.d_pl = a.dist.p_l + off;
+                o.d_plv = a.dist.p_lv + (size_t)off * a.max_vp;
+                o.d_pvl = a.dist.p_vl + (size_t)off * a.max_vp;
+                o.d_lvsq = a.dist.lvsq + (size_t)off * a.max_vp;
+            }
         }
         // An image that has not been started when the deadline has passed is parked as it is -- unless its
         // list is full: then it runs now (a longer launch, never a lost image).
@@ -638,6 +647,11 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     a.vp_out = vp_out; a.sigma_out = sigma_out; a.counts_out = counts_out; a.counts_w_out = counts_w_out;
     a.num_vp_out = num_vp_out; a.assoc_out = (long long*)assoc_out; a.iterations_out = iterations_out;
     a.status_out = status_out; a.flags_out = flags_out; a.metric_out = metric_out; a.trace_out = trace_out;
+    a.dist = vpk_em_dist_out{};
+    if (h->em_dist_set) {                  // consumed by this call
+        a.dist = h->em_dist;
+        h->em_dist_set = false;
+    }
     a.wt_doubles = mode.wt_doubles;
     EmSliceArgs ss = {};
     if (sliced) {
@@ -646,6 +660,18 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     }
     hipLaunchKernelGGL(em_batch_kernel, dim3(wgs), dim3(EM_THREADS), mode.lds_bytes, h->stream, a, ss);
     VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
+
+int vpk_em_set_distribution_out(vpk_handle* h, const vpk_em_dist_out* d) {
+    if (!h) return VPK_ERR_ARG;
+    if (!d) { h->em_dist_set = false; return VPK_OK; }
+    if (!d->p_v || !d->angles || !d->p_l || !d->p_lv || !d->p_vl || !d->lvsq)
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_distribution_out: every buffer must be given");
+    if (h->em_slice_ms > 0.0)
+        return vpk_fail(h, VPK_ERR_STATE, "vpk_em_set_distribution_out: not available with time-sliced launches");
+    h->em_dist = *d;
+    h->em_dist_set = true;
     return VPK_OK;
 }
 

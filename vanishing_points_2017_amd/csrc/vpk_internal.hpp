@@ -44,6 +44,8 @@ struct vpk_handle {
     // time-sliced EM launches (vpk_em_set_time_slice): images not finished within a launch's budget are parked
     // in device-side lists and resumed by the next launch; their slots outlive the launch
     double em_slice_ms = 0.0;        // 0 = off: every call runs its images to completion
+    vpk_em_dist_out em_dist = {};    // vpk_em_set_distribution_out: outputs of the next vpk_em_batch call
+    bool em_dist_set = false;
     int em_slice_nmax = 0;           // slots are sized for at least this many lines
     void* em_sess = nullptr;         // [counters | slot flags | parked-image list A | list B]
     size_t em_sess_bytes = 0;

@@ -23,9 +23,10 @@ def _params(kw):
 
 
 def em_batch_device(rt, offsets, l, lp, cnn, sphere, init_vp=None, params=None, max_vp=MAX_VP,
-                    want_metric=False, want_trace=False):
+                    want_metric=False, want_trace=False, want_distribution=False):
     """Run vpk_em_batch on device tensors.  offsets: host int64 (B+1).  l (sum N x 3, f64) is
-    normalised in place.  Returns a dict of device tensors."""
+    normalised in place.  Returns a dict of device tensors.  want_distribution adds "dist": the arrays of
+    EM_result['distribution'] (include/vpk.h: vpk_em_set_distribution_out)."""
     torch = rt.torch
     offsets = _lib.host_i64(offsets)
     batch = offsets.shape[0] - 1
@@ -47,6 +48,12 @@ def em_batch_device(rt, offsets, l, lp, cnn, sphere, init_vp=None, params=None, 
             "metric": torch.empty((max(total, 1), max_vp), dtype=torch.float64, device=dev) if want_metric else None,
             "trace": torch.empty((batch, p.num_iter + 1, 12), dtype=torch.float64, device=dev) if want_trace else None,
         }
+        if want_distribution:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+            out["dist"] = {"p_v": z(batch, max_vp), "angles": z(batch, max_vp, 2), "p_l": z(max(total, 1)),
+                           "p_lv": z(max(total, 1), max_vp), "p_vl": z(max(total, 1), max_vp), "lvsq": z(max(total, 1), max_vp)}
+            dd = _lib.EmDistOut(*[rt.ptr(out["dist"][k]) for k in ("p_v", "angles", "p_l", "p_lv", "p_vl", "lvsq")])
+            rt.check(rt.lib.vpk_em_set_distribution_out(rt.h, ctypes.byref(dd)))
         n_init = 0 if init_vp is None else int(init_vp.shape[-2])
         rc = rt.lib.vpk_em_batch(
             rt.h, batch, offsets.ctypes.data_as(ctypes.c_void_p), rt.ptr(l), rt.ptr(lp), rt.ptr(cnn),
@@ -87,15 +94,17 @@ def upload_batch(rt, scenes):
     return dev
 
 
-def em_batch(scenes, device=0, want_metric=False, want_trace=False, **kwargs):
+def em_batch(scenes, device=0, want_metric=False, want_trace=False, want_distribution=False, **kwargs):
     """Host-in / host-out convenience: refine a list of images, return one reference-style
-    result dict per image (keys as vp_localisation.py:441-442 plus status/flags/l)."""
+    result dict per image (keys as vp_localisation.py:441-442 plus status/flags/l).  'distribution' is the
+    reference's probability_functions.PDF tuple when want_distribution is set, None otherwise."""
     rt = get_runtime(device)
     p = _params(kwargs)
     d = upload_batch(rt, scenes)
     out = em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], d["init_vp"], p,
-                          want_metric=want_metric, want_trace=want_trace)
+                          want_metric=want_metric, want_trace=want_trace, want_distribution=want_distribution)
     rt.synchronize()
+    dist = {k: v.cpu().numpy() for k, v in out.pop("dist").items()} if want_distribution else None
     host = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
     l_norm = d["l"].cpu().numpy()
     offs = d["offsets"]
@@ -113,6 +122,11 @@ def em_batch(scenes, device=0, want_metric=False, want_trace=False, **kwargs):
                 "decision_metric": None if host["metric"] is None else host["metric"][lo:hi, :m].T.copy(),
                 "iterations": int(host["iterations"][b]), "distribution": None,
                 "sigma": host["sigma"][b, :m].copy()})
+            if dist is not None:                        # probability_functions.py:120, shapes as the reference's
+                from .probability_functions import PDF
+                res["distribution"] = PDF(v=dist["p_v"][b, :m].copy(), lv=dist["p_lv"][lo:hi, :m].copy(),
+                                          vl=dist["p_vl"][lo:hi, :m].T.copy(), l=dist["p_l"][lo:hi].copy(),
+                                          lvsq=dist["lvsq"][lo:hi, :m].copy(), angles=dist["angles"][b, :m].copy())
         else:   # vp_localisation.py:205-206
             res.update({"vp_assoc": None, "vp": None, "counts": None, "count_id": None,
                         "decision_metric": None, "iterations": 0})
