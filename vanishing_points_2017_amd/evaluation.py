@@ -161,16 +161,19 @@ def run_cnn(dataset, model_def, model_weights, mean_file, gpu=0, net=None):
 
 
 def run_em_batch(data, distance_measure="angle", use_weights=True, do_split=True, do_merge=True, device=0,
-                 defer_errors=False):
+                 defer_errors=False, store_distribution=False):
     """EM over a list of datum dicts in ONE launch; fills datum['EM_result'] like run_em_single.
     An image without any initial VP raises ValueError like the reference (vp_localisation.py:165) -- after
     the results of all other images have been filled in; with ``defer_errors`` the positions of such images
-    are returned instead (their EM_result stays None)."""
+    are returned instead (their EM_result stays None).  ``store_distribution`` fills EM_result['distribution'] with the
+    reference's PDF tuple (vp_localisation.py:441; three N x 64 fp64 arrays per image on the device while the batch
+    runs, which is why whole-dataset runs leave it None -- run_em_single keeps it like the reference)."""
     todo = [d for d in data if d.get('cnn_prediction') is not None]
     scenes = [{"l": d['lines']['lines'], "lp": d['lines']['line_segments'],
                "cnn_response": d['cnn_prediction'][:, :], "sphere_image": d['sphere_image']} for d in todo]
-    results = _em.em_batch(scenes, device=device, want_metric=True, distance_measure=distance_measure,
-                           use_weights=use_weights, do_split=do_split, do_merge=do_merge) if scenes else []
+    results = _em.em_batch(scenes, device=device, want_metric=True, want_distribution=store_distribution,
+                           distance_measure=distance_measure, use_weights=use_weights, do_split=do_split,
+                           do_merge=do_merge) if scenes else []
     failed = []
     for d, r in zip(todo, results):
         status = r.pop("status")
@@ -190,7 +193,7 @@ def run_em_batch(data, distance_measure="angle", use_weights=True, do_split=True
     return data
 
 
-def run_em(dataset, start=None, end=None, indices=None, device=0):
+def run_em(dataset, start=None, end=None, indices=None, device=0, store_distribution=False):
     """evaluation.py:295-329.  ``start``/``end`` slice the file list like the reference (:304-307: its only
     means of spreading a dataset over several processes); ``indices`` selects an arbitrary subset instead
     (one rank's share of a cost-balanced partition, sharding.shard_balanced) and ``device`` the GPU."""
@@ -201,7 +204,8 @@ def run_em(dataset, start=None, end=None, indices=None, device=0):
         files = files[start:min(end, len(files))]
     data = [_load_pickle(f) for f in files]
     failed = run_em_batch(data, distance_measure=dataset['distance_measure'], use_weights=dataset['use_weights'],
-                          do_split=dataset['do_split'], do_merge=dataset['do_merge'], device=device, defer_errors=True)
+                          do_split=dataset['do_split'], do_merge=dataset['do_merge'], device=device, defer_errors=True,
+                          store_distribution=store_distribution)
     for f, d in zip(files, data):
         if d.get('EM_result') is None:
             print("SKIPPING: file %s is incomplete" % f)
