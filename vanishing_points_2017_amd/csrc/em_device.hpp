@@ -1194,15 +1194,24 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
                 }
                 j += UNR;
             }
-            for (; j < j1; ++j) {
-                double a[C];
-                load_cols<C>(lcol + (size_t)j * c.ld, a);
-                const double* wr = wt + (size_t)j * W;
+            // the slice's last rows (fewer than a batch): all their loads are issued before the first is used -- one
+            // memory round trip instead of one per row (N = 245: 7 such rows per slice and column group, a third of the
+            // phase's time); same rows in the same order
+            const int rem = j1 - j;
+            if (rem > 0) {
 #pragma unroll
-                for (int t = 0; t < W; ++t) {
-                    const double wv = wr[t];
+                for (int u = 0; u < UNR - 1; ++u)
+                    if (u < rem) load_cols<C>(lcol + (size_t)(j + u) * c.ld, a0[u]);
 #pragma unroll
-                    for (int q = 0; q < C; ++q) acc[t][q] = fma(wv, a[q], acc[t][q]);
+                for (int u = 0; u < UNR - 1; ++u) {
+                    if (u >= rem) break;
+                    const double* wr = wt + (size_t)(j + u) * W;
+#pragma unroll
+                    for (int t = 0; t < W; ++t) {
+                        const double wv = wr[t];
+#pragma unroll
+                        for (int q = 0; q < C; ++q) acc[t][q] = fma(wv, a0[u][q], acc[t][q]);
+                    }
                 }
             }
 #pragma unroll
