@@ -1236,27 +1236,29 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
     if (!direct) {
         block_sync();
         if (tid() == 0) sh.dbuf[9] += lap(tq_);
-        // one column per thread, VPs in batches of RB: all the partials of a batch are loaded before any is
-        // used (the loop is latency-bound otherwise: the stores to w keep the compiler from hoisting loads)
+        // Work items = (column, batch of RB VPs), columns fastest (coalesced), dealt round-robin to ALL threads: with one
+        // thread per column only N of the 512 threads worked, each through M / RB dependent batches of L2 round trips.
+        // All the partials of a batch are loaded before any is used (the stores to w keep the compiler from hoisting
+        // loads); each (column, VP) is still summed over the slices in the fixed order 0..7.
         constexpr int RB = 4;
-        for (int kk = tid(); kk < N; kk += nthreads()) {
+        const int nbatch = (M + RB - 1) / RB;
+        for (int item = tid(); item < N * nbatch; item += nthreads()) {
+            const int t0 = (item / N) * RB, kk = item - (item / N) * N;
             const double blw = bias * c.lweight[kk], dn = c.den[kk];
             cgdp pcol = c.part + kk;
-            for (int t0 = 0; t0 < M; t0 += RB) {
-                double v[RB][8];
+            double v[RB][8];
 #pragma unroll
-                for (int u = 0; u < RB; ++u)
+            for (int u = 0; u < RB; ++u)
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        v[u][r] = (t0 + u < M && r < R) ? pcol[((size_t)r * c.mcap + t0 + u) * c.ldn] : 0.0;
+                for (int r = 0; r < 8; ++r)
+                    v[u][r] = (t0 + u < M && r < R) ? pcol[((size_t)r * c.mcap + t0 + u) * c.ldn] : 0.0;
 #pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    if (t0 + u >= M) break;
-                    double sum = 0.0;
+            for (int u = 0; u < RB; ++u) {
+                if (t0 + u >= M) break;
+                double sum = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) sum += v[u][r];                                   // fixed order
-                    c.w[(size_t)(m0 + t0 + u) * c.ldn + kk] = (wt[(size_t)kk * W + t0 + u] + blw * sum) / dn;
-                }
+                for (int r = 0; r < 8; ++r) sum += v[u][r];                                   // fixed order
+                c.w[(size_t)(m0 + t0 + u) * c.ldn + kk] = (wt[(size_t)kk * W + t0 + u] + blw * sum) / dn;
             }
         }
     }
