@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak (--cnn-precision 1 only)
 
 
 def parse():
@@ -418,10 +419,16 @@ def main():
                     "unit": "TFLOP/s",
                     "traffic": (tc["hbm_read_bytes"] + tc["hbm_write_bytes"]) if tc else None,
                     "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel"}
+        if args.cnn_precision == 1:     # conv2 on the bf16 matrix cores: six bf16 MFMA products per f32 product
+            roof_cnn.update({"kernel": "conv_gemm_split_kernel(%s)" % name, "achieved": 6.0 * roof_cnn["achieved"],
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                             "f32_equivalent_tflops": roof_cnn["achieved"],
+                             "note": "achieved = bf16 MFMA flops issued (6 x the layer's f32 flops) / live layer time, which "
+                                     "here includes the split pass of the layer's input (split_nhwc_kernel)"})
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
         roof_cnn["traffic_source"] = traffic_src
         pm = (mfma.get("bench_yud_102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)") if args.workload == "yud" else None
-        if pm:      # counter view of the same kernel inside the bench: fraction of SIMD-cycles with a busy matrix pipe, and the
+        if pm and args.cnn_precision == 0:      # counter view of the same kernel inside the bench: fraction of SIMD-cycles with a busy matrix pipe, and the
                     # shader clock it ran at (the 157.3 TF peak assumes 2.4 GHz; under this load the part clocks lower)
             roof_cnn["pmc"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"], "source": mfma_src}
             pa = (mfma.get("cnn_alone_B102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)")
