@@ -763,23 +763,46 @@ VPK_DEVFN void prior_setup(EmCtx& c) {
     block_sync();
     if (tid() == 0) {
         sh.sigma_prior = PI_D / (1.282 * GRIDN);  // :71
-        float sum = np_pairwise_sum_f32_400(keep);
-        float dv = (float)(2 * PI_D * sh.sigma_prior * sh.sigma_prior);
-        int nc = 0;
-        for (int i = 0; i < NCELL; ++i) {
-            float w = keep[i] / sum;
-            w = w / dv;
-            sh.wts[i] = w;
-            if (w > 0 && nc < MAXCOMP) {  // calc_pdf visits cells in index order (:20-21)
-                sh.pma[nc] = grid_centre(i % GRIDN);   // means[:,0] = alpha, varies along columns
-                sh.pmb[nc] = grid_centre(i / GRIDN);   // means[:,1] = beta, varies along rows
-                sh.pw[nc] = (double)w;
-                ++nc;
-            }
-        }
-        sh.ncomp = nc;
+        ((float*)SCRATCH())[NCELL] = np_pairwise_sum_f32_400(keep);
     }
     block_sync();
+    // normalise every cell in parallel, then list the positive ones in cell-index order (calc_pdf visits cells in
+    // index order, :20-21): position = positive cells in earlier waves + positive cells in lower lanes.  (One thread
+    // walking the 400 cells with two f32 divisions each was ~50 us per image.)
+    {
+        const float sum = ((float*)SCRATCH())[NCELL];
+        const float dv = (float)(2 * PI_D * sh.sigma_prior * sh.sigma_prior);
+        int* wcount = (int*)(SCRATCH() + 256);            // per-wave counts (behind the 401 floats)
+        for (int base = 0; base < NCELL; base += nthreads()) {   // one round for 512 threads
+            const int i = base + tid();
+            float w = 0.f;
+            if (i < NCELL) {
+                w = keep[i] / sum;
+                w = w / dv;
+            }
+            const unsigned long long pos = wave_ballot(i < NCELL && w > 0);
+            if (lane() == 0) wcount[wave_id()] = popcount64(pos);
+            block_sync();
+            int before = (base == 0) ? 0 : sh.ncomp;
+            for (int k = 0; k < wave_id(); ++k) before += wcount[k];
+            const int nc = before + popcount64(pos & lanes_below());
+            if (i < NCELL) {
+                sh.wts[i] = w;
+                if (w > 0 && nc < MAXCOMP) {
+                    sh.pma[nc] = grid_centre(i % GRIDN);   // means[:,0] = alpha, varies along columns
+                    sh.pmb[nc] = grid_centre(i / GRIDN);   // means[:,1] = beta, varies along rows
+                    sh.pw[nc] = (double)w;
+                }
+            }
+            block_sync();
+            if (tid() == 0) {
+                int tot = before;                              // thread 0: wave 0, lane 0 -> before = carried count
+                for (int k = 0; k < nwaves(); ++k) tot += wcount[k];
+                sh.ncomp = tot < MAXCOMP ? tot : MAXCOMP;
+            }
+            block_sync();
+        }
+    }
 }
 
 // find_maxima (vp_localisation.py:13-31) + find_initial_vps (:111-165).  Leaves the VPs in
@@ -820,19 +843,42 @@ VPK_DEVFN void initial_vps(EmCtx& c) {
         int r0 = ra * S / GRIDN, r1 = (ra + 1) * S / GRIDN;   // rows of the FLIPPED image (:114,:133)
         int c0 = rb * S / GRIDN, c1 = (rb + 1) * S / GRIDN;
         int bw = c1 - c0, npix = (r1 - r0) * bw;
-        int mxv = 0;
-        for (int p = lane(); p < npix; p += WAVE) {
-            int rr = r0 + p / bw, cc = c0 + p % bw;
-            int v = c.sphere[(size_t)(S - 1 - rr) * S + cc];
-            mxv = v > mxv ? v : mxv;
-        }
-        mxv = wave_max_int(mxv);
-        if (mxv == 0) continue;                               // :137-142
-        int cntp = 0, sr = 0, sc = 0;
-        for (int p = lane(); p < npix; p += WAVE) {
-            int rr = p / bw, cc = p % bw;
-            int v = c.sphere[(size_t)(S - 1 - (r0 + rr)) * S + c0 + cc];
-            if (v == mxv) { ++cntp; sr += rr; sc += cc; }
+        // the slice's pixels are loaded ONCE, ten per lane with all loads in flight (25 x 25 pixels at S = 500); the
+        // maximum and the positions that reach it come out of registers.  (Two passes of dependent byte loads were
+        // ~20 memory round trips per cell.)
+        constexpr int PV = 10;
+        int mxv = 0, cntp = 0, sr = 0, sc = 0;
+        if (npix <= PV * WAVE) {
+            int vals[PV];
+#pragma unroll
+            for (int q = 0; q < PV; ++q) {
+                const int p = lane() + q * WAVE;
+                const int pc = p < npix ? p : 0;
+                const int v = c.sphere[(size_t)(S - 1 - (r0 + pc / bw)) * S + c0 + pc % bw];
+                vals[q] = p < npix ? v : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < PV; ++q) mxv = vals[q] > mxv ? vals[q] : mxv;
+            mxv = wave_max_int(mxv);
+            if (mxv == 0) continue;                           // :137-142
+#pragma unroll
+            for (int q = 0; q < PV; ++q) {
+                const int p = lane() + q * WAVE;
+                if (vals[q] == mxv) { ++cntp; sr += p / bw; sc += p % bw; }
+            }
+        } else {
+            for (int p = lane(); p < npix; p += WAVE) {
+                int rr = r0 + p / bw, cc = c0 + p % bw;
+                int v = c.sphere[(size_t)(S - 1 - rr) * S + cc];
+                mxv = v > mxv ? v : mxv;
+            }
+            mxv = wave_max_int(mxv);
+            if (mxv == 0) continue;                           // :137-142
+            for (int p = lane(); p < npix; p += WAVE) {
+                int rr = p / bw, cc = p % bw;
+                int v = c.sphere[(size_t)(S - 1 - (r0 + rr)) * S + c0 + cc];
+                if (v == mxv) { ++cntp; sr += rr; sc += cc; }
+            }
         }
         cntp = wave_sum_int(cntp);
         sr = wave_sum_int(sr);
