@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--em-wgs", type=int, default=-1,
-                    help="workgroups (CUs) per EM launch; default: images/3 for yud (the launch lasts as long as its "
+                    help="workgroups (CUs) per EM launch; default: 0.29 x images for yud (the launch lasts as long as its "
                          "slowest image either way, and the CNN keeps the other CUs), one per image for stress")
     ap.add_argument("--cnn-precision", type=int, default=0, choices=[0, 1],
                     help="0: native f32 matrix instructions (default); 1: conv2..5 as six bf16 matrix products per f32 "
@@ -237,7 +237,7 @@ def main():
         lanes = [get_runtime(local_rank, "em%d" % i) for i in range(n_lanes)]
         rt = lanes[0]
         rt_cnn = get_runtime(local_rank, "cnn")
-        em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, count // 3) if args.workload == "yud" else 0)
+        em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, (count * 5) // 17) if args.workload == "yud" else 0)   # 30 of 102: measured optimum (26: -1.5 %, 34: -1.5 %)
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)
     scenes, kw = make_workload(args.workload, rank, count)
