@@ -261,3 +261,37 @@ def test_distribution_matches_the_reference(name):
     r2 = vp_localisation.expectation_maximisation(g["l"].copy(), g["lp"].copy(), g["cnn_response"],
                                                   sphere_image=g["sphere_image"], return_distribution=True, **kw)
     assert isinstance(r2["distribution"], PDF) and np.array_equal(r2["distribution"].vl, p.vl)
+
+
+def test_distribution_request_is_consumed_by_one_call_and_validated():
+    """vpk_em_set_distribution_out applies to the next vpk_em_batch call only; incomplete buffer sets and time-sliced
+    launches are refused (include/vpk.h)."""
+    import ctypes
+    import torch
+    from vanishing_points_2017_amd import _lib, em as gem
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(0)
+    g = load("clean3_n60")
+    d = gem.upload_batch(rt, [_scene(g)])
+    p = gem._params({})
+    l0 = d["l"].clone()
+    out1 = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, p, want_distribution=True)
+    rt.synchronize()
+    keep = {k: v.clone() for k, v in out1["dist"].items()}
+    assert float(keep["p_vl"].abs().sum()) > 0
+    for v in out1["dist"].values():
+        v.fill_(-7.0)
+    d["l"].copy_(l0)
+    gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, p)      # no request: nothing written
+    rt.synchronize()
+    assert all(bool((v == -7.0).all()) for v in out1["dist"].values())
+    bad = _lib.EmDistOut(rt.ptr(keep["p_v"]), None, rt.ptr(keep["p_l"]), rt.ptr(keep["p_lv"]), rt.ptr(keep["p_vl"]),
+                         rt.ptr(keep["lvsq"]))
+    assert rt.lib.vpk_em_set_distribution_out(rt.h, ctypes.byref(bad)) != 0
+    rt.handle.em_set_time_slice(5.0, 64)
+    try:
+        ok = _lib.EmDistOut(*[rt.ptr(keep[k]) for k in ("p_v", "angles", "p_l", "p_lv", "p_vl", "lvsq")])
+        assert rt.lib.vpk_em_set_distribution_out(rt.h, ctypes.byref(ok)) != 0
+    finally:
+        rt.handle.em_set_time_slice(0.0, 0)
+    assert rt.lib.vpk_em_set_distribution_out(rt.h, None) == 0
