@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
     }
 }
 
+// -DSG_TIME: s_memtime around the phases of a stage, read back by scripts/split_gemm_phase_times.py (development only)
 #ifdef SG_TIME
 __device__ long long sg_dbg[256 * 8 * 8];
 #define SG_T(i) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; }
