@@ -2,7 +2,7 @@
 images 102.., config 3 images 103.., config 4 images beyond the 64 stored ones.  The oracle runs in a process pool
 (the GPU box has many host cores).  Any mismatch is dumped to gpurun_out/mismatch_fresh/.
 
-    python scripts/sweep_fresh.py [images per config]
+    python scripts/sweep_fresh.py [images per config [offset [configs]]]     e.g.  400 200 2,4
 """
 import multiprocessing as mp
 import os
@@ -26,11 +26,15 @@ def oracle_one(sc):
 
 def main():
     per = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+    offset = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    only = [int(c) for c in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 3, 4]
     from vanishing_points_2017_amd import em as gem, synth
     os.makedirs("gpurun_out/mismatch_fresh", exist_ok=True)
     total = bad = 0
     pool = mp.get_context("fork").Pool(min(64, os.cpu_count() or 8))
-    for cfg, start in ((2, 102), (3, 103), (4, 2000)):
+    for cfg, start in ((2, 102 + offset), (3, 103 + offset), (4, 2000 + offset)):
+        if cfg not in only:
+            continue
         scenes = [next(synth.config_scenes(cfg, count=1, start=start + i)) for i in range(per)]
         t0 = time.time()
         refs = pool.map(oracle_one, scenes, chunksize=1)
