@@ -92,6 +92,12 @@ int vpk_device_info(const vpk_handle* h, int32_t info[4]);
  * queue inside the launch, which then lasts about as long as its slowest image anyway and leaves the
  * other CUs to the CNN. */
 int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
+/* Which kernel evaluates weight_matrix (vp_localisation.py:515-524) inside the EM.  0 (default): the row-sliced
+ * kernel (partial sums never leave the wave, operands by DPP row broadcast) wherever its LDS panel fits, the round-1/2
+ * kernels elsewhere; 1: always the round-1/2 kernels.  Both sum every (column, VP) in the same order, so every output
+ * of vpk_em_batch / vpk_weight_matrix is bit-identical under either setting (tests/test_gpu_em.py): the switch exists
+ * for that test and for A/B timing. */
+int vpk_em_set_smoother(vpk_handle* h, int mode);
 
 /* Time-sliced EM launches for pipelines (run_cnn of batch k+1 while the EM of batch k is unfinished,
  * evaluation.py:254-329).  The EM of a never-converging image takes 99 iterations (vp_localisation.py:256)

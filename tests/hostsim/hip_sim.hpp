@@ -61,6 +61,10 @@ template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]) {
     for (int q = 0; q < C; ++q) out[q] = p[q];
 }
 VPK_DEV void sched_fence() {}
+// never executed with one lane (the row-sliced smoother needs a 64-lane wave); present so that the source compiles
+template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b) { for (int q = 0; q < 8; ++q) a[q] = fma(op, b, a[q]); }
+VPK_DEV void wave_lds_order() {}
+VPK_DEV int uniform_int(int v) { return v; }
 VPK_DEV void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
 VPK_DEV long long __double_as_longlong(double v) { long long r; memcpy(&r, &v, 8); return r; }
 VPK_DEV double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }

@@ -295,3 +295,61 @@ def test_distribution_request_is_consumed_by_one_call_and_validated():
     finally:
         rt.handle.em_set_time_slice(0.0, 0)
     assert rt.lib.vpk_em_set_distribution_out(rt.h, None) == 0
+
+
+def _with_smoother(mode, fn):
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(0)
+    rt.handle.em_set_smoother(mode)
+    try:
+        return fn()
+    finally:
+        rt.handle.em_set_smoother(0)
+
+
+def test_row_sliced_smoother_gives_the_bits_of_the_round2_kernels():
+    """vpk_em_set_smoother: the row-sliced weight_matrix kernel (default) and the round-1/2 kernels sum every
+    (column, VP) in the same order -- eight row slices, ascending rows, slices in order -- so whole EM runs agree in
+    EVERY output bit: VPs, variances, the decision metric, iteration counts, assignments.  YUD-shape images (102, the
+    bench's batch: every N from 100 to 400, up to 34 hypotheses), small and odd line counts (slices that are short or
+    empty), and ECD-shape images that do not fit the row-sliced panel and fall back."""
+    from vanishing_points_2017_amd import em as gem, synth
+    scenes = list(synth.config_scenes(2, count=102))
+    for n in (3, 7, 8, 9, 15, 17, 33, 57, 63, 64, 65, 66, 127, 129):
+        sc = synth.make_scene(900 + n, max(n, 40), 3)
+        scenes.append(dict(sc, l=sc["l"][:n].copy(), lp=sc["lp"][:n].copy()))
+    scenes += list(synth.config_scenes(3, count=6))
+    new = _with_smoother(0, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
+    old = _with_smoother(1, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
+    ok = 0
+    for a, b in zip(new, old):
+        assert a["status"] == b["status"]
+        if a["status"] != 0:
+            continue
+        ok += 1
+        assert a["iterations"] == b["iterations"]
+        for key in ("vp", "sigma", "counts", "counts_weighted", "vp_assoc", "decision_metric"):
+            assert np.array_equal(a[key], b[key]), key
+    assert ok >= 110
+
+
+@pytest.mark.parametrize("n,m", [(100, 25), (245, 22), (380, 24), (400, 32), (64, 3), (65, 9), (9, 2), (500, 17),
+                                 (900, 8), (1000, 8), (1100, 8)])
+def test_weight_matrix_row_sliced_vs_round2_vs_numpy(n, m):
+    """vpk_weight_matrix under both smoother settings on random inputs: identical bits, and both within rounding of
+    the NumPy expression of vp_localisation.py:515-524.  (900..1024 lines: the round-2 kernel's single-chain mode,
+    which the row-sliced kernel leaves alone.)"""
+    from vanishing_points_2017_amd import kernels
+    rng = np.random.RandomState(n * 100 + m)
+    lsim = rng.rand(n, n) ** 6
+    lsim = lsim + lsim.T
+    np.fill_diagonal(lsim, 0.0)
+    pvl = rng.rand(m, n)
+    pvl /= pvl.sum(0)
+    lw = rng.rand(n) * 0.4
+    new = _with_smoother(0, lambda: kernels.weight_matrix(pvl, lw, lsim))
+    old = _with_smoother(1, lambda: kernels.weight_matrix(pvl, lw, lsim))
+    assert np.array_equal(new, old)
+    w_ = pvl * lw
+    want = (w_ + lw * (w_ @ lsim)) / (1 + lw * lsim.sum(0))
+    assert relerr(new, want) <= 1e-12

@@ -102,6 +102,7 @@ struct EmCtx {
     gdp lcopy;    // N x 3 normalised lines (l points here once the setup has run)
     gdp lpcopy;   // N x 4 segment end points (lp likewise)
     gdp state;    // snapshot of Shared while the image is suspended
+    int smoother = 0; // 0: the row-sliced smoother wherever it applies; 1: always the round-1/2 kernels (A/B tests: same bits)
 };
 
 // point the context's scratch pointers into one slot
@@ -928,6 +929,33 @@ VPK_DEVFN void line_geometry_setup(EmCtx& c) {
     block_sync();
 }
 
+// ---- geometry of the row-sliced smoother (smooth_rows) -----------------------------------------------------------
+// The N rows of lsim are cut into EIGHT slices of jch = ceil(N / 8) consecutive rows (the summation order every stored
+// result was produced with: per (column, VP) eight ascending fma chains, then ((((p0 + p1) + p2) + ...) + p7).  The
+// operand panel w_[line][vp] is kept slice by slice, [slice][row in slice][W], with the slice stride padded to 16 mod 32
+// doubles so that the two slices whose rows one ds_read_b64 touches (lanes 0-31: two rows of 16 lanes) lie in
+// different halves of the 64 banks.
+constexpr int RS_TT = 4;                               // VPs per reduction round (one output per lane and round)
+constexpr int RS_RED_DOUBLES = RS_TT * 16 * 9;         // per wave: [vp][column][8 slices + 1 pad]
+constexpr int RS_PANEL_FLAG = 0x100;                   // sh.ibuf[5] = RS_PANEL_FLAG + W: the E-step left this layout
+VPK_DEV int rs_jchunk(int N) { return (N + 7) >> 3; }
+VPK_DEV int rs_sstride(int jch, int W) { const int q = jch * W; return q + ((16 - q) & 31); }
+VPK_DEV int rs_panel_doubles(int jch, int W) { return 8 * rs_sstride(jch, W) + 32; }   // + slack: lanes read 16 + i past a row
+VPK_DEV int rs_row(int n, int jch, int S, int W) { const int sl = n / jch; return sl * S + (n - sl * jch) * W; }
+// Which smoother the next smooth() takes for M hypotheses -- decided in ONE place because the E-step writes the panel in
+// that smoother's layout.  0: none in LDS (wsrc in HBM), 1: smooth_full's [line][W], 2: smooth_rows' sliced layout.
+VPK_DEV int smooth_plan(const EmCtx& c, int M) {
+    const int N = c.N;
+    if (!c.prm.use_weights || M <= 0 || M > 32) return 0;
+    const int Wp = ((M + MT - 1) / MT) * MT;
+    if (WAVE == 64 && nwaves() == 8 && c.smoother == 0) {
+        const int colw = N > WAVE ? 2 * WAVE : WAVE;               // smooth_full's column groups: when they divide evenly
+        const bool direct = (((N + colw - 1) / colw) % 8) == 0;    // among the waves it sums ALL rows in one chain
+        if (!direct && rs_panel_doubles(rs_jchunk(N), Wp) + 8 * RS_RED_DOUBLES <= c.wt_doubles) return 2;
+    }
+    return ((long long)N * Wp <= c.wt_doubles) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // E-step: calc_probabilities (probability_functions.py:99-147, "angle" branch)
 // ---------------------------------------------------------------------------------------------
@@ -978,7 +1006,9 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     // When the smoother's whole operand panel fits in LDS the weights go there directly ([line][vp],
     // Wp = M rounded to the VP tile) as well as to HBM, and smooth_full skips its staging pass.
     const int Wp = ((M + MT - 1) / MT) * MT;
-    const bool panel = c.prm.use_weights && M > 0 && M <= 32 && (long long)N * Wp <= c.wt_doubles;
+    const int plan = smooth_plan(c, M);                      // 1: [line][Wp] for smooth_full, 2: slice by slice for smooth_rows
+    const bool panel = plan != 0;
+    const int rs_jch = rs_jchunk(N), rs_S = rs_sstride(rs_jch, Wp);
     double* wt = WT();
     // one thread per line; the VP loop is unrolled four deep with the four sqrt/div/exp chains written
     // side by side (independent until the ordered sum), because a lone wave per SIMD is bound by the
@@ -989,7 +1019,7 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     for (int n = tid(); n < N; n += nthreads()) {
         const double lmx = gmx[n], lmy = gmy[n], v2x = gvx[n], v2y = gvy[n], n2 = gn2[n];
         gdp lvq = c.lvsq + n, pvq = c.pvl + n;
-        double* wl = wt + (size_t)n * Wp;                    // this line's panel row; parks p_lv p_v until p_l is known
+        double* wl = wt + (plan == 2 ? (size_t)rs_row(n, rs_jch, rs_S, Wp) : (size_t)n * Wp);   // this line's panel row; parks p_lv p_v until p_l is known
         double pl = 0.0;
         int m = 0;
         for (; m + EU <= M; m += EU) {
@@ -1034,23 +1064,26 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
 #pragma unroll
             for (int u = 0; u < EU; ++u) {
                 pvq[(size_t)(m + u) * c.ldn] = q[u];
-                ws[m + u] = q[u] * lw;                       // weight_matrix :519
-                if (panel) wl[m + u] = q[u] * lw;
+                if (panel) wl[m + u] = q[u] * lw;            // weight_matrix :519 (the HBM copy has no reader when the
+                else ws[m + u] = q[u] * lw;                  //   smoother takes the whole panel from LDS in one pass)
             }
         }
         for (; m < M; ++m) {
             const double q1 = (panel ? wl[m] : pvq[(size_t)m * c.ldn]) / pl;
             pvq[(size_t)m * c.ldn] = q1;
-            ws[m] = q1 * lw;
-            if (panel) wl[m] = q1 * lw;
+            if (panel) wl[m] = q1 * lw; else ws[m] = q1 * lw;
         }
         for (m = M; m < Wp; ++m) {                           // padding of the last VP tile
-            ws[m] = 0.0;
-            if (panel) wl[m] = 0.0;
+            if (panel) wl[m] = 0.0; else ws[m] = 0.0;
         }
     }
+    if (plan == 2)                                           // zero operand rows where a short or empty slice has no line
+        for (int p = N * Wp + tid(); p < 8 * rs_jch * Wp; p += nthreads()) {
+            const int j = p / Wp;
+            wt[rs_row(j, rs_jch, rs_S, Wp) + (p - j * Wp)] = 0.0;
+        }
     if (tid() == 0) sh.dbuf[15] += lap(tq_);
-    if (tid() == 0) sh.ibuf[5] = panel ? Wp : 0;             // consumed (and cleared) by smooth()
+    if (tid() == 0) sh.ibuf[5] = plan == 2 ? RS_PANEL_FLAG + Wp : (plan == 1 ? Wp : 0);   // consumed (and cleared) by smooth()
     block_sync();
 }
 
@@ -1312,6 +1345,136 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
     if (tid() == 0) sh.dbuf[10] += lap(tq_);
 }
 
+// Row-sliced smoother: the same eight row slices and the same summation order as smooth_full, but no partial sum ever
+// leaves the wave.  A wave owns 16 columns; its four rows of 16 lanes own the slices d and d + 4 (d = lane / 16), so the
+// eight partials of a (column, VP) live in the four lanes {column, 16 + column, ...} of ONE wave and are summed through a
+// 4.6 KB wave-private LDS scratch in the fixed order 0..7 -- no HBM/L2 round trip of the partials, no workgroup barrier
+// before the results are written.  The w_ operands no longer come as wave-uniform broadcast reads (W / 2 ds_read_b128
+// per row, as many LDS cycles as the FMAs take SIMD cycles): lane i of a row of 16 reads operand i (and 16 + i) of its
+// slice's row ONCE and the FMAs take them through DPP row_newbcast (fmac8_row_bcast).  Per lane and row of a slice:
+// one 8-byte lsim load (a row of 16 lanes = one 128-byte line), one or two 8-byte LDS reads, W FMAs.
+template <int NT>
+VPK_DEVFN void smooth_rows(EmCtx& c) {
+    Shared& sh = SH();
+    constexpr int W = NT * MT;
+    constexpr int UNR = 4;                          // rows per load batch and slice; two batches are in flight
+    const int N = uniform_int(c.N), M = uniform_int(sh.M);
+    const double bias = c.prm.wbias;
+    double* wt = WT();
+    long long tq_ = clock_ticks();
+    const int jch = rs_jchunk(N), S = rs_sstride(jch, W);
+    if (sh.ibuf[5] != RS_PANEL_FLAG + W) {          // no E-step left the panel in place (vpk_weight_matrix): stage it
+        for (int p = tid(); p < N * W; p += nthreads()) {
+            const int j = p / W, m = p - j * W;
+            wt[rs_row(j, jch, S, W) + m] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m] : 0.0;
+        }
+        for (int p = N * W + tid(); p < 8 * jch * W; p += nthreads()) {   // rows a short or empty slice does not have
+            const int j = p / W;
+            wt[rs_row(j, jch, S, W) + (p - j * W)] = 0.0;
+        }
+        block_sync();
+    }
+    if (tid() == 0) sh.dbuf[8] += lap(tq_);
+    double* red = wt + rs_panel_doubles(jch, W) + wave_id() * RS_RED_DOUBLES;
+    const int d = lane() >> 4, i = lane() & 15;
+    const int jA0 = d * jch, jB0 = (d + 4) * jch;
+    int nA = N - jA0, nB = N - jB0;                 // rows of this lane's two slices
+    nA = nA < 0 ? 0 : (nA > jch ? jch : nA);
+    nB = nB < 0 ? 0 : (nB > jch ? jch : nB);
+    const double* oA = wt + (size_t)d * S + i;      // operand i of row r of the slice: oA[r * W] (and oA[r * W + 16])
+    const double* oB = wt + (size_t)(d + 4) * S + i;
+    const size_t ld = (size_t)uniform_int(c.ld), ldn = (size_t)uniform_int(c.ldn);
+    cgdp lsim = c.lsim, lweight = c.lweight, den = c.den;   // (locals: the compiler barriers below would make it re-read c)
+    gdp wout = c.w;
+    // Every lane walks jch rows of both of its slices, also where a slice is short or empty (the last ones): there the
+    // row index is clamped to a real row and the operand row of the panel is ZERO (estep / the staging pass above clear
+    // the rows of the "lines" N .. 8 jch - 1), and fma(0, finite, acc) returns acc bit for bit (acc is never -0: it
+    // starts at +0 and a zero product is absorbed).  So the loop has no divergent branch, every load is unconditional,
+    // and the compiler can count its waits.
+    const int nfull = jch / UNR, rem = jch - nfull * UNR;
+    const int lastA = nA > 0 ? jA0 + nA - 1 : N - 1, lastB = nB > 0 ? jB0 + nB - 1 : N - 1;
+    const int kstep = uniform_int(nwaves()) * 16;
+    for (int k0 = uniform_int(wave_id()) * 16; k0 < N; k0 += kstep) {
+        const int k = k0 + i;
+        const int kc = k < N ? k : N - 1;           // lanes past the last column stay active: they are operand sources
+        cgdp pcol = lsim + kc;
+        const double lwk = lweight[kc];             // requested now, consumed after the row loop
+        double dn = den[kc];
+        double accA[W], accB[W];
+#pragma unroll
+        for (int t = 0; t < W; ++t) { accA[t] = 0.0; accB[t] = 0.0; }
+        double aA[UNR], aB[UNR], nA_[UNR], nB_[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rn = u < jch ? u : jch - 1;
+            const int gA = jA0 + rn < lastA ? jA0 + rn : lastA, gB = jB0 + rn < lastB ? jB0 + rn : lastB;
+            aA[u] = pcol[(size_t)gA * ld];
+            aB[u] = pcol[(size_t)gB * ld];
+        }
+        double cA0 = oA[0], cA1 = W >= 24 ? oA[16] : 0.0, cB0 = oB[0], cB1 = W >= 24 ? oB[16] : 0.0;   // operands of row 0
+        for (int b = 0; b <= nfull; ++b) {
+            const int r = b * UNR;
+            const int nrow = b < nfull ? UNR : rem;  // rows of this batch (the last one is the remainder, maybe empty)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {         // the next batch's loads go out before this batch's FMAs
+                int rn = r + UNR + u;
+                rn = rn < jch ? rn : jch - 1;
+                const int gA = jA0 + rn < lastA ? jA0 + rn : lastA, gB = jB0 + rn < lastB ? jB0 + rn : lastB;
+                nA_[u] = pcol[(size_t)gA * ld];
+                nB_[u] = pcol[(size_t)gB * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (u < nrow) {                     // wave-uniform
+                    int rq = r + u + 1;             // the next row's operands are requested before this row's FMAs
+                    rq = rq < jch ? rq : jch - 1;
+                    const double* qA = oA + (size_t)rq * W;
+                    const double* qB = oB + (size_t)rq * W;
+                    const double xA0 = qA[0], xA1 = W >= 24 ? qA[16] : 0.0, xB0 = qB[0], xB1 = W >= 24 ? qB[16] : 0.0;
+                    fmac8_row_bcast<0>(accA, cA0, aA[u]);
+                    if (W >= 16) fmac8_row_bcast<8>(accA + (W >= 16 ? 8 : 0), cA0, aA[u]);
+                    if (W >= 24) fmac8_row_bcast<0>(accA + (W >= 24 ? 16 : 0), cA1, aA[u]);
+                    if (W >= 32) fmac8_row_bcast<8>(accA + (W >= 32 ? 24 : 0), cA1, aA[u]);
+                    fmac8_row_bcast<0>(accB, cB0, aB[u]);
+                    if (W >= 16) fmac8_row_bcast<8>(accB + (W >= 16 ? 8 : 0), cB0, aB[u]);
+                    if (W >= 24) fmac8_row_bcast<0>(accB + (W >= 24 ? 16 : 0), cB1, aB[u]);
+                    if (W >= 32) fmac8_row_bcast<8>(accB + (W >= 32 ? 24 : 0), cB1, aB[u]);
+                    cA0 = xA0; cA1 = xA1; cB0 = xB0; cB1 = xB1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { aA[u] = nA_[u]; aB[u] = nB_[u]; }
+        }
+        // the eight partials of every (VP, column) of this wave, summed in slice order: RS_TT VPs per round through the
+        // wave's scratch [vp][column][slice]; lane (d, i) writes its slices d and d + 4 and finishes VP t0 + d of column i
+        const double blw = bias * lwk;
+        asm volatile("" : "+v"(dn));                // dn has arrived before the rounds: no wait inside them (a wait there
+                                                    //   would also wait for the previous round's store)
+        const double* wk = wt + rs_row(kc, jch, S, W);       // w_[kc][.]
+        double* rw = red + (size_t)i * 9 + d;
+        const double* rr_ = red + ((size_t)d * 16 + i) * 9;
+#pragma unroll
+        for (int t0 = 0; t0 < W; t0 += RS_TT) {
+            if (t0 < M) {
+#pragma unroll
+                for (int u = 0; u < RS_TT; ++u) {
+                    rw[(size_t)u * 16 * 9] = accA[t0 + u];
+                    rw[(size_t)u * 16 * 9 + 4] = accB[t0 + u];
+                }
+                wave_lds_order();
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += rr_[q];                                      // fixed order
+                const int t = t0 + d;
+                if (t < M && k < N) wout[(size_t)t * ldn + k] = (wk[t] + blw * sum) / dn;
+                wave_lds_order();
+            }
+        }
+    }
+    block_sync();
+    if (tid() == 0) sh.dbuf[9] += lap(tq_);
+}
+
 VPK_DEVFN void smooth_dispatch(EmCtx& c);
 VPK_DEVFN void smooth(EmCtx& c) {
     smooth_dispatch(c);
@@ -1328,6 +1491,13 @@ VPK_DEVFN void smooth_dispatch(EmCtx& c) {
         return;
     }
     if (M == 0) return;
+    if (WAVE == 64 && (sh.ibuf[5] >= RS_PANEL_FLAG || smooth_plan(c, M) == 2)) {   // (an E-step's panel decides; none: the plan)
+        if (M <= 8) smooth_rows<1>(c);
+        else if (M <= 16) smooth_rows<2>(c);
+        else if (M <= 24) smooth_rows<3>(c);
+        else smooth_rows<4>(c);
+        return;
+    }
     // single-pass kernel on as many VPs as the LDS panel holds (N x wfit doubles, wfit a multiple of the VP
     // tile, at most 32 accumulator sets per lane); more VPs than that take further passes over lsim
     int wfit = (int)((c.wt_doubles / N) / MT) * MT;

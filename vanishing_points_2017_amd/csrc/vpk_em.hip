@@ -27,7 +27,7 @@ constexpr int EM_WAVES = EM_THREADS / 64;
 constexpr size_t EM_LDS_BYTES = SH_BYTES + WT_DOUBLES * sizeof(double);
 // when a batch leaves at most one workgroup per CU, the workgroup takes (almost) the whole 160 KiB so
 // that the smoother's operand panel of any YUD/ECD-sized image fits and lsim is read once per E-step
-constexpr int WT_DOUBLES_BIG = 16384;   // 128 KiB
+constexpr int WT_DOUBLES_BIG = (int)((163840 - SH_BYTES) / sizeof(double)) / 32 * 32;   // everything a CU has (~147 KiB)
 constexpr size_t EM_LDS_BYTES_BIG = SH_BYTES + WT_DOUBLES_BIG * sizeof(double);
 static_assert(EM_LDS_BYTES_BIG <= 163840, "LDS per CU");
 #define VPK_SHARED_DECL Shared& sh = SH()
@@ -60,6 +60,7 @@ struct EmBatchArgs {
     double* metric_out;
     double* trace_out;
     int wt_doubles;
+    int smoother;               // vpk_em_set_smoother
     vpk_em_dist_out dist;       // all null = not requested
 };
 
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
             c.n_init = a.n_init;
             c.prm = a.prm;
             c.wt_doubles = a.wt_doubles;
+            c.smoother = a.smoother;
             o.max_vp = a.max_vp;
             o.vp = a.vp_out + (size_t)img * a.max_vp * 3;
             o.sigma = a.sigma_out + (size_t)img * a.max_vp;
@@ -317,10 +319,10 @@ __global__ __launch_bounds__(EM_BOUND) void estep_kernel(int n, int m, const dou
 __global__ __launch_bounds__(EM_BOUND) void weight_matrix_kernel(int n, int m, const double* p_vl,
                                                                    const double* lweight, const double* lsim,
                                                                    double bias, EmLayout L, double* ws,
-                                                                   double* w_out) {
+                                                                   double* w_out, int smoother, int wt_doubles) {
     VPK_SHARED_DECL;
     EmCtx c;
-    c.N = n; c.wt_doubles = WT_DOUBLES;
+    c.N = n; c.wt_doubles = wt_doubles; c.smoother = smoother;
     c.prm.use_weights = 1;
     c.prm.wbias = bias;
     bind_scratch(c, ws, L, false);
@@ -514,6 +516,7 @@ int em_flush(vpk_handle* h) {
     a.L = h->em_sess_layout;
     a.scratch = (double*)h->em_ws;
     a.wt_doubles = h->em_sess_wt_doubles;
+    a.smoother = h->em_smoother;
     hipLaunchKernelGGL(em_batch_kernel, dim3(h->em_sess_wgs), dim3(EM_THREADS), h->em_sess_lds, h->stream, a, ss);
     VPK_HIP(h, hipGetLastError());
     h->em_unflushed = false;
@@ -527,6 +530,12 @@ EmLayout small_layout(int n, int m) {
 }  // namespace
 
 extern "C" {
+
+int vpk_em_set_smoother(vpk_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_smoother: mode must be 0 or 1");
+    h->em_smoother = mode;
+    return VPK_OK;
+}
 
 int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups) {
     if (!h || max_workgroups < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_workgroups: bad argument");
@@ -653,6 +662,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
         h->em_dist_set = false;
     }
     a.wt_doubles = mode.wt_doubles;
+    a.smoother = h->em_smoother;
     EmSliceArgs ss = {};
     if (sliced) {
         ss = sess_next(h, h->em_slice_ms);
@@ -742,8 +752,9 @@ int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const dou
     EmLayout L = em_layout(n, (int)em_align((size_t)m, 8), EM_WAVES, true, false);
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
-    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, m, p_vl, lweight, lsim,
-                       bias, L, (double*)h->small_ws, w_out);
+    // the batch kernel's LDS budget, so that this entry point takes the same smoother an image of this size takes there
+    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES_BIG, h->stream, n, m, p_vl, lweight, lsim,
+                       bias, L, (double*)h->small_ws, w_out, h->em_smoother, WT_DOUBLES_BIG);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }

@@ -19,6 +19,7 @@ struct vpk_handle {
     int num_cu = 0;
     int cu_share = 0;            // CUs this handle's launches are sized for (= num_cu)
     int em_max_workgroups = 0;   // vpk_em_set_workgroups (0 = no cap)
+    int em_smoother = 0;         // vpk_em_set_smoother
     int lds_per_block = 0;
     int arch = 0;
     size_t total_mem = 0;

@@ -180,6 +180,37 @@ VPK_DEV void pin8(double& a0, double& a1, double& a2, double& a3, double& a4, do
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "memory");
 }
 
+// Eight fp64 FMAs whose first factor comes from ANOTHER lane of the same row of 16 lanes: acc[q] += (the value `op`
+// has in lane BASE + q of this lane's row) * b, q = 0..7 in this order.  DPP row_newbcast is the one DPP control the
+// double-precision ALU has on gfx90a+/gfx950 and it costs nothing on top of the FMA (scripts/ubench/dpp_fma.hip), so 16
+// lanes that hold 16 different operands replace 16 wave-uniform LDS broadcast reads by ONE 8-byte read per lane.  All
+// lanes of the row must be active (they are the operand sources).  The leading s_nop covers the wait states a DPP read
+// needs after a VALU write of `op`: the hazard recogniser does not look inside an asm statement.
+template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %8, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %8, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %8, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %8, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %8, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %8, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %8, %9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %8, %9 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "v"(op), "v"(b), "n"(BASE), "n"(BASE + 1), "n"(BASE + 2), "n"(BASE + 3), "n"(BASE + 4), "n"(BASE + 5),
+          "n"(BASE + 6), "n"(BASE + 7));
+}
+// a value every lane holds identically, moved to a scalar register: loops and branches on it are scalar (values read through
+// a context pointer arrive in vector registers and would otherwise be treated as divergent)
+VPK_DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Order this wave's LDS accesses as written.  The LDS serves one wave's instructions in issue order, so a wave that
+// writes LDS and reads the words back (other lanes' words included: a wave's lanes run in lockstep) needs no wait and
+// no barrier instruction -- only the compiler must keep the order.
+VPK_DEV void wave_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // constant-rate (100 MHz) device clock for the optional phase timing in the EM trace
 VPK_DEV long long clock_ticks() { return (long long)wall_clock64(); }
 constexpr double CLOCK_US = 0.01;
