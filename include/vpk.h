@@ -47,7 +47,10 @@ enum vpk_em_status {
     VPK_EM_NO_VP = 1,         /* reference returns the all-None result (vp_localisation.py:258-260,
                                  :402-404) -- also used where the reference would raise on an empty
                                  argmax (M == 0 at :349)                                         */
-    VPK_EM_NO_INITIAL_VP = 2  /* reference raises ValueError from np.vstack([]) (:165)           */
+    VPK_EM_NO_INITIAL_VP = 2, /* reference raises ValueError from np.vstack([]) (:165)           */
+    VPK_EM_NO_SLOT = 3        /* time-sliced launches only: no working-set slot became free within the launch's
+                                 bounded wait (cannot happen while the documented slot invariant holds); the image
+                                 was NOT refined and its other outputs are unset -- an error, never a result */
 };
 /* bit flags OR-ed into flags_out: situations where third-party tie-breaking is implementation
  * defined (Python heapq order inside sklearn's AgglomerativeClustering, vp_localisation.py:574) */
@@ -98,6 +101,14 @@ int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
  * of vpk_em_batch / vpk_weight_matrix is bit-identical under either setting (tests/test_gpu_em.py): the switch exists
  * for that test and for A/B timing. */
 int vpk_em_set_smoother(vpk_handle* h, int mode);
+/* LDS the EM workgroup may plan with for its weight_matrix operand panel and the split's cluster matrix, in doubles;
+ * 0 (default) = everything a CU has beside the workgroup's state (~18 800).  A smaller budget sends images down the
+ * paths that larger images take by necessity -- the chunked smoother (operands staged through LDS piece by piece), the
+ * split's distance matrix and direction vectors in HBM.  Results agree to rounding, not to the bit: the chunked
+ * smoother sums a column's rows in ONE chain where the in-LDS kernels sum eight row slices; the parity bar
+ * (assignments exact, VPs 1e-4) holds either way, and the GPU tests use the switch to run those paths on the
+ * reference's small goldens.  Applies to vpk_em_batch and vpk_weight_matrix. */
+int vpk_em_set_lds_panel(vpk_handle* h, int doubles);
 
 /* Time-sliced EM launches for pipelines (run_cnn of batch k+1 while the EM of batch k is unfinished,
  * evaluation.py:254-329).  The EM of a never-converging image takes 99 iterations (vp_localisation.py:256)

@@ -38,7 +38,9 @@ for mode in (1, 0, 1, 0):
         for name, col in (("estep", 4), ("smooth", 5), ("mstep", 6)):
             tot[name] += tr[b, :it[b] + 1, col].sum()
     slow = int(np.argmax(tr[:, -1, 2]))
-    print("smoother %d: kernel %.2f ms | batch sums (ms): %s | slowest image %.2f ms (N=%d, %d iterations; smooth %.0f us/iter)" % (
-        mode, ms, {k: round(v / 1e3, 1) for k, v in tot.items()}, tr[slow, -1, 2] / 1e3,
-        int(d["offsets"][slow + 1] - d["offsets"][slow]), it[slow], tr[slow, :it[slow] + 1, 5].mean()))
+    print("smoother %d: kernel %.2f ms | batch sums (ms): %s | slowest image %.2f ms (N=%d, %d iterations; smooth %.0f us/iter; "
+          "smoother split of that image, ms: rows %.2f, staging + reduction + wait %.2f)" % (
+        mode, ms, {k: round(float(v) / 1e3, 1) for k, v in tot.items()}, tr[slow, -1, 2] / 1e3,
+        int(d["offsets"][slow + 1] - d["offsets"][slow]), it[slow], tr[slow, :it[slow] + 1, 5].mean(),
+        tr[slow, -1, 7] / 1e3, tr[slow, -1, 6] / 1e3))
 rt.handle.em_set_smoother(0)

@@ -65,6 +65,8 @@ VPK_DEV void sched_fence() {}
 template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b) { for (int q = 0; q < 8; ++q) a[q] = fma(op, b, a[q]); }
 VPK_DEV void wave_lds_order() {}
 VPK_DEV int uniform_int(int v) { return v; }
+VPK_DEV cgdp uniform_ptr(cgdp p) { return p; }
+VPK_DEV double load_at(cgdp base, unsigned byte_off) { return *reinterpret_cast<cgdp>(reinterpret_cast<const char*>(base) + byte_off); }
 VPK_DEV void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
 VPK_DEV long long __double_as_longlong(double v) { long long r; memcpy(&r, &v, 8); return r; }
 VPK_DEV double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }

@@ -19,6 +19,7 @@ static void make_ctx(EmCtx& c, std::vector<double>& buf, int n, const vpk_em_par
     c.N = n;
     c.prm = p;
     c.wt_doubles = WT_DOUBLES;
+    if (const char* e = getenv("VPK_SIM_WT_DOUBLES")) c.wt_doubles = atoi(e);   // the LDS budget the phases plan with (vpk_em_set_lds_panel)
     bind_scratch(c, buf.data(), L, p.do_split != 0);
 }
 

@@ -55,8 +55,12 @@ def default_params(**kw):
     return p
 
 
-def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, sliced=False, **kw):
+def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, sliced=False, lds_doubles=None, **kw):
     n = lp.shape[0]
+    if lds_doubles is None:     # the LDS budget the phases plan with (the library's vpk_em_set_lds_panel)
+        os.environ.pop("VPK_SIM_WT_DOUBLES", None)
+    else:
+        os.environ["VPK_SIM_WT_DOUBLES"] = str(int(lds_doubles))
     p = default_params(**kw)
     l = np.ascontiguousarray(l, dtype=np.float64)
     lp = np.ascontiguousarray(lp, dtype=np.float64)
@@ -82,6 +86,7 @@ def em_single(l, lp, cnn, sphere, init_vp=None, max_vp=64, want_metric=False, sl
     raw = np.ctypeslib.as_array(lib().sim_last_states(), shape=(p.num_iter, 1 + 4 * 64)).copy()
     states = [(raw[i, 65:65 + 3 * int(raw[i, 0])].reshape(-1, 3), raw[i, 1:1 + int(raw[i, 0])]) for i in range(p.num_iter)]
     os.environ.pop("VPK_SIM_SLICED", None)
+    os.environ.pop("VPK_SIM_WT_DOUBLES", None)
     return {"slices": slices, "states": states, "status": int(st[0]), "flags": int(fl[0]), "iterations": int(it[0]), "vp": vp[:m],
             "sigma": sigma[:m], "counts": counts[:m], "counts_weighted": cw[:m], "vp_assoc": assoc,
             "l": l, "trace": trace, "decision_metric": None if metric is None else metric[:, :m].T}

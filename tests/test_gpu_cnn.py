@@ -110,3 +110,28 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
             assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
         net.set_precision(0)
+
+
+def test_split_path_beyond_4_gib_of_activations():
+    """vpk_cnn_forward takes up to 4096 images per call; in the split-precision path conv2's input is 65 x 65 x 96 x 6 B =
+    2.4 MB per image, so image 1765 starts 4 GiB into the arena (conv4/5: ~1820, conv3: ~2730).  The gather offsets are
+    32-bit and relative to a tile's first image (cnn_split_gemm.hpp), never to the arena: with 1800 images -- six
+    distinct rasters repeated -- every image must give the bits its twin among the first six gives, and those must be
+    the native path's result to f32 rounding.  (Relative to the arena, images 1765.. silently read other images'
+    activations.)"""
+    from vanishing_points_2017_amd import cnn, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    six = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=6)])
+    net = cnn.Net(w, mean)
+    native = net.forward(six)
+    sphere = np.concatenate([six] * 300)
+    try:
+        net.set_precision(1)
+        out = net.forward(sphere)
+    finally:
+        net.set_precision(0)
+    assert out.shape == (1800, 20, 20)
+    assert np.abs(out[:6] - native).max() <= 2e-5
+    twins = out.reshape(300, 6, 20, 20)
+    assert np.array_equal(twins, np.broadcast_to(twins[:1], twins.shape))

@@ -68,3 +68,46 @@ def test_layout_change_while_images_are_parked_is_refused():
     rt.synchronize()
     assert int(out["iterations"].cpu()[0]) == 99
     rt.handle.em_set_time_slice(0.0)
+
+
+def test_full_parked_lists_make_images_run_on_instead_of_overflowing(monkeypatch):
+    """The device-side lists of parked images have a capacity (8192 not-yet-started, 1024 suspended images).  With the
+    capacities shrunk to 3 and 2 (VPK_EM_WAIT_CAP / VPK_EM_STARTED_CAP, read at vpk_create) a 40-image batch on 6
+    workgroups with a 0.2 ms budget overflows both: images that find the waiting list full start anyway and run to
+    completion (no deadline: they must not take a slot and suspend at once), images that find the suspended list full
+    are resumed on the spot.  Nothing is lost, nothing is written past a list, the launch ends, and every result
+    equals the uninterrupted one."""
+    from vanishing_points_2017_amd import em as gem, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    monkeypatch.setenv("VPK_EM_WAIT_CAP", "3")
+    monkeypatch.setenv("VPK_EM_STARTED_CAP", "2")
+    rt = get_runtime(0, "slice_caps")
+    monkeypatch.delenv("VPK_EM_WAIT_CAP")
+    monkeypatch.delenv("VPK_EM_STARTED_CAP")
+    rt.handle.em_set_workgroups(6)
+    scenes = list(synth.config_scenes(2, count=39, start=10)) + [next(synth.config_scenes(2, count=1, start=86))]
+    p = gem._params({})
+    d = gem.upload_batch(rt, scenes)
+    l0 = d["l"].clone()
+    rt.handle.em_set_time_slice(0.0)
+    ref = gem.em_batch_device(rt, d["offsets"], l0.clone(), d["lp"], d["cnn"], d["sphere"], None, p)
+    rt.synchronize()
+    ref = _host(ref)
+    assert ref["iterations"].max() == 99
+    rt.handle.em_set_time_slice(0.2, int(np.diff(d["offsets"]).max()))
+    keep = []
+    for step in range(3):
+        lb = l0.clone()
+        keep.append((lb, gem.em_batch_device(rt, d["offsets"], lb, d["lp"], d["cnn"], d["sphere"], None, p)))
+    with rt.on_stream():
+        rt.handle.em_flush()
+    rt.synchronize()
+    rt.handle.em_set_time_slice(0.0)
+    for lb, out in keep:
+        got = _host(out)
+        assert (got["status"] == ref["status"]).all() and (got["status"] != 3).all()
+        for k in ("iterations", "num_vp", "vp_assoc", "flags"):
+            assert np.array_equal(got[k], ref[k]), k
+        for b in range(len(scenes)):
+            m = int(ref["num_vp"][b])
+            assert np.array_equal(got["vp"][b, :m], ref["vp"][b, :m])

@@ -26,6 +26,19 @@ def test_full_run_matches_reference_golden(name):
     check_em_result(res, g, vp_tol=1e-9)
 
 
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith(("yud_n2", "ecd_", "periodicmerge", "mergeabort", "nosplit"))])
+def test_full_run_with_a_tiny_lds_budget(name):
+    """96 doubles of LDS to plan with (the library's vpk_em_set_lds_panel): no operand panel (smooth_blocks with a few
+    rows per chunk), a split set of more than 32 lines stages its direction vectors in the slot's HBM rows and clusters
+    there (round-2 advice: that staging had no bound in LDS).  Same goldens, same bar."""
+    g = load(name)
+    kw = em_kwargs(g)
+    res = simlib.em_single(g["l"].copy(), g["lp"], g["cnn_response"], g["sphere_image"], lds_doubles=96, **kw)
+    if res["status"] != 0:
+        res["vp"] = None
+    check_em_result(res, g, vp_tol=1e-9)
+
+
 @pytest.mark.parametrize("name", [c for c in CASES if "i_v0" in load(c)])
 def test_pieces(name):
     g = load(name)

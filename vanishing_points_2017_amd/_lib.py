@@ -33,7 +33,7 @@ class EmDistOut(ctypes.Structure):
 
 EXPORTS = [
     "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
-    "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_smoother", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_em_set_distribution_out", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
+    "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_smoother", "vpk_em_set_lds_panel", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_em_set_distribution_out", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_set_precision", "vpk_cnn_last_layer_ms",
     "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
     "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_line_counts", "vpk_cluster2", "vpk_horizon_batch", "vpk_lsd_detect",
@@ -61,6 +61,7 @@ def load():
     lib.vpk_device_info.argtypes = [c_void, ctypes.POINTER(ctypes.c_int32)]
     lib.vpk_em_set_workgroups.argtypes = [c_void, ctypes.c_int]
     lib.vpk_em_set_smoother.argtypes = [c_void, ctypes.c_int]
+    lib.vpk_em_set_lds_panel.argtypes = [c_void, ctypes.c_int]
     lib.vpk_em_set_time_slice.argtypes = [c_void, ctypes.c_double, ctypes.c_int]
     lib.vpk_em_set_distribution_out.argtypes = [c_void, ctypes.c_void_p]
     lib.vpk_em_flush.argtypes = [c_void]
@@ -140,6 +141,9 @@ class Handle(object):
 
     def em_set_smoother(self, mode):
         self.check(self.lib.vpk_em_set_smoother(self.h, int(mode)))
+
+    def em_set_lds_panel(self, doubles):
+        self.check(self.lib.vpk_em_set_lds_panel(self.h, int(doubles)))
 
     def em_set_time_slice(self, slice_ms, n_max=0):
         """Time-sliced EM launches (include/vpk.h: vpk_em_set_time_slice); 0 switches back."""

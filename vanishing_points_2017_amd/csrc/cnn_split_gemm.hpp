@@ -137,6 +137,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WPE) void conv_gemm_split_k
         SG_T(6)
         // ---- B gather: this wave brings column block `wave` (32 columns x 96 bytes per stage) as 192 chunks of 16 bytes;
         //      chunk index = column * 6 + piece * 2 + k half, lane l of instruction q brings chunk 64 q + l ----
+        // Offsets are 32-bit and relative to the tile's FIRST image (a tile of SG_BN columns spans a few images at most):
+        // relative to the arena they would pass 2^32 bytes from image ~1765 on (conv2: 65 x 65 x 96 x 6 B per image), and
+        // a forward call may carry up to 4096 images.  The 64-bit part goes into the scalar base.
+        const int b_first = (nt * SG_BN) / ohw;
         unsigned boff[3 * CB];
 #pragma unroll
         for (int q = 0; q < 3 * CB; ++q) {
@@ -146,9 +150,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WPE) void conv_gemm_split_k
             n = n < d.N ? n : d.N - 1;                   // tail columns re-read the last valid one
             const int b = n / ohw, r = n - b * ohw;
             const int oh = r / d.OW, ow = r - oh * d.OW;
-            boff[q] = (unsigned)(((b * d.Hp + oh) * d.Wp + ow) * d.Ctot) * 6u + (unsigned)part * 16u;
+            boff[q] = (unsigned)((((b - b_first) * d.Hp + oh) * d.Wp + ow) * d.Ctot) * 6u + (unsigned)part * 16u;
         }
-        const unsigned char* bgrp = reinterpret_cast<const unsigned char*>(act) + (size_t)g * d.Cg * 6;
+        const unsigned char* bgrp = reinterpret_cast<const unsigned char*>(act) + (size_t)g * d.Cg * 6 +
+                                    (size_t)b_first * d.Hp * d.Wp * d.Ctot * 6;
         // ---- A fragments: contiguous 1 KB pieces of the packed weights ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB) * 3 * 1024;

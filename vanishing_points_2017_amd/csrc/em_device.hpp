@@ -1345,6 +1345,14 @@ VPK_DEVFN void smooth_full(EmCtx& c, int m0) {
     if (tid() == 0) sh.dbuf[10] += lap(tq_);
 }
 
+// lsim carries 8 rows more than the image has lines; the rows N .. 8 ceil(N / 8) - 1 are zero (smooth_rows walks them
+// with zero operands where a slice is short or empty).  Once per image, after the matrix is in place.
+VPK_DEVFN void zero_tail_rows(EmCtx& c) {
+    const int N = c.N, jend = 8 * rs_jchunk(N);
+    for (int p = tid(); p < (jend - N) * c.ld; p += nthreads()) c.lsim[(size_t)N * c.ld + p] = 0.0;
+    block_sync();
+}
+
 // Row-sliced smoother: the same eight row slices and the same summation order as smooth_full, but no partial sum ever
 // leaves the wave.  A wave owns 16 columns; its four rows of 16 lanes own the slices d and d + 4 (d = lane / 16), so the
 // eight partials of a (column, VP) live in the four lanes {column, 16 + column, ...} of ONE wave and are summed through a
@@ -1378,75 +1386,95 @@ VPK_DEVFN void smooth_rows(EmCtx& c) {
     double* red = wt + rs_panel_doubles(jch, W) + wave_id() * RS_RED_DOUBLES;
     const int d = lane() >> 4, i = lane() & 15;
     const int jA0 = d * jch, jB0 = (d + 4) * jch;
-    int nA = N - jA0, nB = N - jB0;                 // rows of this lane's two slices
-    nA = nA < 0 ? 0 : (nA > jch ? jch : nA);
-    nB = nB < 0 ? 0 : (nB > jch ? jch : nB);
     const double* oA = wt + (size_t)d * S + i;      // operand i of row r of the slice: oA[r * W] (and oA[r * W + 16])
     const double* oB = wt + (size_t)(d + 4) * S + i;
     const size_t ld = (size_t)uniform_int(c.ld), ldn = (size_t)uniform_int(c.ldn);
     cgdp lsim = c.lsim, lweight = c.lweight, den = c.den;   // (locals: the compiler barriers below would make it re-read c)
     gdp wout = c.w;
-    // Every lane walks jch rows of both of its slices, also where a slice is short or empty (the last ones): there the
-    // row index is clamped to a real row and the operand row of the panel is ZERO (estep / the staging pass above clear
-    // the rows of the "lines" N .. 8 jch - 1), and fma(0, finite, acc) returns acc bit for bit (acc is never -0: it
-    // starts at +0 and a zero product is absorbed).  So the loop has no divergent branch, every load is unconditional,
-    // and the compiler can count its waits.
-    const int nfull = jch / UNR, rem = jch - nfull * UNR;
-    const int lastA = nA > 0 ? jA0 + nA - 1 : N - 1, lastB = nB > 0 ? jB0 + nB - 1 : N - 1;
+    // Every lane walks jch rows of both of its slices, also where a slice is short or empty (the last ones): the rows
+    // N .. 8 jch - 1 exist in lsim as zeros (zero_tail_rows) and the operand rows of those "lines" are zero in the panel
+    // (estep / the staging pass above), and fma(0, 0, acc) returns acc bit for bit (acc is never -0: it starts at +0
+    // and a zero product is absorbed).  So the loop has no divergent branch, every load is unconditional with the
+    // address (scalar row base) + (per-lane constant), and the compiler can count its waits.  The loads run one batch
+    // of UNR rows ahead of the FMAs ACROSS column blocks: the last batch of a block requests the first rows of the
+    // wave's next block, so only the first block of a call starts cold.
+    const int nb = (jch + UNR - 1) / UNR;           // batches per column block; the last has jch - (nb - 1) UNR rows
+    cgdp lbase = uniform_ptr(lsim);
+    const unsigned rowbytes = (unsigned)ld * 8u;
     const int kstep = uniform_int(nwaves()) * 16;
-    for (int k0 = uniform_int(wave_id()) * 16; k0 < N; k0 += kstep) {
-        const int k = k0 + i;
-        const int kc = k < N ? k : N - 1;           // lanes past the last column stay active: they are operand sources
-        cgdp pcol = lsim + kc;
-        const double lwk = lweight[kc];             // requested now, consumed after the row loop
-        double dn = den[kc];
-        double accA[W], accB[W];
-#pragma unroll
-        for (int t = 0; t < W; ++t) { accA[t] = 0.0; accB[t] = 0.0; }
+    int k0 = uniform_int(wave_id()) * 16;
+    if (k0 < N) {
+        int k = k0 + i;
+        int kc = k < N ? k : N - 1;                 // lanes past the last column stay active: they are operand sources
+        unsigned offA = ((unsigned)jA0 * (unsigned)ld + (unsigned)kc) * 8u, offB = ((unsigned)jB0 * (unsigned)ld + (unsigned)kc) * 8u;
         double aA[UNR], aB[UNR], nA_[UNR], nB_[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int rn = u < jch ? u : jch - 1;
-            const int gA = jA0 + rn < lastA ? jA0 + rn : lastA, gB = jB0 + rn < lastB ? jB0 + rn : lastB;
-            aA[u] = pcol[(size_t)gA * ld];
-            aB[u] = pcol[(size_t)gB * ld];
+            cgdp rowp = (cgdp)((const VPK_GLOBAL char*)lbase + (size_t)rn * rowbytes);
+            aA[u] = load_at(rowp, offA);
+            aB[u] = load_at(rowp, offB);
         }
-        double cA0 = oA[0], cA1 = W >= 24 ? oA[16] : 0.0, cB0 = oB[0], cB1 = W >= 24 ? oB[16] : 0.0;   // operands of row 0
-        for (int b = 0; b <= nfull; ++b) {
-            const int r = b * UNR;
-            const int nrow = b < nfull ? UNR : rem;  // rows of this batch (the last one is the remainder, maybe empty)
+        for (;;) {
+            const double lwk = lweight[kc];         // requested now, consumed after the row loop
+            double dn = den[kc];
+            const int k0n = k0 + kstep;
+            const bool has_next = k0n < N;
+            const int kn = k0n + i;
+            const int kcn = has_next ? (kn < N ? kn : N - 1) : kc;
+            const unsigned offAn = ((unsigned)jA0 * (unsigned)ld + (unsigned)kcn) * 8u, offBn = ((unsigned)jB0 * (unsigned)ld + (unsigned)kcn) * 8u;
+            double accA[W], accB[W];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {         // the next batch's loads go out before this batch's FMAs
-                int rn = r + UNR + u;
-                rn = rn < jch ? rn : jch - 1;
-                const int gA = jA0 + rn < lastA ? jA0 + rn : lastA, gB = jB0 + rn < lastB ? jB0 + rn : lastB;
-                nA_[u] = pcol[(size_t)gA * ld];
-                nB_[u] = pcol[(size_t)gB * ld];
-            }
+            for (int t = 0; t < W; ++t) { accA[t] = 0.0; accB[t] = 0.0; }
+            double cA0 = oA[0], cA1 = W >= 24 ? oA[16] : 0.0, cB0 = oB[0], cB1 = W >= 24 ? oB[16] : 0.0;   // operands of row 0
+            // one batch: request the rows of the following batch into (nxA, nxB), then the FMAs of this batch's rows
+            // out of (cuA, cuB).  The two register sets swap roles from batch to batch (no copies: a copy would wait
+            // for the loads it moves).
+            auto batch = [&](int b, double (&cuA)[UNR], double (&cuB)[UNR], double (&nxA)[UNR], double (&nxB)[UNR])
+                             __attribute__((always_inline)) {
+                const int r = b * UNR;
+                const bool lastb = b + 1 == nb;
+                const int nrow = lastb ? jch - r : UNR;
+                const int rnext = lastb ? 0 : r + UNR;          // first row of the batch requested now
+                const unsigned oa = lastb ? offAn : offA, ob = lastb ? offBn : offB;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (u < nrow) {                     // wave-uniform
-                    int rq = r + u + 1;             // the next row's operands are requested before this row's FMAs
-                    rq = rq < jch ? rq : jch - 1;
-                    const double* qA = oA + (size_t)rq * W;
-                    const double* qB = oB + (size_t)rq * W;
-                    const double xA0 = qA[0], xA1 = W >= 24 ? qA[16] : 0.0, xB0 = qB[0], xB1 = W >= 24 ? qB[16] : 0.0;
-                    fmac8_row_bcast<0>(accA, cA0, aA[u]);
-                    if (W >= 16) fmac8_row_bcast<8>(accA + (W >= 16 ? 8 : 0), cA0, aA[u]);
-                    if (W >= 24) fmac8_row_bcast<0>(accA + (W >= 24 ? 16 : 0), cA1, aA[u]);
-                    if (W >= 32) fmac8_row_bcast<8>(accA + (W >= 32 ? 24 : 0), cA1, aA[u]);
-                    fmac8_row_bcast<0>(accB, cB0, aB[u]);
-                    if (W >= 16) fmac8_row_bcast<8>(accB + (W >= 16 ? 8 : 0), cB0, aB[u]);
-                    if (W >= 24) fmac8_row_bcast<0>(accB + (W >= 24 ? 16 : 0), cB1, aB[u]);
-                    if (W >= 32) fmac8_row_bcast<8>(accB + (W >= 32 ? 24 : 0), cB1, aB[u]);
-                    cA0 = xA0; cA1 = xA1; cB0 = xB0; cB1 = xB1;
+                for (int u = 0; u < UNR; ++u) {
+                    int rn = rnext + u;
+                    rn = rn < jch ? rn : jch - 1;
+                    cgdp rowp = (cgdp)((const VPK_GLOBAL char*)lbase + (size_t)rn * rowbytes);
+                    nxA[u] = load_at(rowp, oa);
+                    nxB[u] = load_at(rowp, ob);
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) { aA[u] = nA_[u]; aB[u] = nB_[u]; }
-        }
+                for (int u = 0; u < UNR; ++u) {
+                    if (u < nrow) {                 // wave-uniform
+                        int rq = r + u + 1;         // the next row's operands are requested before this row's FMAs
+                        rq = rq < jch ? rq : 0;     // (after the block's last row: row 0 again, for the next block)
+                        const double* qA = oA + (size_t)rq * W;
+                        const double* qB = oB + (size_t)rq * W;
+                        const double xA0 = qA[0], xA1 = W >= 24 ? qA[16] : 0.0, xB0 = qB[0], xB1 = W >= 24 ? qB[16] : 0.0;
+                        fmac8_row_bcast<0>(accA, cA0, cuA[u]);
+                        if (W >= 16) fmac8_row_bcast<8>(accA + (W >= 16 ? 8 : 0), cA0, cuA[u]);
+                        if (W >= 24) fmac8_row_bcast<0>(accA + (W >= 24 ? 16 : 0), cA1, cuA[u]);
+                        if (W >= 32) fmac8_row_bcast<8>(accA + (W >= 32 ? 24 : 0), cA1, cuA[u]);
+                        fmac8_row_bcast<0>(accB, cB0, cuB[u]);
+                        if (W >= 16) fmac8_row_bcast<8>(accB + (W >= 16 ? 8 : 0), cB0, cuB[u]);
+                        if (W >= 24) fmac8_row_bcast<0>(accB + (W >= 24 ? 16 : 0), cB1, cuB[u]);
+                        if (W >= 32) fmac8_row_bcast<8>(accB + (W >= 32 ? 24 : 0), cB1, cuB[u]);
+                        cA0 = xA0; cA1 = xA1; cB0 = xB0; cB1 = xB1;
+                    }
+                }
+            };
+            int b = 0;
+            for (; b + 1 < nb; b += 2) {
+                batch(b, aA, aB, nA_, nB_);
+                batch(b + 1, nA_, nB_, aA, aB);
+            }
+            const bool odd = b < nb;
+            if (odd) batch(b, aA, aB, nA_, nB_);    // the next block's first rows are in (nA_, nB_): moved after the rounds
         // the eight partials of every (VP, column) of this wave, summed in slice order: RS_TT VPs per round through the
         // wave's scratch [vp][column][slice]; lane (d, i) writes its slices d and d + 4 and finishes VP t0 + d of column i
+        if (tid() == 0) sh.dbuf[9] += lap(tq_);     // row loops (wave 0)
         const double blw = bias * lwk;
         asm volatile("" : "+v"(dn));                // dn has arrived before the rounds: no wait inside them (a wait there
                                                     //   would also wait for the previous round's store)
@@ -1470,9 +1498,17 @@ VPK_DEVFN void smooth_rows(EmCtx& c) {
                 wave_lds_order();
             }
         }
+        if (tid() == 0) sh.dbuf[10] += lap(tq_);    // reduction rounds (wave 0)
+            if (!has_next) break;
+            if (odd) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { aA[u] = nA_[u]; aB[u] = nB_[u]; }
+            }
+            k0 = k0n; k = kn; kc = kcn; offA = offAn; offB = offBn;
+        }
     }
     block_sync();
-    if (tid() == 0) sh.dbuf[9] += lap(tq_);
+    if (tid() == 0) sh.dbuf[10] += lap(tq_);        // + waiting for the other waves
 }
 
 VPK_DEVFN void smooth_dispatch(EmCtx& c);
@@ -2016,19 +2052,32 @@ VPK_DEVFN void split_vp(EmCtx& c) {
     // direction vectors and norms are staged in LDS once (not two dependent global loads per pair), and for 2 phi <
     // pi/2 the value is 1 - (2 c^2 - 1) = 2 (1 - c)(1 + c) without acos / cos (as cos9_of_cos does for the similarity:
     // within 2e-16 of the library chain); the clipped branch is numpy's 1 - cos(pi/2) = 1 - 6.123e-17.
-    double* dirs = in_lds ? DL + cluster_lds_doubles(nw) : DL;   // [nw][vx, vy, norm]: behind the LDS matrix, or alone
+    // Staged [nw][vx, vy, norm]: behind the LDS matrix, alone in LDS, or -- a set of more lines than a third of the LDS
+    // panel has doubles (3 nw > wt_doubles: thousands of lines on one VP) -- in the slot's p_vl rows in HBM (mcap x ldn >=
+    // 8 N doubles; the E-step that follows every split rewrites them before anything reads them).  Same values, same
+    // expressions, wherever they are staged.
+    const bool dirs_lds = in_lds || 3 * (long long)nw <= c.wt_doubles;
+    double* dirs = in_lds ? DL + cluster_lds_doubles(nw) : DL;
+    gdp dirs_g = c.pvl;
     for (int a = tid(); a < nw; a += nthreads()) {
         cgdp q = c.lp + 4 * (size_t)c.idx[a];
         const double vx = q[0] - q[2], vy = q[1] - q[3];      // lines_points_cosangle :716-719
-        dirs[3 * a] = vx; dirs[3 * a + 1] = vy; dirs[3 * a + 2] = norm2(vx, vy);
+        const double nv = norm2(vx, vy);
+        if (dirs_lds) { dirs[3 * a] = vx; dirs[3 * a + 1] = vy; dirs[3 * a + 2] = nv; }
+        else { dirs_g[3 * (size_t)a] = vx; dirs_g[3 * (size_t)a + 1] = vy; dirs_g[3 * (size_t)a + 2] = nv; }
     }
     block_sync();
-    for (int p = tid(); p < nw * nw; p += nthreads()) {
-        int a = p / nw, b = p % nw;
+    for (long long p = tid(); p < (long long)nw * nw; p += nthreads()) {
+        const int a = (int)(p / nw), b = (int)(p - (long long)a * nw);
         double v = 0.0;
         if (a != b) {
-            const double cc = clip(fabs(dot2(dirs[3 * a], dirs[3 * a + 1], dirs[3 * b], dirs[3 * b + 1]) /
-                                        (dirs[3 * a + 2] * dirs[3 * b + 2])), -1.0, 1.0);
+            double ax, ay, an, bx, by, bn;
+            if (dirs_lds) { ax = dirs[3 * a]; ay = dirs[3 * a + 1]; an = dirs[3 * a + 2]; bx = dirs[3 * b]; by = dirs[3 * b + 1]; bn = dirs[3 * b + 2]; }
+            else {
+                ax = dirs_g[3 * (size_t)a]; ay = dirs_g[3 * (size_t)a + 1]; an = dirs_g[3 * (size_t)a + 2];
+                bx = dirs_g[3 * (size_t)b]; by = dirs_g[3 * (size_t)b + 1]; bn = dirs_g[3 * (size_t)b + 2];
+            }
+            const double cc = clip(fabs(dot2(ax, ay, bx, by) / (an * bn)), -1.0, 1.0);
             const double COS_PI_4 = 0.70710678118654757;      // cos(pi/4): 2 phi >= pi/2 below it
             if (cc != cc) v = cc;
             else if (!(cc > COS_PI_4)) v = 1 - 6.123233995736766e-17;
@@ -2254,7 +2303,7 @@ VPK_DEVFN int em_run(EmCtx& c, EmOut& o, EmSlice& sl) {
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;
     if (c.N <= 0) { write_result(c, o, VPK_EM_NO_VP, 0); return EM_DONE; }
 
-    if (P.use_weights) pairwise_setup(c, true);               // :177-178 (+ :230 kNN score)
+    if (P.use_weights) { pairwise_setup(c, true); zero_tail_rows(c); }   // :177-178 (+ :230 kNN score)
     else pairwise_setup(c, false);                            // only lines_angles is needed
     trace_put(o, P.num_iter, 0, lap(tk));                     // last trace row: setup timings
     normalise_lines(c);                                       // :185-186, :226 (the caller's array, in place)

@@ -51,7 +51,7 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.nwaves = nwaves;
     size_t o = 0;
     const size_t n = (size_t)L.ldn;
-    L.lsim = o;    o += use_weights ? n * n : 8;
+    L.lsim = o;    o += use_weights ? (n + 8) * n : 8;   // + 8 zero rows: the row-sliced smoother walks 8 ceil(N / 8) rows
     L.pdist = o;   o += use_weights ? n * n : 8;       // pair distances (setup only: the kNN rating reads rows of it)
     L.den = o;     o += n;
     L.lweight = o; o += n;

@@ -1,6 +1,7 @@
 // vpk_core.hip -- handle lifetime, stream plumbing, error reporting for libvpk.so
 #include "vpk_internal.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 int vpk_fail(vpk_handle* h, int code, const char* what) {
@@ -61,6 +62,8 @@ int vpk_create(int device, vpk_handle** out) {
         return VPK_ERR_HIP;
     }
     h->own_stream = true;
+    if (const char* e = getenv("VPK_EM_WAIT_CAP")) { const int v = atoi(e); if (v >= 1 && v <= h->em_wait_cap) h->em_wait_cap = v; }
+    if (const char* e = getenv("VPK_EM_STARTED_CAP")) { const int v = atoi(e); if (v >= 1 && v <= h->em_started_cap) h->em_started_cap = v; }
     *out = h;
     return VPK_OK;
 }

@@ -93,16 +93,23 @@ struct EmSliceArgs {
     int nslots;
 };
 
-// take a free slot (session mode: slots outlive the launch, so they are not tied to the workgroup)
+// take a free slot (session mode: slots outlive the launch, so they are not tied to the workgroup).  The invariant
+// below (EmSliceArgs) guarantees a free slot; should it ever be broken the search gives up after a bounded number of
+// sweeps (slots are released by images that FINISH, so a short sleep between sweeps is all that helps) and returns -1:
+// the image is reported with VPK_EM_NO_SLOT instead of hanging the GPU.
+constexpr int EM_SLOT_SWEEPS = 1 << 16;
 VPK_DEV int acquire_slot(const EmSliceArgs& ss) {
     Shared& sh = SH();
     if (tid() == 0) {
         int got = -1;
-        for (int start = (block_id() * 2) % ss.nslots; got < 0;)
+        const int start = (block_id() * 2) % ss.nslots;
+        for (int sweep = 0; sweep < EM_SLOT_SWEEPS && got < 0; ++sweep) {
             for (int k = 0; k < ss.nslots && got < 0; ++k) {
                 const int s = (start + k) % ss.nslots;
                 if (atomicCAS(&ss.busy[s], 0, 1) == 0) got = s;
             }
+            if (got < 0) __builtin_amdgcn_s_sleep(127);
+        }
         sh.ibuf[7] = got;
     }
     block_sync();
@@ -202,20 +209,24 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
             }
         }
         // An image that has not been started when the deadline has passed is parked as it is -- unless its
-        // list is full: then it runs now (a longer launch, never a lost image).
+        // list is full: then it runs now, TO COMPLETION (a longer launch, never a lost image; with the launch's
+        // deadline it would take a slot, suspend at its first checkpoint and the workgroup would start the next one:
+        // more suspended images than workgroups, which is what the slot count rules out).
         bool park_unstarted = false;
+        bool list_full = false;
         if (ss.enabled && slot < 0 && deadline != EM_NO_DEADLINE) {
             if (tid() == 0) {
                 int e = -1;
                 if (clock_ticks() >= deadline) {
                     e = atomicAdd(&ss.ctr[5], 1);
-                    if (e >= ss.cap_waiting) e = -1;
+                    if (e >= ss.cap_waiting) e = -2;
                 }
                 sh.ibuf[7] = e;
             }
             block_sync();
             const int e = sh.ibuf[7];
             block_sync();
+            list_full = e == -2;
             if (e >= 0) {
                 if (tid() == 0) {
                     EmCarry& k = ss.out_waiting[e];
@@ -225,18 +236,36 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
             }
         }
         if (park_unstarted) continue;
+        if (list_full) sl.deadline = EM_NO_DEADLINE;
         if (slot < 0) {
             slot = ss.enabled ? acquire_slot(ss) : block_id();
+            if (slot < 0) {                    // bounded wait expired (see acquire_slot): report, do not hang
+                if (tid() == 0) { *o.status = VPK_EM_NO_SLOT; *o.num_vp = 0; *o.iterations = 0; *o.flags = 0; }
+                block_sync();
+                continue;
+            }
             bind_scratch(c, a.scratch + (size_t)slot * a.L.total_doubles, a.L, c.prm.do_split != 0);
         }
-        const int result = em_run(c, o, sl);
-        if (result == EM_SUSPENDED) {          // only with a deadline; at most one per workgroup and launch (see above)
+        int result = em_run(c, o, sl);
+        while (result == EM_SUSPENDED) {       // only with a deadline; at most one per workgroup and launch (see above)
             if (tid() == 0) {
-                const int e = atomicAdd(&ss.ctr[2], 1);
-                EmCarry& k = ss.out_started[e];
-                k.c = c; k.o = o; k.iter = sl.start_iter; k.slot = slot;
+                int e = atomicAdd(&ss.ctr[2], 1);
+                if (e < ss.cap_started) {
+                    EmCarry& k = ss.out_started[e];
+                    k.c = c; k.o = o; k.iter = sl.start_iter; k.slot = slot;
+                } else {
+                    e = -1;                    // the list is full: this image is resumed right here and runs on
+                }
+                sh.ibuf[7] = e;
             }
             block_sync();
+            const bool parked = sh.ibuf[7] >= 0;
+            block_sync();
+            if (parked) break;
+            sl.deadline = EM_NO_DEADLINE;
+            result = em_run(c, o, sl);         // resumes from the state it has just saved in its slot
+        }
+        if (result == EM_SUSPENDED) {
         } else if (ss.enabled) {
             block_sync();
             if (tid() == 0) { __threadfence(); atomicExch(&ss.busy[slot], 0); }
@@ -245,8 +274,8 @@ __global__ __launch_bounds__(EM_BOUND) void em_batch_kernel(EmBatchArgs a, EmSli
 }
 
 // between two time-sliced launches: what the last launch parked becomes the next launch's input list
-__global__ void em_rotate_kernel(int* ctr, int cap_waiting) {
-    ctr[1] = ctr[2];
+__global__ void em_rotate_kernel(int* ctr, int cap_waiting, int cap_started) {
+    ctr[1] = ctr[2] < cap_started ? ctr[2] : cap_started;   // (the counters keep counting when a list is full)
     ctr[0] = 0;
     ctr[2] = 0;
     ctr[4] = ctr[5] < cap_waiting ? ctr[5] : cap_waiting;   // the counter keeps counting when the list is full
@@ -341,6 +370,7 @@ __global__ __launch_bounds__(EM_BOUND) void weight_matrix_kernel(int n, int m, c
         c.den[k] = 1 + bias * c.lweight[k] * sum;
     }
     block_sync();
+    zero_tail_rows(c);
     smooth(c);
     for (int p = tid(); p < m * n; p += nthreads()) w_out[p] = c.w[(size_t)(p / n) * c.ldn + p % n];
 }
@@ -447,8 +477,11 @@ int em_prepare(vpk_handle* h) {
 // One workgroup per CU (see EM_BOUND), with the whole remaining LDS (128 KiB) as the smoother's operand
 // panel: single-pass smoothing for every image whose N x W panel fits.
 struct EmMode { int per_cu; int wt_doubles; size_t lds_bytes; };
-EmMode em_mode(const vpk_handle*, int, int, int) {
-    return EmMode{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
+EmMode em_mode(const vpk_handle* h) {
+    if (h->em_lds_doubles <= 0) return EmMode{1, WT_DOUBLES_BIG, EM_LDS_BYTES_BIG};
+    // vpk_em_set_lds_panel: the budget the phases PLAN with; the launch still gets at least the setup phases' scratch
+    const int wt = std::min(std::max(h->em_lds_doubles, 64), WT_DOUBLES_BIG);
+    return EmMode{1, wt, SH_BYTES + (size_t)std::max(wt, PART_DOUBLES) * sizeof(double)};
 }
 
 int em_slots(const vpk_handle* h, int batch, size_t slot_bytes, int per_cu) {
@@ -469,8 +502,8 @@ int check_params(vpk_handle* h, const vpk_em_params* p, int n_init, bool has_ini
     return VPK_OK;
 }
 
-constexpr int EM_WAIT_CAP = 8192;       // images parked before they were started (a full list makes further ones run on)
-constexpr int EM_STARTED_CAP = 1024;    // suspended images: at most one per workgroup (vpk_em_set_workgroups <= CUs)
+// list capacities: vpk_handle::em_wait_cap (images parked before they were started; a full list makes further ones
+// run on) and ::em_started_cap (suspended images: at most one per workgroup, vpk_em_set_workgroups <= CUs)
 constexpr size_t EM_SESS_HEAD = 256;    // counters
 
 struct SessView { int* ctr; int* busy; EmCarry* started[2]; EmCarry* waiting[2]; };
@@ -480,19 +513,19 @@ SessView sess_view(vpk_handle* h) {
     v.ctr = (int*)base;
     v.busy = (int*)(base + EM_SESS_HEAD);
     char* p = base + EM_SESS_HEAD + em_align((size_t)h->em_sess_slots * 4, 256);
-    const size_t sb = em_align(sizeof(EmCarry) * EM_STARTED_CAP, 256), wb = em_align(sizeof(EmCarry) * EM_WAIT_CAP, 256);
+    const size_t sb = em_align(sizeof(EmCarry) * h->em_started_cap, 256), wb = em_align(sizeof(EmCarry) * h->em_wait_cap, 256);
     v.started[0] = (EmCarry*)p; v.started[1] = (EmCarry*)(p + sb);
     v.waiting[0] = (EmCarry*)(p + 2 * sb); v.waiting[1] = (EmCarry*)(p + 2 * sb + wb);
     return v;
 }
-size_t sess_bytes(int slots) {
-    return EM_SESS_HEAD + em_align((size_t)slots * 4, 256) + 2 * em_align(sizeof(EmCarry) * EM_STARTED_CAP, 256) +
-           2 * em_align(sizeof(EmCarry) * EM_WAIT_CAP, 256);
+size_t sess_bytes(const vpk_handle* h, int slots) {
+    return EM_SESS_HEAD + em_align((size_t)slots * 4, 256) + 2 * em_align(sizeof(EmCarry) * h->em_started_cap, 256) +
+           2 * em_align(sizeof(EmCarry) * h->em_wait_cap, 256);
 }
 // the previous launch's output lists become this launch's input lists
 EmSliceArgs sess_next(vpk_handle* h, double slice_ms) {
     SessView v = sess_view(h);
-    hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr, EM_WAIT_CAP);
+    hipLaunchKernelGGL(em_rotate_kernel, dim3(1), dim3(1), 0, h->stream, v.ctr, h->em_wait_cap, h->em_started_cap);
     h->em_sess_in ^= 1;
     EmSliceArgs ss;
     ss.enabled = 1;
@@ -501,7 +534,7 @@ EmSliceArgs sess_next(vpk_handle* h, double slice_ms) {
     ss.ctr = v.ctr;
     ss.in_started = v.started[h->em_sess_in]; ss.out_started = v.started[h->em_sess_in ^ 1];
     ss.in_waiting = v.waiting[h->em_sess_in]; ss.out_waiting = v.waiting[h->em_sess_in ^ 1];
-    ss.cap_started = EM_STARTED_CAP; ss.cap_waiting = EM_WAIT_CAP;
+    ss.cap_started = h->em_started_cap; ss.cap_waiting = h->em_wait_cap;
     ss.busy = v.busy; ss.nslots = h->em_sess_slots;
     return ss;
 }
@@ -537,6 +570,13 @@ int vpk_em_set_smoother(vpk_handle* h, int mode) {
     return VPK_OK;
 }
 
+int vpk_em_set_lds_panel(vpk_handle* h, int doubles) {
+    if (!h || doubles < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_lds_panel: bad argument");
+    if (h->em_unflushed) return vpk_fail(h, VPK_ERR_STATE, "vpk_em_set_lds_panel: images are parked: vpk_em_flush first");
+    h->em_lds_doubles = doubles;
+    return VPK_OK;
+}
+
 int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups) {
     if (!h || max_workgroups < 0) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_workgroups: bad argument");
     h->em_max_workgroups = max_workgroups;
@@ -548,7 +588,7 @@ size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const v
     int mcap = em_mcap(p->num_init_vp, n_init, n_init > 0, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
     EmLayout L = em_layout(n_max, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
     size_t slot = L.total_doubles * sizeof(double);
-    return (size_t)em_slots(h, batch, slot, em_mode(h, batch, n_max, mcap).per_cu) * slot;
+    return (size_t)em_slots(h, batch, slot, em_mode(h).per_cu) * slot;
 }
 
 int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, const double* lp,
@@ -580,7 +620,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
     int mcap = em_mcap(p->num_init_vp, n_init, has_init, p->do_split != 0, p->num_iter, p->split_merge_freq, MAXM);
     EmLayout L = em_layout((int)nmax, mcap, EM_WAVES, p->use_weights != 0, p->do_split != 0);
     const size_t slot_bytes = L.total_doubles * sizeof(double);
-    const EmMode mode = em_mode(h, batch, (int)nmax, mcap);
+    const EmMode mode = em_mode(h);
     int slots = em_slots(h, batch, slot_bytes, mode.per_cu);
     int wgs = slots;
     if (sliced) {
@@ -588,7 +628,6 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
         // follow the batch; slots outlive the launch: running (<= wgs) + parked and not yet resumed (<= wgs)
         wgs = h->cu_share * mode.per_cu;
         if (h->em_max_workgroups > 0 && wgs > h->em_max_workgroups) wgs = h->em_max_workgroups;
-        if (wgs > EM_STARTED_CAP) wgs = EM_STARTED_CAP;
         slots = 2 * wgs + 8;
         if ((size_t)slots * slot_bytes > h->total_mem / 2)
             return vpk_fail(h, VPK_ERR_LIMIT, "vpk_em_batch: time-sliced slots exceed half of the device memory");
@@ -598,7 +637,7 @@ int vpk_em_batch(vpk_handle* h, int batch, const int64_t* offsets, double* l, co
             if (h->em_unflushed)
                 return vpk_fail(h, VPK_ERR_STATE, "vpk_em_batch: the slot layout changed (more lines than "
                                 "vpk_em_set_time_slice was told, or other parameters) while images are parked: vpk_em_flush first");
-            const size_t need = sess_bytes(slots);
+            const size_t need = sess_bytes(h, slots);
             rc = vpk_reserve(h, &h->em_sess, &h->em_sess_bytes, need, "hipMalloc(EM session)");
             if (rc) return rc;
             VPK_HIP(h, hipMemsetAsync(h->em_sess, 0, need, h->stream));
@@ -753,8 +792,9 @@ int vpk_weight_matrix(vpk_handle* h, int n, int m, const double* p_vl, const dou
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
     // the batch kernel's LDS budget, so that this entry point takes the same smoother an image of this size takes there
-    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES_BIG, h->stream, n, m, p_vl, lweight, lsim,
-                       bias, L, (double*)h->small_ws, w_out, h->em_smoother, WT_DOUBLES_BIG);
+    const EmMode mode = em_mode(h);
+    hipLaunchKernelGGL(weight_matrix_kernel, dim3(1), dim3(EM_THREADS), mode.lds_bytes, h->stream, n, m, p_vl, lweight, lsim,
+                       bias, L, (double*)h->small_ws, w_out, h->em_smoother, mode.wt_doubles);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }

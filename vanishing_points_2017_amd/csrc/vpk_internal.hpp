@@ -20,6 +20,11 @@ struct vpk_handle {
     int cu_share = 0;            // CUs this handle's launches are sized for (= num_cu)
     int em_max_workgroups = 0;   // vpk_em_set_workgroups (0 = no cap)
     int em_smoother = 0;         // vpk_em_set_smoother
+    int em_lds_doubles = 0;      // vpk_em_set_lds_panel (0 = whole CU)
+    // capacities of the time-sliced launches' parked-image lists (vpk_em.hip); the environment variables
+    // VPK_EM_WAIT_CAP / VPK_EM_STARTED_CAP shrink them at vpk_create so that tests can fill them with a few images
+    int em_wait_cap = 8192;
+    int em_started_cap = 1024;
     int lds_per_block = 0;
     int arch = 0;
     size_t total_mem = 0;

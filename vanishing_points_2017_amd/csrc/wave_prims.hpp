@@ -203,6 +203,15 @@ template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b)
 // a value every lane holds identically, moved to a scalar register: loops and branches on it are scalar (values read through
 // a context pointer arrive in vector registers and would otherwise be treated as divergent)
 VPK_DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+VPK_DEV cgdp uniform_ptr(cgdp p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (cgdp)(((unsigned long long)hi << 32) | lo);
+}
+// one double at (scalar base) + (per-lane byte offset): the saddr form of global_load, no per-load address arithmetic
+VPK_DEV double load_at(cgdp base, unsigned byte_off) {
+    return *reinterpret_cast<cgdp>(reinterpret_cast<const VPK_GLOBAL char*>(base) + byte_off);
+}
 // Order this wave's LDS accesses as written.  The LDS serves one wave's instructions in issue order, so a wave that
 // writes LDS and reads the words back (other lanes' words included: a wave's lanes run in lockstep) needs no wait and
 // no barrier instruction -- only the compiler must keep the order.

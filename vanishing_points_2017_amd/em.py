@@ -113,6 +113,8 @@ def em_batch(scenes, device=0, want_metric=False, want_trace=False, want_distrib
         lo, hi = int(offs[b]), int(offs[b + 1])
         m = int(host["num_vp"][b])
         status = int(host["status"][b])
+        if status == 3:         # VPK_EM_NO_SLOT (include/vpk.h): the image was not refined -- an error, not a result
+            raise _lib.VpkError("vpk_em_batch: image %d found no working-set slot (time-sliced launch)" % b)
         res = {"status": status, "flags": int(host["flags"][b]) & 0xffffffff, "l": l_norm[lo:hi]}
         if status == 0:
             res.update({
