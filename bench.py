@@ -17,6 +17,10 @@ line.  Images shard across ranks (weak scaling: 102 images per rank), no data-pa
 all_gather of the fixed-size result records per step (sharding.device_records / gather_device).
 Rank 0 prints ONE JSON line.
 
+With no --workload given (the driver's invocation) and one GPU, the line also carries "workloads": a short run of the
+HBM-roofline workload (configs[4] stress: 512 images x 1000 lines x 8 VPs x 50 iterations, 3 steps) and one pass over the
+2 018-image HLW-shape set (configs[3]: EM + horizon selection, AUC, parity of the stored subsample with the reference).
+
 What is timed: CNN forward -> EM on inputs resident in HBM.  LSD, the rasteriser and the horizon / AUC
 stage are not in the timed region; the "parity" object compares the EM kernel's results on the same
 scenes with stored results of the reference itself (tests/golden/full_c2.npz), outside the timed region.
@@ -47,7 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="yud", choices=["yud", "stress"])
+    ap.add_argument("--workload", default=None, choices=["yud", "stress"],
+                    help="default: yud, followed (one GPU only) by a short stress run and the HLW-shape pass, reported under 'workloads'")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 'workloads' part of the default run")
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
     ap.add_argument("--em-mode", default="lanes", choices=["lanes", "slice", "serial"],
                     help="slice: one CNN stream + one EM stream whose launches are time-sliced (vpk_em_set_time_slice): a launch "
@@ -74,15 +80,37 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT touching the HIP runtime (a process that has initialised HIP must
+    not start the ranks): KFD's topology nodes with SIMDs, narrowed by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.  None if the
+    topology cannot be read (then the children validate the count themselves)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """--gpus N with no launcher environment: run N ranks as CHILD processes (torch.distributed.run, one per
-    GPU) and return their exit code.  Called before this process has touched the GPU: a process that has
-    initialised HIP must never exec or fork workers."""
+    GPU) and return their exit code.  This parent never touches the GPU: it counts devices from sysfs (visible_gpus),
+    not through torch / HIP, and every child checks its own device."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if have < args.gpus:
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
         return 2
     s = socket.socket()
@@ -209,7 +237,121 @@ def main():
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    extra = args.workload is None and not args.no_extra and world == 1 and args.em_mode == "lanes"
+    if args.workload is None:
+        args.workload = "yud"
+    line = run_workload(args, dist, rank, local_rank, world)
+    if rank == 0 and extra:
+        line["workloads"] = extra_workloads(args, local_rank)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def hlw_pass(local_rank):
+    """BASELINE configs[3] on this GPU: the 2 018 HLW-shape images (100..1000 lines) through ONE vpk_em_batch launch and
+    the batched horizon selection, inputs (lines, response maps, GPU rasters) resident in HBM before the clock starts;
+    then the 64 images the reference's own results are stored for (tests/golden/full_c4.npz; the generator's raster
+    for those) as a second small batch, compared with them.  Returns the "workloads.hlw" object."""
+    from vanishing_points_2017_amd import auc as auc_mod, calc_horizon as ch, em as gem, parity, sphere_mapping, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt = get_runtime(local_rank, "em0")
+    rt.handle.em_set_workgroups(0)
+    t0 = time.time()
+    scenes = list(synth.config_scenes(4, raster=None))
+    rasters = sphere_mapping.raster_batch([s["l"] for s in scenes], size=500, alpha=0.1, device=local_rank)
+    for s, r in zip(scenes, rasters):
+        s["sphere_image"] = r
+    setup_s = time.time() - t0
+    params = gem._params({})
+    d = gem.upload_batch(rt, scenes)
+    rt.synchronize()
+    t1 = time.perf_counter()
+    out = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, params, max_vp=64)
+    rt.synchronize()
+    em_s = time.perf_counter() - t1
+    host = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+    results = []
+    for b in range(len(scenes)):
+        m = int(host["num_vp"][b]) if host["status"][b] == 0 else 0
+        results.append({"vp": host["vp"][b, :m], "counts": host["counts"][b, :m]})
+    t2 = time.perf_counter()
+    horizons = ch.calculate_horizon_batch(results, maxbest=20, theta_vmin=np.pi / 10, device=local_rank)
+    hor_s = time.perf_counter() - t2
+    errs = np.array([ch.horizon_error(h[0], h[1], s["true_horizon"], s["image_shape"]) for s, h in zip(scenes, horizons)])
+    n_lines = np.diff(d["offsets"])
+    iters = host["iterations"]
+    evals = iters + 5
+    b_em = float(np.sum(8.0 * n_lines ** 2 * (evals + 1) + evals * (64.0 * n_lines + 16.0 * np.maximum(host["num_vp"], 1) * n_lines)))
+    res = {"config": "configs[3] HLW-shape: 2018 images, N~U{100..1000} lines, EM + horizon selection on one GPU (the 8-GPU "
+                     "sharded form is benchmark.py --hlw --synthetic --gpus 8)",
+           "images": len(scenes), "images_per_s": len(scenes) / (em_s + hor_s), "em_ms": em_s * 1e3, "horizon_ms": hor_s * 1e3,
+           "em_images_per_s": len(scenes) / em_s, "ok_images": int((host["status"] == 0).sum()),
+           "iterations_mean": float(iters.mean()), "lines_mean": float(n_lines.mean()),
+           "em_roofline": {"bound": "hbm", "achieved": b_em / em_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": b_em / em_s / 1e9 / HBM_PEAK_GBS,
+                           "note": "B_EM (SURVEY 8d) of the 2018 images / the launch's wall time (host clock around a synchronised launch)"},
+           "horizon_auc": float(auc_mod.calc_auc(errs.copy(), cutoff=0.25)[0]),
+           "setup_s_outside_timing": setup_s,
+           "note": "timed: one vpk_em_batch launch over all images + vpk_horizon_batch; not timed: generator, GPU raster, upload"}
+    if os.path.isfile(parity.golden_path(4)):
+        ref = parity.ReferenceResults(4)
+        stored = [next(synth.config_scenes(4, count=1, start=int(i))) for i in ref.index]
+        same = [parity.input_sha(sc) == ref.get(i)["input_sha"] for sc, i in zip(stored, ref.index)]
+        got = gem.em_batch(stored, device=local_rank)
+        comps, e_gpu, e_ref = {}, [], []
+        for sc, i, r, ok in zip(stored, ref.index, got, same):
+            if not ok:
+                continue
+            g = ref.get(i)
+            comps[int(i)] = parity.compare_one(r, g)
+            if r["status"] == 0 and g["status"] == 0:
+                hp = ch.calculate_horizon_and_ortho_vp(r, maxbest=20, theta_vmin=np.pi / 10)
+                e_gpu.append(ch.horizon_error(hp[0], hp[1], sc["true_horizon"], sc["image_shape"]))
+                e_ref.append(ch.horizon_error(g["hP1"], g["hP2"], sc["true_horizon"], sc["image_shape"]))
+        par = parity.summarise(comps)
+        par["inputs_differ"] = int(len(same) - sum(same))
+        if e_gpu:
+            par["horizon_auc"] = float(auc_mod.calc_auc(np.array(e_gpu), cutoff=0.25)[0])
+            par["horizon_auc_reference"] = float(auc_mod.calc_auc(np.array(e_ref), cutoff=0.25)[0])
+        par["source"] = "tests/golden/full_c4.npz: the reference's own EM + calc_horizon on %d of the 2018 scenes" % len(ref)
+        res["parity"] = par
+    return res
+
+
+def extra_workloads(args, local_rank):
+    """The other two BASELINE workloads, after the headline run (one GPU, default invocation only)."""
+    import copy
+    out = {}
+    a = copy.copy(args)
+    a.workload, a.steps, a.warmup, a.images = "stress", 3, 1, 0
+    a.no_alt = a.no_cpu_baseline = True
+    a.em_wgs, a.cnn_precision = -1, 0
+    s = run_workload(a, None, 0, local_rank, 1)
+    out["stress"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "stage_ms",
+                                       "em_stats", "roofline", "roofline_secondary")}
+    out["hlw"] = hlw_pass(local_rank)
+    return out
+
+
+_NETS = {}
+
+
+def get_net(local_rank, rt_cnn):
+    """one weight upload (1.03 GB) per process"""
+    from vanishing_points_2017_amd import cnn
+    key = (local_rank, id(rt_cnn))
+    if key not in _NETS:
+        _NETS[key] = (cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0), device=local_rank, runtime=rt_cnn),
+                      cnn.synthetic_weights(0), cnn.synthetic_mean(0))
+    return _NETS[key]
+
+
+def run_workload(args, dist, rank, local_rank, world):
+    """K timed steps of one workload; returns the JSON line as a dict (rank 0) or None."""
+    import torch
     from vanishing_points_2017_amd import cnn, em as gem, sharding
     from vanishing_points_2017_amd.runtime import get_runtime
     count = args.images or (102 if args.workload == "yud" else 512)
@@ -241,9 +383,7 @@ def main():
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)
     scenes, kw = make_workload(args.workload, rank, count)
-    weights = cnn.synthetic_weights(0)
-    mean = cnn.synthetic_mean(0)
-    net = cnn.Net(weights, mean, device=local_rank, runtime=rt_cnn)
+    net, weights, mean = get_net(local_rank, rt_cnn)
     net.set_profiling(True)
     net.set_fusion(args.cnn_fusion)
     net.set_precision(args.cnn_precision)
@@ -428,20 +568,36 @@ def main():
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
         roof_cnn["traffic_source"] = traffic_src
         pm = (mfma.get("bench_yud_102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)") if args.workload == "yud" else None
-        if pm and args.cnn_precision == 0:      # counter view of the same kernel inside the bench: fraction of SIMD-cycles with a busy matrix pipe, and the
-                    # shader clock it ran at (the 157.3 TF peak assumes 2.4 GHz; under this load the part clocks lower)
-            roof_cnn["pmc"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"], "source": mfma_src}
-            pa = (mfma.get("cnn_alone_B102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)")
-            if pa and count == 102:     # the same kernel without the EM beside it (profiled run of the CNN alone, 12 timed passes)
-                flop3 = sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
-                roof_cnn["alone"] = {"achieved": flop3 / (pa["avg_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s",
-                                     "frac": flop3 / (pa["avg_ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                     "mfma_util": pa["mfma_util"], "shader_clock_ghz": pa["shader_clock_ghz"],
-                                     "note": "average over the conv2 / conv3 / conv5 launches of the kernel, CNN alone"}
-        # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step,
-        # each EM stream one batch every n_lanes steps
-        roof = roof_em if (em_ms / n_lanes >= cnn_ms * 1.5 or args.workload == "stress") else roof_cnn
+        if pm and args.cnn_precision == 0:
+            # Counter view of this kernel from the --pmc pass of the bench command.  A --pmc pass SERIALISES dispatches: the
+            # kernel ran with nothing beside it, so this is the kernel alone at the clock the run's power state gave it --
+            # matrix-pipe busy fraction and shader clock (the 157.3 TF peak assumes 2.4 GHz) -- and says nothing about
+            # co-running with the EM; the live `achieved` above is the co-running figure.
+            roof_cnn["pmc_serialised_pass"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"],
+                                               "source": mfma_src,
+                                               "note": "rocprofv3 --pmc serialises dispatches: kernel alone, not beside the EM"}
+        # the same kernel without the EM beside it: kernel-trace of the CNN alone (scripts/time_cnn.py, 12 timed passes)
+        import csv
+        import glob
+        traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cnn_kernel_stats.csv")))
+        if traces and count == 102 and args.cnn_precision == 0:
+            try:
+                rows = list(csv.DictReader(open(traces[-1])))
+                avg_us = [float(r["AverageUs"]) for r in rows if "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0" in r["Name"]]
+                if avg_us:
+                    flop3 = sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
+                    roof_cnn["alone"] = {"achieved": flop3 / (avg_us[0] * 1e-6) / 1e12, "unit": "TFLOP/s",
+                                         "frac": flop3 / (avg_us[0] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                         "source": os.path.relpath(traces[-1], ROOT),
+                                         "note": "average launch of the kernel (conv2 / conv3 / conv5) in the kernel trace of the CNN alone"}
+            except (OSError, ValueError, KeyError):
+                pass
+        # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step, each EM
+        # stream one batch every n_lanes steps; whichever takes longer per step
+        roof = roof_em if (em_ms / n_lanes >= cnn_ms or args.workload == "stress") else roof_cnn
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["dominant_rule"] = ("EM launch %.2f ms / %d lanes = %.2f ms per step vs CNN stream %.2f ms per step"
+                                 % (em_ms, n_lanes, em_ms / n_lanes, cnn_ms))
         line = {
             "metric": "images/sec (LSD->CNN->EM) + horizon-AUC parity, YUD-shape, 1/2/4/8 GPU" if args.workload == "yud"
                       else "images/sec (CNN->EM), synthetic stress, 1->8 GPU roofline scan",
@@ -486,10 +642,8 @@ def main():
                 line["cpu_baseline"]["reference_note"] = ("the reference's EM itself (Python loops + joblib, 8-core build "
                                                           "container, CNN excluded) on the same 102 scenes; the 'port' is "
                                                           "this repo's vectorised oracle on this host")
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 if __name__ == "__main__":
