@@ -87,15 +87,24 @@ def visible_gpus():
     import glob
     n = 0
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if not nodes:
-        return None
+    if not nodes:       # no KFD topology (no GPU driver, or a sandbox): ask a throw-away child process instead
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               capture_output=True, text=True, timeout=300)
+            return int(r.stdout.strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+            return None
     for f in nodes:
         try:
             props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
         except OSError:
             return None
         if int(props.get("simd_count", "0")) > 0:
-            n += 1
+            # a GPU node; containers restrict GPUs by withholding the render node, so count only what can be opened
+            minor = props.get("drm_render_minor")
+            if minor is None or os.access("/dev/dri/renderD%s" % minor, os.R_OK | os.W_OK):
+                n += 1
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -121,6 +130,7 @@ def spawn_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
     return subprocess.call(cmd, env=env)
 
 
@@ -237,6 +247,8 @@ def main():
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    if world > 1:       # N ranks share one host: divide its cores (torch's intra-op pool, OpenMP / MKL in NumPy)
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     extra = args.workload is None and not args.no_extra and world == 1 and args.em_mode == "lanes"
     if args.workload is None:
         args.workload = "yud"
@@ -604,7 +616,7 @@ def run_workload(args, dist, rank, local_rank, world):
             "metric_note": "BASELINE.json's metric name; the timed region is CNN forward -> EM refinement with inputs resident "
                            "in HBM (no LSD, no rasteriser); horizon-AUC parity is the 'parity' object, outside the timed region",
             "value": value, "unit": "images/s", "n_gpus": world, "ranks_seen": world if dist is None else dist.get_world_size(),
-            "steps": args.steps, "warmup": args.warmup,
+            "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": torch.get_num_threads(),
             "ms_per_step": elapsed / args.steps * 1e3, "host_submit_ms_per_step": submit_s / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,

@@ -144,10 +144,11 @@ def test_bench_modes_produce_a_valid_line(mode):
         assert alt["value"] > 0 and alt["steps"] == 3 and "bf16" in alt["cnn"]
 
 
-def test_sharded_benchmark_two_ranks_on_one_gpu(tmp_path):
-    """benchmark.py --hlw --synthetic with TWO ranks (torch.distributed.run) that share this box's GPU: cost-balanced
-    shards, the real EM on each rank, records gathered (gloo here: RCCL refuses two ranks on one device), AUC on
-    rank 0 -- and the same AUC as the one-process run."""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_sharded_benchmark_ranks_sharing_one_gpu(tmp_path, ranks):
+    """benchmark.py --hlw --synthetic with TWO / EIGHT ranks (torch.distributed.run, as on an 8-GPU node) that share this
+    box's GPU: cost-balanced shards, the real EM on each rank, records gathered (gloo here: RCCL refuses several ranks on
+    one device), AUC on rank 0 -- and the same AUC as the one-process run, a clean exit of every rank."""
     import os
     import re
     import subprocess
@@ -155,26 +156,28 @@ def test_sharded_benchmark_two_ranks_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    args = ["--hlw", "--synthetic", "--count", "48", "--update_datafiles", "--run_em"]
+    args = ["--hlw", "--synthetic", "--count", "48" if ranks == 2 else "72", "--update_datafiles", "--run_em"]
     one = subprocess.run([sys.executable, "-m", "vanishing_points_2017_amd.benchmark", "--result_dir", str(tmp_path / "one")] + args,
                          capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     env2 = dict(env, VPK_DIST_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29641", "-m", "vanishing_points_2017_amd.benchmark",
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29641 + ranks), "-m", "vanishing_points_2017_amd.benchmark",
                           "--result_dir", str(tmp_path / "two")] + args,
                          capture_output=True, text=True, env=env2, timeout=900, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     auc1 = float(re.search(r"AUC:\s+([0-9.eE+-]+)", one.stdout).group(1))
     auc2 = float(re.search(r"AUC:\s+([0-9.eE+-]+)", two.stdout).group(1))
-    assert "2 rank(s)" in two.stdout
+    assert "%d rank(s)" % ranks in two.stdout
     assert auc1 == auc2 and 0.5 < auc1 <= 1.0
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_ranks_sharing_one_gpu(ranks):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, RANK / WORLD_SIZE in the
-    environment), two ranks sharing this box's GPU over gloo: image shards per rank, per-step record gather, barrier +
-    max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = ranks_seen = 2."""
+    environment), two / eight ranks sharing this box's GPU over gloo: image shards per rank, per-step record gather,
+    barrier + max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = ranks_seen = N, no 'workloads' part (that
+    is the one-GPU default run's), host threads divided among the ranks."""
     import json
     import os
     import subprocess
@@ -182,13 +185,15 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["VPK_DIST_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(root, "bench.py"), "--gpus", "2",
-                        "--steps", "3", "--warmup", "1", "--images", "12", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29651 + ranks), os.path.join(root, "bench.py"),
+                        "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--images", "12", "--no-alt"],
                        capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["n_gpus"] == ranks and line["ranks_seen"] == ranks and line["scaling"] == "weak"
     assert line["config"]["images_per_gpu"] == 12 and line["value"] > 0
+    assert "workloads" not in line and "cpu_baseline" not in line
+    assert line["host_threads_per_rank"] * ranks <= (os.cpu_count() or 1) or line["host_threads_per_rank"] == 1
