@@ -218,6 +218,43 @@ int vpk_em_set_distribution_out(vpk_handle* h, const vpk_em_dist_out* d);
 size_t vpk_em_workspace_bytes(const vpk_handle* h, int batch, int n_max, const vpk_em_params* p,
                               int n_init);
 
+/* ---- one pipeline step as one host call ------------------------------------------------------- */
+/* replaces: one batch's worth of run_cnn followed by run_em (evaluation.py:254-329) in a pipeline that overlaps
+ * consecutive batches: the CNN forward on `cnn`'s stream, then -- ordered behind it by an event, without a host wait
+ * -- a copy of the resident lines into l_work, the EM on `em`'s stream with the CNN's response maps as its prior, and
+ * optionally the fixed-size result records a multi-GPU run gathers (layout of vpk_build_records).  Everything is
+ * enqueued from C++: the host spends tens of microseconds per step.  Buffers as for vpk_cnn_forward / vpk_em_batch;
+ * `events`: NULL or four hipEvent_t of the caller (any may be NULL) recorded before / after the CNN on its stream and
+ * before / after the EM on its stream.  `cnn` and `em` may be the same handle (one stream: the stages run in turn).
+ * The buffers of a step must not be reused before its EM has finished: `reuse_event` expresses that on the device. */
+typedef struct vpk_step_args {
+    const uint8_t* sphere;          /* B x sphere_size x sphere_size */
+    int32_t batch, sphere_size;
+    float* cnn_out;                 /* B x 400: response maps (kept: they are the EM's input) */
+    const int64_t* offsets;         /* [host] B + 1 */
+    const double* l_in;             /* sum(N) x 3 resident lines (not modified) */
+    double* l_work;                 /* sum(N) x 3 working copy, normalised in place by the EM */
+    const double* lp;               /* sum(N) x 4 */
+    const double* init_vp;          /* NULL or B x n_init x 3 */
+    int32_t n_init, max_vp;
+    const vpk_em_params* params;
+    double* vp_out; double* sigma_out; double* counts_out; double* counts_w_out;
+    int32_t* num_vp_out; int64_t* assoc_out; int32_t* iterations_out; int32_t* status_out; uint32_t* flags_out;
+    double* records;                /* NULL or B x vpk_record_width() */
+    const int64_t* image_ids;       /* device, B (with records) */
+    void* events;                   /* NULL or hipEvent_t[4] */
+    void* reuse_event;              /* NULL or a hipEvent_t of the caller that guards these buffers: the CNN stream waits
+                                       for it before it overwrites cnn_out, and it is recorded behind this step's EM --
+                                       so a ring of vpk_step_args can be re-enqueued without host synchronisation */
+} vpk_step_args;
+int vpk_pipeline_step(vpk_handle* cnn, vpk_handle* em, const vpk_step_args* a);
+/* Fixed-size result records, one row of vpk_record_width() doubles per image: [image id, status, m, (x, y, z) x 20,
+ * line count x 20, NaN] with the m <= 20 best-supported VPs in descending order of their counts (calc_horizon.py:34-36:
+ * what the horizon selection reads); the records every rank contributes to the final all_gather. */
+int vpk_record_width(void);
+int vpk_build_records(vpk_handle* h, int batch, int max_vp, const int64_t* image_ids, const double* vp,
+                      const double* counts, const int32_t* num_vp, const int32_t* status, double* records);
+
 /* ---- fine-grained entry points (single image; unit parity against the reference functions) ---- */
 /* calc_lsim (vp_localisation.py:87-108) + line_rating_knn (:34-84) in one pass over the pairs:
  * lsim_out n x n (row stride n), lscore_out n (before the clip), langle_out n (lines_angles). */

@@ -197,3 +197,56 @@ def test_bench_ranks_sharing_one_gpu(ranks):
     assert line["config"]["images_per_gpu"] == 12 and line["value"] > 0
     assert "workloads" not in line and "cpu_baseline" not in line
     assert line["host_threads_per_rank"] * ranks <= (os.cpu_count() or 1) or line["host_threads_per_rank"] == 1
+
+
+def test_pipeline_step_equals_separate_calls():
+    """vpk_pipeline_step (CNN -> EM of one batch enqueued by one host call, on two streams) against vpk_cnn_forward
+    followed by vpk_em_batch: the same response maps and the same EM outputs, bit for bit; its records are
+    sharding.pack_records' (the host form) and sharding.device_records' (the torch form); a ring of two buffer sets
+    re-enqueued three times without any host synchronisation in between keeps giving the same bits (the guard event
+    orders the reuse on the device), and the resident input lines are never modified."""
+    import torch
+    from vanishing_points_2017_amd import cnn, em as gem, pipeline, sharding, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rt_cnn, rt_em = get_runtime(0, "pipe_cnn"), get_runtime(0, "pipe_em")
+    scenes = list(synth.config_scenes(2, count=9, start=60))
+    net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0), runtime=rt_cnn)
+    params = gem._params({})
+    d = gem.upload_batch(rt_em, scenes)
+    rt_em.synchronize()
+    l0 = d["l"].clone()
+    # separate calls
+    resp = net.forward_device(d["sphere"])
+    rt_cnn.synchronize()
+    ref = gem.em_batch_device(rt_em, d["offsets"], l0.clone(), d["lp"], resp.reshape(-1, 400), d["sphere"], None, params)
+    rt_em.synchronize()
+    ids = torch.arange(100, 100 + len(scenes), dtype=torch.int64, device=rt_em.tdev)
+    ring = [pipeline.Step(rt_cnn, rt_em, d, params, l_in=l0, records=True, image_ids=ids) for _ in range(2)]
+    for rep in range(3):
+        for st in ring:
+            st.enqueue()
+    rt_cnn.synchronize()
+    rt_em.synchronize()
+    for st in ring:
+        assert torch.equal(st.resp, resp)
+        for k in ("vp_assoc", "iterations", "status", "num_vp", "flags"):
+            assert torch.equal(st.out[k], ref[k]), k
+        m = ref["num_vp"].cpu().numpy()
+        for b in range(len(scenes)):
+            for k in ("vp", "sigma", "counts", "counts_weighted"):
+                assert torch.equal(st.out[k][b, :m[b]], ref[k][b, :m[b]]), (k, b)
+        want = sharding.device_records(torch, ids, ref).cpu().numpy()
+        got = st.records.cpu().numpy()
+        assert np.array_equal(got[:, :-1], want[:, :-1]) and np.isnan(got[:, -1]).all()
+        cnn_ms, em_ms = st.stage_ms()
+        assert cnn_ms > 0 and em_ms > 0
+    assert torch.equal(l0, d["l"])                      # the resident lines are inputs only
+    host = {k: v.cpu().numpy() for k, v in ref.items() if v is not None}
+    res = [{"status": int(host["status"][b]), "vp": host["vp"][b, :host["num_vp"][b]], "counts": host["counts"][b, :host["num_vp"][b]]}
+           for b in range(len(scenes))]
+    packed = sharding.pack_records(ids.cpu().numpy(), res)
+    rec = ring[0].records.cpu().numpy()
+    assert np.array_equal(rec[:, :3], packed[:, :3])
+    for b in range(len(scenes)):                        # same VPs kept; the order among EQUAL counts is each form's own
+        a, c = sharding.unpack_record(rec[b]), sharding.unpack_record(packed[b])
+        assert np.array_equal(np.sort(a["counts"]), np.sort(c["counts"]))

@@ -31,12 +31,26 @@ class EmDistOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("p_v", "angles", "p_l", "p_lv", "p_vl", "lvsq")]
 
 
+class StepArgs(ctypes.Structure):
+    """vpk_step_args (include/vpk.h): the buffers of one vpk_pipeline_step call."""
+    _fields_ = [("sphere", ctypes.c_void_p), ("batch", ctypes.c_int32), ("sphere_size", ctypes.c_int32),
+                ("cnn_out", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("l_in", ctypes.c_void_p),
+                ("l_work", ctypes.c_void_p), ("lp", ctypes.c_void_p), ("init_vp", ctypes.c_void_p),
+                ("n_init", ctypes.c_int32), ("max_vp", ctypes.c_int32), ("params", ctypes.c_void_p),
+                ("vp_out", ctypes.c_void_p), ("sigma_out", ctypes.c_void_p), ("counts_out", ctypes.c_void_p),
+                ("counts_w_out", ctypes.c_void_p), ("num_vp_out", ctypes.c_void_p), ("assoc_out", ctypes.c_void_p),
+                ("iterations_out", ctypes.c_void_p), ("status_out", ctypes.c_void_p), ("flags_out", ctypes.c_void_p),
+                ("records", ctypes.c_void_p), ("image_ids", ctypes.c_void_p), ("events", ctypes.c_void_p),
+                ("reuse_event", ctypes.c_void_p)]
+
+
 EXPORTS = [
     "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_smoother", "vpk_em_set_lds_panel", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_em_set_distribution_out", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_set_precision", "vpk_cnn_last_layer_ms",
     "vpk_sphere_raster", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
     "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_line_counts", "vpk_cluster2", "vpk_horizon_batch", "vpk_lsd_detect",
+    "vpk_pipeline_step", "vpk_build_records", "vpk_record_width",
 ]
 
 _lib = None
@@ -65,6 +79,8 @@ def load():
     lib.vpk_em_set_time_slice.argtypes = [c_void, ctypes.c_double, ctypes.c_int]
     lib.vpk_em_set_distribution_out.argtypes = [c_void, ctypes.c_void_p]
     lib.vpk_em_flush.argtypes = [c_void]
+    lib.vpk_pipeline_step.argtypes = [c_void, c_void, ctypes.POINTER(StepArgs)]
+    lib.vpk_build_records.argtypes = [c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 6
     lib.vpk_horizon_batch.argtypes = [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, ctypes.c_int,
                                       ctypes.c_double, ctypes.c_double, c_void, c_void]
     lib.vpk_get_stream.argtypes = [c_void]

@@ -23,6 +23,7 @@ UNITS = {
     "vpk_cnn.hip": [],
     "vpk_raster.hip": [],
     "vpk_horizon.hip": ["-ffp-contract=off"],
+    "vpk_pipeline.hip": [],
     "vpk_lsd.cpp": ["-ffp-contract=off"],      # host code: the front end's line segment detector
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -76,6 +76,7 @@ int vpk_destroy(vpk_handle* h) {
     if (h->em_ws) (void)hipFree(h->em_ws);
     if (h->em_hdr) (void)hipFree(h->em_hdr);
     if (h->em_sess) (void)hipFree(h->em_sess);
+    if (h->step_event) (void)hipEventDestroy(h->step_event);
     for (int i = 0; i < vpk_handle::VPK_HDR_RING; ++i) {
         if (h->em_hdr_host[i]) (void)hipHostFree(h->em_hdr_host[i]);
         if (h->em_hdr_ev[i]) (void)hipEventDestroy(h->em_hdr_ev[i]);

@@ -63,6 +63,7 @@ struct vpk_handle {
     int em_sess_wt_doubles = 0;
     size_t em_sess_lds = 0;
     vpk::EmLayout em_sess_layout = {};
+    hipEvent_t step_event = nullptr; // vpk_pipeline_step: orders the EM stream behind the CNN stream
     vpk_cnn_state* cnn = nullptr;
 };
 
