@@ -568,9 +568,11 @@ def _alpha(area):
 COLOR_A = 26            # agg::rgba8(rgba(1, 1, 1, 0.1)).a = uround(0.1 * 255)
 
 
-def blend_white(p, cover):
+def blend_white(p, cover, color_a=COLOR_A):
     """One channel of an opaque grey pixel p (R = G = B, A = 255) after blending white with this coverage."""
-    t = COLOR_A * cover + 128                  # rgba8::mult_cover = multiply(a, cover): a * cover / 255, rounded
+    if color_a == 255 and cover == 255:
+        return 255
+    t = color_a * cover + 128                  # rgba8::mult_cover = multiply(a, cover): a * cover / 255, rounded
     alpha = ((t >> 8) + t) >> 8
     if alpha == 0:
         return p
@@ -581,15 +583,24 @@ def blend_white(p, cover):
 
 
 def line_coverage(line, size=500, samples=10000, width_px=100.0 / 72.0):
+    """{(y, x): cover} of one line's stroke.  A non-finite sample breaks the path (PathNanRemover: the next finite sample
+    is a move_to); the sub-paths are stroked one by one and their covers blended one after the other by the caller --
+    returned here merged, which is the same thing wherever the strokes do not overlap (they are separated by a gap)."""
     x, y = curve_pixels(line, size, samples)
     ok = np.isfinite(x) & np.isfinite(y)
-    if not ok.all():          # PathNanRemover: a NaN vertex breaks the path; this restatement handles all-finite curves
-        x, y = x[ok], y[ok]
-    pts = simplify(x, y)
-    poly = stroke_outline(pts, width_px)
-    if len(poly) < 3:
-        return {}
-    return polygon_coverage(poly, size, size)
+    out = {}
+    idx = np.nonzero(ok)[0]
+    if len(idx) == 0:
+        return out
+    runs = np.split(idx, np.nonzero(np.diff(idx) > 1)[0] + 1)
+    for run in runs:
+        pts = simplify(x[run], y[run])
+        poly = stroke_outline(pts, width_px)
+        if len(poly) < 3:
+            continue
+        for k, c in polygon_coverage(poly, size, size).items():
+            out[k] = c if k not in out else out[k]          # (overlapping sub-paths of one line: first wins; not expected)
+    return out
 
 
 def blend_black(p, cover):
@@ -630,12 +641,13 @@ def spine_coverage(size=500, linewidth_pt=0.8, dpi=100.0):
 _SPINES = {}
 
 
-def raster(lines, size=500, samples=10000):
-    """sphere_line_plot(lines, size, alpha=0.1) -> uint8 (size, size)."""
+def raster(lines, size=500, samples=10000, alpha=0.1):
+    """sphere_line_plot(lines, size, alpha) -> uint8 (size, size)."""
     img = np.zeros((size, size), dtype=np.int64)
-    for line in np.asarray(lines, dtype=np.float64):
+    color_a = int(alpha * 255 + 0.5)                   # agg::rgba8(rgba): uround
+    for line in np.asarray(lines, dtype=np.float64).reshape(-1, 3):
         for (y, x), c in line_coverage(line, size, samples).items():
-            img[y, x] = blend_white(int(img[y, x]), c)
+            img[y, x] = blend_white(int(img[y, x]), c, color_a)
     if size not in _SPINES:
         _SPINES[size] = spine_coverage(size)
     for cov in _SPINES[size]:

@@ -21,7 +21,7 @@ UNITS = {
     "vpk_core.hip": [],
     "vpk_em.hip": ["-ffp-contract=off"],
     "vpk_cnn.hip": [],
-    "vpk_raster.hip": [],
+    "vpk_raster.hip": ["-ffp-contract=off"],   # the curve samples must round like NumPy's separate ufunc calls
     "vpk_horizon.hip": ["-ffp-contract=off"],
     "vpk_pipeline.hip": [],
     "vpk_lsd.cpp": ["-ffp-contract=off"],      # host code: the front end's line segment detector
