@@ -19,13 +19,15 @@
 // Decomposition.  One persistent workgroup per image (images come from a queue).  Phase A: one THREAD per line evaluates
 // the 10 000 samples, simplifies them on the fly (the simplifier is a sequential state machine) and strokes the result:
 // a closed outline polygon of ~100-200 vertices in the workgroup's HBM scratch.  Phase B, line by line in input order
-// (the blend is not commutative in 8-bit arithmetic): the polygon's edges are dealt to the threads, every edge adds its
-// cells into the image-sized (cover, area) accumulators in HBM/L2 with integer atomics (sums are order independent: same
-// cells as Agg's sorted list), then one thread per touched row sweeps its cells left to right -- running cover, alpha,
-// blend into the uint8 image -- and clears them.  Two workgroup barriers per line.
+// (the blend is not commutative in 8-bit arithmetic): the polygon's edges are dealt to the threads and walked twice -- first
+// to find every row's cell range, then, after a prefix sum has packed the ranges into a 96 KB LDS pool, to add the
+// cells (cover, area) there with LDS atomics (sums are order independent: same cells as Agg's sorted list) -- and one
+// thread per touched row sweeps its cells left to right: running cover, alpha, blend into the uint8 image.  Four
+// workgroup barriers per line.
 #include "vpk_internal.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -239,33 +241,48 @@ __device__ void stroke_outline(V2* p, int n, double width, Outline& o) {
 // ---------------------------------------------------------------------------------------------------------------
 // rasterizer_cells_aa::line / render_hline: cells of one edge, added with integer atomics
 // ---------------------------------------------------------------------------------------------------------------
+// Where the cells of the line being drawn live.  Default: an LDS pool -- a stroke touches a few thousand pixels, so the
+// polygon's edges are walked twice: pass 1 (BOUNDS) only records every row's first / last cell, a prefix sum over the rows
+// packs the rows' cell ranges into the pool, pass 2 (POOL) adds the cells there with LDS atomics.  A polygon whose ranges
+// do not fit the pool (GLOBAL) uses image-sized accumulators in HBM / L2 with global atomics instead.
+constexpr int POOL = 12288;             // cells (cover, area) of one polygon in LDS: 96 KB
+enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
+
 struct CellSink {
-    int* cover; int* area;              // [size][size + 2], x shifted by one (cells at x = -1 and x = size exist)
-    int* rowmin; int* rowmax;           // LDS, per row
+    int* cover; int* area;              // GLOBAL: [size][size + 2], x shifted by one (cells at x = -1 and x = size exist)
+    int* pcover; int* parea;            // POOLED: LDS pool
+    int* rowmin; int* rowmax; int* rowoff;   // LDS, per row
     int size;
-    __device__ __forceinline__ void add(int ex, int ey, int c, int a) const {
+    template <int MODE> __device__ __forceinline__ void add(int ex, int ey, int c, int a) const {
         if ((c | a) == 0) return;
         if (ey < 0 || ey >= size || ex < -1 || ex > size) return;
-        const size_t idx = (size_t)ey * (size + 2) + ex + 1;
-        if (c) atomicAdd(cover + idx, c);
-        if (a) atomicAdd(area + idx, a);
-        atomicMin(rowmin + ey, ex + 1);
-        atomicMax(rowmax + ey, ex + 1);
+        if (MODE == BOUNDS) {
+            atomicMin(rowmin + ey, ex + 1);
+            atomicMax(rowmax + ey, ex + 1);
+        } else if (MODE == POOLED) {
+            const int idx = rowoff[ey] + (ex + 1 - rowmin[ey]);
+            if (c) atomicAdd(pcover + idx, c);
+            if (a) atomicAdd(parea + idx, a);
+        } else {
+            const size_t idx = (size_t)ey * (size + 2) + ex + 1;
+            if (c) atomicAdd(cover + idx, c);
+            if (a) atomicAdd(area + idx, a);
+        }
     }
-    __device__ void hline(int ey, int x1, int y1, int x2, int y2) const {
+    template <int MODE> __device__ void hline(int ey, int x1, int y1, int x2, int y2) const {
         int ex1 = x1 >> SHIFT;
         const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
         if (y1 == y2) return;
         if (ex1 == ex2) {
             const int delta = y2 - y1;
-            add(ex1, ey, delta, (fx1 + fx2) * delta);
+            add<MODE>(ex1, ey, delta, (fx1 + fx2) * delta);
             return;
         }
         int p = (SUB - fx1) * (y2 - y1), first = SUB, incr = 1, dx = x2 - x1;
         if (dx < 0) { p = fx1 * (y2 - y1); first = 0; incr = -1; dx = -dx; }
         int delta = p / dx, mod = p % dx;
         if (mod < 0) { --delta; mod += dx; }
-        add(ex1, ey, delta, (fx1 + first) * delta);
+        add<MODE>(ex1, ey, delta, (fx1 + first) * delta);
         ex1 += incr;
         y1 += delta;
         if (ex1 != ex2) {
@@ -277,20 +294,20 @@ struct CellSink {
                 delta = lift;
                 mod += rem;
                 if (mod >= 0) { mod -= dx; ++delta; }
-                add(ex1, ey, delta, SUB * delta);
+                add<MODE>(ex1, ey, delta, SUB * delta);
                 y1 += delta;
                 ex1 += incr;
             }
         }
         delta = y2 - y1;
-        add(ex1, ey, delta, (fx2 + SUB - first) * delta);
+        add<MODE>(ex1, ey, delta, (fx2 + SUB - first) * delta);
     }
-    __device__ void line(int x1, int y1, int x2, int y2) const {
+    template <int MODE> __device__ void line(int x1, int y1, int x2, int y2) const {
         const int dx = x2 - x1;
         int dy = y2 - y1;
         int ey1 = y1 >> SHIFT;
         const int ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
-        if (ey1 == ey2) { hline(ey1, x1, fy1, x2, fy2); return; }
+        if (ey1 == ey2) { hline<MODE>(ey1, x1, fy1, x2, fy2); return; }
         int incr = 1;
         if (dx == 0) {
             const int ex = x1 >> SHIFT;
@@ -298,13 +315,13 @@ struct CellSink {
             int first = SUB;
             if (dy < 0) { first = 0; incr = -1; }
             int delta = first - fy1;
-            add(ex, ey1, delta, two_fx * delta);
+            add<MODE>(ex, ey1, delta, two_fx * delta);
             ey1 += incr;
             delta = first + first - SUB;
             const int a = two_fx * delta;
-            while (ey1 != ey2) { add(ex, ey1, delta, a); ey1 += incr; }
+            while (ey1 != ey2) { add<MODE>(ex, ey1, delta, a); ey1 += incr; }
             delta = fy2 - SUB + first;
-            add(ex, ey1, delta, two_fx * delta);
+            add<MODE>(ex, ey1, delta, two_fx * delta);
             return;
         }
         long long p = (long long)(SUB - fy1) * dx;
@@ -313,7 +330,7 @@ struct CellSink {
         int delta = (int)(p / dy), mod = (int)(p % dy);
         if (mod < 0) { --delta; mod += dy; }
         int x_from = x1 + delta;
-        hline(ey1, x1, fy1, x_from, first);
+        hline<MODE>(ey1, x1, fy1, x_from, first);
         ey1 += incr;
         if (ey1 != ey2) {
             p = (long long)SUB * dx;
@@ -325,12 +342,12 @@ struct CellSink {
                 mod += rem;
                 if (mod >= 0) { mod -= dy; ++delta; }
                 const int x_to = x_from + delta;
-                hline(ey1, x_from, SUB - first, x_to, first);
+                hline<MODE>(ey1, x_from, SUB - first, x_to, first);
                 x_from = x_to;
                 ey1 += incr;
             }
         }
-        hline(ey1, x_from, SUB - first, x2, fy2);
+        hline<MODE>(ey1, x_from, SUB - first, x2, fy2);
     }
 };
 
@@ -342,46 +359,46 @@ struct EdgeClip {
         return (unsigned)(x > bx2) | ((unsigned)(y > by2) << 1) | ((unsigned)(x < bx1) << 2) | ((unsigned)(y < by1) << 3);
     }
     __device__ __forceinline__ unsigned flags_y(double y) const { return ((unsigned)(y > by2) << 1) | ((unsigned)(y < by1) << 3); }
-    __device__ void clip_y(double x1, double y1, double x2, double y2, unsigned f1, unsigned f2) const {
+    template <int MODE> __device__ void clip_y(double x1, double y1, double x2, double y2, unsigned f1, unsigned f2) const {
         f1 &= 10; f2 &= 10;
-        if ((f1 | f2) == 0) { c->line(iround(x1 * SUB), iround(y1 * SUB), iround(x2 * SUB), iround(y2 * SUB)); return; }
+        if ((f1 | f2) == 0) { c->line<MODE>(iround(x1 * SUB), iround(y1 * SUB), iround(x2 * SUB), iround(y2 * SUB)); return; }
         if (f1 == f2) return;
         double tx1 = x1, ty1 = y1, tx2 = x2, ty2 = y2;
         if (f1 & 8) { tx1 = x1 + (by1 - y1) * (x2 - x1) / (y2 - y1); ty1 = by1; }
         if (f1 & 2) { tx1 = x1 + (by2 - y1) * (x2 - x1) / (y2 - y1); ty1 = by2; }
         if (f2 & 8) { tx2 = x1 + (by1 - y1) * (x2 - x1) / (y2 - y1); ty2 = by1; }
         if (f2 & 2) { tx2 = x1 + (by2 - y1) * (x2 - x1) / (y2 - y1); ty2 = by2; }
-        c->line(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB));
+        c->line<MODE>(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB));
     }
-    __device__ void edge(double x1, double y1, double x2, double y2) const {
+    template <int MODE> __device__ void edge(double x1, double y1, double x2, double y2) const {
         const unsigned f1 = flags(x1, y1), f2 = flags(x2, y2);
         if ((f1 & 10) == (f2 & 10) && (f1 & 10) != 0) return;      // invisible by y
         double y3, y4;
         unsigned f3, f4;
         switch (((f1 & 5) << 1) | (f2 & 5)) {
-        case 0: clip_y(x1, y1, x2, y2, f1, f2); break;
+        case 0: clip_y<MODE>(x1, y1, x2, y2, f1, f2); break;
         case 1:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y(x1, y1, bx2, y3, f1, f3); clip_y(bx2, y3, bx2, y2, f3, f2); break;
+            clip_y<MODE>(x1, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx2, y2, f3, f2); break;
         case 2:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y(bx2, y1, bx2, y3, f1, f3); clip_y(bx2, y3, x2, y2, f3, f2); break;
-        case 3: clip_y(bx2, y1, bx2, y2, f1, f2); break;
+            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, x2, y2, f3, f2); break;
+        case 3: clip_y<MODE>(bx2, y1, bx2, y2, f1, f2); break;
         case 4:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y(x1, y1, bx1, y3, f1, f3); clip_y(bx1, y3, bx1, y2, f3, f2); break;
+            clip_y<MODE>(x1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx1, y2, f3, f2); break;
         case 6:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
             f3 = flags_y(y3); f4 = flags_y(y4);
-            clip_y(bx2, y1, bx2, y3, f1, f3); clip_y(bx2, y3, bx1, y4, f3, f4); clip_y(bx1, y4, bx1, y2, f4, f2); break;
+            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx1, y4, f3, f4); clip_y<MODE>(bx1, y4, bx1, y2, f4, f2); break;
         case 8:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y(bx1, y1, bx1, y3, f1, f3); clip_y(bx1, y3, x2, y2, f3, f2); break;
+            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, x2, y2, f3, f2); break;
         case 9:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
             f3 = flags_y(y3); f4 = flags_y(y4);
-            clip_y(bx1, y1, bx1, y3, f1, f3); clip_y(bx1, y3, bx2, y4, f3, f4); clip_y(bx2, y4, bx2, y2, f4, f2); break;
-        case 12: clip_y(bx1, y1, bx1, y2, f1, f2); break;
+            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx2, y4, f3, f4); clip_y<MODE>(bx2, y4, bx2, y2, f4, f2); break;
+        case 12: clip_y<MODE>(bx1, y1, bx1, y2, f1, f2); break;
         default: break;
         }
     }
@@ -410,52 +427,102 @@ struct PolyRef { int first, count; };   // vertices [first, first + count) of th
 // One workgroup rasterises one image.  scratch per workgroup: simplified points RT x MAXS, outline vertices RT x MAXV,
 // polygon tables, cover / area accumulators.
 struct RasterArgs {
-    const double* l; const long long* offsets; int batch; int size; int samples; unsigned a8;
+    const double* l; const long long* offsets; const double* tab; int batch; int size; int samples; unsigned a8;
     unsigned char* out; int* queue; unsigned* flags;
     V2* simp; V2* verts; int* polys;     // per workgroup: RT * MAXS, RT * MAXV, RT * (1 + 2 * MAXSUB)
     int* cover; int* area;               // per workgroup: size * (size + 2) each, zero between lines
 };
 
+// sweep_scanline + render_scanline_aa_solid of one row: cells cell(0 .. len) (cover, area), first cell at pixel lo - 1
+template <class GetCell>
+__device__ __forceinline__ void sweep_row(GetCell cell, int lo, int hi, unsigned char* prow, int size, unsigned grey, unsigned a8) {
+    int cover = 0, span_from = 0;
+    bool span = false;
+    for (int xi = lo; xi <= hi; ++xi) {
+        int c, a;
+        cell(xi - lo, c, a);
+        if ((c | a) == 0) continue;
+        const int cx = xi - 1;                            // pixel x of cell index xi
+        if (span && cx > span_from) {                     // the run of whole pixels between two cells
+            const unsigned al = calc_alpha(cover << (SHIFT + 1));
+            if (al)
+                for (int xx = span_from < 0 ? 0 : span_from; xx < cx && xx < size; ++xx)
+                    prow[xx] = (unsigned char)blend(prow[xx], grey, a8, al);
+        }
+        cover += c;
+        int x = cx;
+        if (a) {
+            const unsigned al = calc_alpha((cover << (SHIFT + 1)) - a);
+            if (al && x >= 0 && x < size) prow[x] = (unsigned char)blend(prow[x], grey, a8, al);
+            ++x;
+        }
+        span = true;
+        span_from = x;
+    }
+}
+
+// One closed polygon: cells, then one thread per touched row sweeps and blends.  img: the image in HBM; every row is
+// read and written by one thread only (the same thread for every polygon), lines are ordered by the barriers.
 __device__ void raster_polygon(const V2* v, int n, unsigned grey, unsigned a8, const CellSink& sink, unsigned char* img,
-                               int size) {
-    // edges -> cells
+                               int size, int* s_total) {
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = &sink;
+    // pass 1: the rows' cell ranges
     for (int k = threadIdx.x; k < n; k += RT) {
         const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
-        ec.edge(a.x, a.y, b.x, b.y);
+        ec.edge<BOUNDS>(a.x, a.y, b.x, b.y);
     }
     __syncthreads();
-    // sweep_scanline + render_scanline_aa_solid, one thread per row
+    // exclusive prefix sum of the ranges' lengths over the rows (one wave, 16 rows per lane at size <= 1024)
+    if (threadIdx.x < 64) {
+        const int per = (size + 63) / 64;
+        const int y0 = threadIdx.x * per;
+        int sum = 0;
+        for (int y = y0; y < y0 + per && y < size; ++y) {
+            const int len = sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
+            sum += len;
+        }
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        int off = incl - sum;
+        for (int y = y0; y < y0 + per && y < size; ++y) {
+            sink.rowoff[y] = off;
+            off += sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
+        }
+        if (threadIdx.x == 63) *s_total = incl;
+    }
+    __syncthreads();
+    const bool pooled = *s_total <= POOL;
+    // pass 2: the cells
+    if (pooled) {
+        for (int k = threadIdx.x; k < n; k += RT) {
+            const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
+            ec.edge<POOLED>(a.x, a.y, b.x, b.y);
+        }
+    } else {
+        for (int k = threadIdx.x; k < n; k += RT) {
+            const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
+            ec.edge<GLOBAL>(a.x, a.y, b.x, b.y);
+        }
+    }
+    __syncthreads();
     const int ldc = size + 2;
     for (int y = threadIdx.x; y < size; y += RT) {
         const int lo = sink.rowmin[y], hi = sink.rowmax[y];
         if (hi < lo) continue;
-        int* crow = sink.cover + (size_t)y * ldc;
-        int* arow = sink.area + (size_t)y * ldc;
         unsigned char* prow = img + (size_t)y * size;
-        int cover = 0;
-        int x = lo - 1;                                   // pixel x of cell index xi is xi - 1
-        int span_from = 0;
-        bool span = false;
-        for (int xi = lo; xi <= hi; ++xi) {
-            const int c = atomicExch(crow + xi, 0), a = atomicExch(arow + xi, 0);   // read through L2 and clear
-            if ((c | a) == 0) continue;
-            const int cx = xi - 1;
-            if (span && cx > span_from) {                 // the run of whole pixels between two cells
-                const unsigned al = calc_alpha(cover << (SHIFT + 1));
-                if (al)
-                    for (int xx = span_from < 0 ? 0 : span_from; xx < cx && xx < size; ++xx) prow[xx] = (unsigned char)blend(prow[xx], grey, a8, al);
-            }
-            cover += c;
-            x = cx;
-            if (a) {
-                const unsigned al = calc_alpha((cover << (SHIFT + 1)) - a);
-                if (al && x >= 0 && x < size) prow[x] = (unsigned char)blend(prow[x], grey, a8, al);
-                ++x;
-            }
-            span = true;
-            span_from = x;
+        if (pooled) {
+            int* pc = sink.pcover + sink.rowoff[y];
+            int* pa = sink.parea + sink.rowoff[y];
+            sweep_row([&](int q, int& c, int& a) { c = pc[q]; a = pa[q]; pc[q] = 0; pa[q] = 0; }, lo, hi, prow, size, grey, a8);
+        } else {
+            int* crow = sink.cover + (size_t)y * ldc + lo;
+            int* arow = sink.area + (size_t)y * ldc + lo;
+            sweep_row([&](int q, int& c, int& a) { c = atomicExch(crow + q, 0); a = atomicExch(arow + q, 0); }, lo, hi, prow,
+                      size, grey, a8);
         }
         sink.rowmin[y] = 0x7fffffff;
         sink.rowmax[y] = -1;
@@ -463,9 +530,22 @@ __device__ void raster_polygon(const V2* v, int n, unsigned grey, unsigned a8, c
     __syncthreads();
 }
 
+// sin / cos of the sample angles: the same 10 000 values for every line of every image
+__global__ void raster_table_kernel(int ns, double* tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
+    const double step = (hi_a - lo_a) / (ns - 1);
+    const double al = (i == ns - 1) ? hi_a : lo_a + i * step;       // numpy.linspace
+    tab[3 * i] = al;
+    tab[3 * i + 1] = sin(al);
+    tab[3 * i + 2] = cos(al);
+}
+
 __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
-    __shared__ int s_rowmin[1024], s_rowmax[1024];
-    __shared__ int s_img;
+    __shared__ int s_rowmin[1024], s_rowmax[1024], s_rowoff[1024];
+    __shared__ int s_pcover[POOL], s_parea[POOL];
+    __shared__ int s_img, s_total;
     const int size = A.size;
     const int wg = blockIdx.x;
     V2* simp = A.simp + (size_t)wg * RT * MAXS;
@@ -474,8 +554,10 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
     CellSink sink;
     sink.cover = A.cover + (size_t)wg * size * (size + 2);
     sink.area = A.area + (size_t)wg * size * (size + 2);
-    sink.rowmin = s_rowmin; sink.rowmax = s_rowmax; sink.size = size;
-    for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; }
+    sink.rowmin = s_rowmin; sink.rowmax = s_rowmax; sink.rowoff = s_rowoff; sink.size = size;
+    sink.pcover = s_pcover; sink.parea = s_parea;
+    for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; }
+    for (int q = threadIdx.x; q < POOL; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
     const double width_px = 100.0 / 72.0;                 // 1 pt at 100 dpi (matplotlib 1.5.1's default line width)
     for (;;) {
         if (threadIdx.x == 0) s_img = atomicAdd(A.queue, 1);
@@ -491,6 +573,7 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
         __syncthreads();
         for (long long base = lo; base < hi; base += RT) {
             const int nb = (int)((hi - base) < RT ? (hi - base) : RT);
+            const long long t_a = wall_clock64();
             // ---- phase A: thread t -> outline of line base + t ----
             if ((int)threadIdx.x < nb) {
                 const int t = threadIdx.x;
@@ -504,7 +587,6 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
                 s.init(sp, MAXS, fl);
                 const int ns = A.samples;
                 const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
-                const double step = (hi_a - lo_a) / (ns - 1);
                 auto flush = [&]() {                      // end of a sub-path: stroke what the simplifier kept
                     s.end();
                     if (s.n >= 2) {
@@ -518,8 +600,8 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
                     s.n = 0;
                 };
                 for (int i = 0; i < ns; ++i) {
-                    const double al = (i == ns - 1) ? hi_a : lo_a + i * step;       // numpy.linspace
-                    double be = -atan((-la * sin(al) - lc * cos(al)) / lb);          // sphere_mapping.py:63
+                    const double al = A.tab[3 * i], sa = A.tab[3 * i + 1], ca = A.tab[3 * i + 2];   // (wave-uniform loads)
+                    double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
                     be *= -1;                                                         // :65
                     const double x = (al - lo_a) / (hi_a - lo_a) * size;
                     const double y = size - (be - lo_a) / (hi_a - lo_a) * size;
@@ -533,12 +615,17 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
                 pt[0] = npoly;
             }
             __syncthreads();
+            const long long t_b = wall_clock64();
             // ---- phase B: the lines of this batch in order ----
             for (int t = 0; t < nb; ++t) {
                 const int* pt = polys + t * (1 + 2 * MAXSUB);
                 const int npoly = pt[0];
                 for (int q = 0; q < npoly; ++q)
-                    raster_polygon(verts + (size_t)t * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], 255u, A.a8, sink, img, size);
+                    raster_polygon(verts + (size_t)t * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], 255u, A.a8, sink, img, size, &s_total);
+            }
+            if (threadIdx.x == 0 && blockIdx.x == 0) {     // device time of the two phases (100 MHz ticks), workgroup 0
+                atomicAdd(A.queue + 2, (int)(t_b - t_a));
+                atomicAdd(A.queue + 3, (int)(wall_clock64() - t_b));
             }
         }
         // ---- the axes' spines over the lines: left, right, bottom, top (matplotlib's drawing order) ----
@@ -560,7 +647,7 @@ __global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
                     polys[0] = o.n;
                 }
                 __syncthreads();
-                raster_polygon(sv, polys[0], 0u, 255u, sink, img, size);
+                raster_polygon(sv, polys[0], 0u, 255u, sink, img, size, &s_total);
             }
         }
         __syncthreads();
@@ -581,12 +668,14 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     //             cover, area]
     const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
+    const int samples = 10000;                            // sphere_mapping.py:40
+    const size_t tb = vpk::em_align((size_t)samples * 3 * 8, 256);
     const size_t simp_b = (size_t)RT * MAXS * sizeof(V2), vert_b = (size_t)RT * MAXV * sizeof(V2);
     const size_t poly_b = vpk::em_align((size_t)RT * (1 + 2 * MAXSUB) * 4, 256);
     const size_t acc_b = vpk::em_align((size_t)size * (size + 2) * 4, 256);
     const size_t per_wg = simp_b + vert_b + poly_b + 2 * acc_b;
-    while (wgs > 1 && ob + fb + (size_t)wgs * per_wg > h->total_mem / 4) wgs /= 2;
-    int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, ob + fb + (size_t)wgs * per_wg, "hipMalloc(raster workspace)");
+    while (wgs > 1 && ob + fb + tb + (size_t)wgs * per_wg > h->total_mem / 4) wgs /= 2;
+    int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, ob + fb + tb + (size_t)wgs * per_wg, "hipMalloc(raster workspace)");
     if (rc) return rc;
     char* base = (char*)h->raster_hdr;
     // offsets [host] -> device: caller-owned pageable memory, so the copy is waited for
@@ -595,10 +684,12 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     VPK_HIP(h, hipStreamSynchronize(h->stream));
     VPK_HIP(h, hipMemsetAsync(base + ob, 0, fb, h->stream));
     RasterArgs A;
-    A.l = l; A.offsets = (const long long*)base; A.batch = batch; A.size = size; A.samples = 10000;
+    hipLaunchKernelGGL(raster_table_kernel, dim3((samples + 255) / 256), dim3(256), 0, h->stream, samples, (double*)(base + ob + fb));
+    A.l = l; A.offsets = (const long long*)base; A.tab = (const double*)(base + ob + fb); A.batch = batch; A.size = size;
+    A.samples = samples;
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround
     A.out = out; A.queue = (int*)(base + ob); A.flags = (unsigned*)(base + ob + 256);
-    char* p = base + ob + fb;
+    char* p = base + ob + fb + tb;
     A.simp = (V2*)p; p += (size_t)wgs * simp_b;
     A.verts = (V2*)p; p += (size_t)wgs * vert_b;
     A.polys = (int*)p; p += (size_t)wgs * poly_b;
@@ -607,6 +698,13 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     VPK_HIP(h, hipMemsetAsync(A.cover, 0, 2 * (size_t)wgs * acc_b, h->stream));    // the sweeps leave them zero again
     hipLaunchKernelGGL(raster_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
     VPK_HIP(h, hipGetLastError());
+    if (getenv("VPK_RASTER_TIMES")) {                     // development: where workgroup 0 spent its time
+        int q[8];
+        VPK_HIP(h, hipStreamSynchronize(h->stream));
+        VPK_HIP(h, hipMemcpy(q, A.queue, sizeof(q), hipMemcpyDeviceToHost));
+        fprintf(stderr, "vpk_sphere_raster: workgroup 0: outlines %.2f ms, cells + blending %.2f ms (%d images on %d workgroups)\n",
+                q[2] * 1e-5, q[3] * 1e-5, batch, wgs);
+    }
     return VPK_OK;
 }
 
