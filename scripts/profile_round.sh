@@ -1,29 +1,29 @@
 #!/bin/bash
 # rocprofv3 passes for profiles/ (one MI355X through gpurun): kernel traces (+ per-kernel stats), HBM traffic
 # counters and MFMA-busy counters, every --pmc set in its own pass with --kernel-trace only.
-# Summaries land in gpurun_out/prof/summary (copy them to profiles/).   ROUND=r02 bash scripts/profile_round.sh
+# Summaries land in gpurun_out/prof/summary (copy them to profiles/).   ROUND=r03 bash scripts/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/prof
-N=${ROUND:-r02}
+N=${ROUND:-r03}
 rm -rf $R; mkdir -p $R/summary
-BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
+BENCH="python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_trace -o t -- $BENCH > $R/yud_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/stress_trace -o t -- python3 bench.py --workload stress --steps 3 --warmup 1 --no-cpu-baseline --no-alt > $R/stress_trace.log 2>&1
 # CNN alone: 2 warm-up + 12 timed forward passes at B = 102 (the summary drops the warm-up dispatches)
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- python3 bench.py --workload yud --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --workload yud --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/stress_fetch -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/stress_write -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_write.log 2>&1
 # CNN alone with conv2..5 on the bf16 matrix cores (vpk_cnn_set_precision(1)) and the bench with that path
 export VPK_PRECISION=1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_split_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_split_trace.log 2>&1
 unset VPK_PRECISION
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --cnn-precision 1 --em-wgs 47 > $R/yud_split_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt --cnn-precision 1 --em-wgs 47 > $R/yud_split_trace.log 2>&1
 # MFMA utilisation of the conv / dense kernels: CNN alone and inside the bench (beside the EM)
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/cnn_mfma -o t -- python3 scripts/time_cnn.py --passes 6 102 > $R/cnn_mfma.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/yud_mfma -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt > $R/yud_mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/yud_mfma -o t -- python3 bench.py --workload yud --steps 4 --warmup 2 --no-cpu-baseline --no-alt > $R/yud_mfma.log 2>&1
 python3 scripts/rocpd_stats.py $(find $R/yud_trace -name '*.db' | head -1) $R/summary/${N}_yud_kernel_stats.csv > $R/summary/${N}_yud_top.txt
 python3 scripts/rocpd_stats.py $(find $R/stress_trace -name '*.db' | head -1) $R/summary/${N}_stress_kernel_stats.csv > $R/summary/${N}_stress_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_trace -name '*.db' | head -1) $R/summary/${N}_cnn_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_top.txt
