@@ -165,6 +165,10 @@ int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
  * image row 0 = beta = +pi/2.  alpha = per-line blend weight (0.1 in the reference). */
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
                       double alpha, uint8_t* out);
+/* per-image flags of the LAST vpk_sphere_raster call on this handle (waits for it): bit 0 = a line produced more outline
+ * vertices / coverage than the kernel's buffers hold and was truncated or dropped (never seen on real line sets: a
+ * simplified curve keeps 30-100 of its 10 000 samples). */
+int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out);
 
 /* ---- front end: line segment detection (HOST code, host pointers) -------------------------------------------- */
 /* replaces: lsdpython.lsd.detect_line_segments(image) as called by detect_lsd_lines (evaluation.py:227-251; the

@@ -16,16 +16,12 @@
 //                             p' = ((65280 - 255 p) a + 65280 p) / (65280 + a), truncated; ONE LINE AFTER THE OTHER
 //   the axes' four spines     0.8 pt black strokes snapped to the pixel centres of the border, drawn over the lines
 //
-// Decomposition.  One persistent workgroup per image (images come from a queue).  Phase A: one THREAD per line evaluates
-// the 10 000 samples, simplifies them on the fly (the simplifier is a sequential state machine) and strokes the result:
-// a closed outline polygon of ~100-200 vertices in the workgroup's HBM scratch.  Phase B, line by line in input order
-// (the blend is not commutative in 8-bit arithmetic): the polygon's edges are dealt to the threads and walked twice -- first
-// to find every row's cell range, then, after a prefix sum has packed the ranges into a 96 KB LDS pool, to add the
-// cells (cover, area) there with LDS atomics (sums are order independent: same cells as Agg's sorted list) -- and one
-// thread per touched row sweeps its cells left to right: running cover, alpha, blend into the uint8 image.  Four
-// workgroup barriers per line.
+// Decomposition: three kernels (outlines per line over all CUs, coverage per line over all CUs, ordered blend per image
+// row), described where they are defined below.
 #include "vpk_internal.hpp"
 
+#include <algorithm>
+#include <stdlib.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -253,6 +249,7 @@ struct CellSink {
     int* pcover; int* parea;            // POOLED: LDS pool
     int* rowmin; int* rowmax; int* rowoff;   // LDS, per row
     int size;
+    int blo, bhi, boff;                 // POOLED: the band of rows [blo, bhi) the pool holds now; pool index = rowoff - boff
     template <int MODE> __device__ __forceinline__ void add(int ex, int ey, int c, int a) const {
         if ((c | a) == 0) return;
         if (ey < 0 || ey >= size || ex < -1 || ex > size) return;
@@ -260,7 +257,8 @@ struct CellSink {
             atomicMin(rowmin + ey, ex + 1);
             atomicMax(rowmax + ey, ex + 1);
         } else if (MODE == POOLED) {
-            const int idx = rowoff[ey] + (ex + 1 - rowmin[ey]);
+            if (ey < blo || ey >= bhi) return;
+            const int idx = rowoff[ey] - boff + (ex + 1 - rowmin[ey]);
             if (c) atomicAdd(pcover + idx, c);
             if (a) atomicAdd(parea + idx, a);
         } else {
@@ -269,7 +267,7 @@ struct CellSink {
             if (a) atomicAdd(area + idx, a);
         }
     }
-    template <int MODE> __device__ void hline(int ey, int x1, int y1, int x2, int y2) const {
+    template <int MODE> __device__ __noinline__ void hline(int ey, int x1, int y1, int x2, int y2) const {
         int ex1 = x1 >> SHIFT;
         const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
         if (y1 == y2) return;
@@ -302,52 +300,53 @@ struct CellSink {
         delta = y2 - y1;
         add<MODE>(ex1, ey, delta, (fx2 + SUB - first) * delta);
     }
-    template <int MODE> __device__ void line(int x1, int y1, int x2, int y2) const {
+    // rasterizer_cells_aa::line for the rows [part * nrows / nparts, (part + 1) * nrows / nparts) of the edge only: a long
+    // edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
+    // the running remainder wraps); after k middle rows the remainder has wrapped floor((mod0 + k rem) / dy) times, so
+    // any row's (x_from, x_to) follows in closed form and a thread can start in the middle of the edge with exactly the
+    // state the sequential walk has there.
+    template <int MODE> __device__ __noinline__ void line(int x1, int y1, int x2, int y2, int part, int nparts) const {
         const int dx = x2 - x1;
         int dy = y2 - y1;
-        int ey1 = y1 >> SHIFT;
-        const int ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
-        if (ey1 == ey2) { hline<MODE>(ey1, x1, fy1, x2, fy2); return; }
-        int incr = 1;
+        const int ey1 = y1 >> SHIFT, ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
+        if (ey1 == ey2) { if (part == 0) hline<MODE>(ey1, x1, fy1, x2, fy2); return; }
+        const int incr = dy < 0 ? -1 : 1;
+        const int nrows = (ey2 - ey1) * incr + 1;
+        const int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
+        if (r0 >= r1) return;
+        const int first = dy < 0 ? 0 : SUB;
         if (dx == 0) {
             const int ex = x1 >> SHIFT;
             const int two_fx = (x1 - (ex << SHIFT)) << 1;
-            int first = SUB;
-            if (dy < 0) { first = 0; incr = -1; }
-            int delta = first - fy1;
-            add<MODE>(ex, ey1, delta, two_fx * delta);
-            ey1 += incr;
-            delta = first + first - SUB;
-            const int a = two_fx * delta;
-            while (ey1 != ey2) { add<MODE>(ex, ey1, delta, a); ey1 += incr; }
-            delta = fy2 - SUB + first;
-            add<MODE>(ex, ey1, delta, two_fx * delta);
+            for (int r = r0; r < r1; ++r) {
+                int delta;
+                if (r == 0) delta = first - fy1;
+                else if (r == nrows - 1) delta = fy2 - SUB + first;
+                else delta = first + first - SUB;
+                add<MODE>(ex, ey1 + r * incr, delta, two_fx * delta);
+            }
             return;
         }
-        long long p = (long long)(SUB - fy1) * dx;
-        int first = SUB;
-        if (dy < 0) { p = (long long)fy1 * dx; first = 0; incr = -1; dy = -dy; }
-        int delta = (int)(p / dy), mod = (int)(p % dy);
-        if (mod < 0) { --delta; mod += dy; }
-        int x_from = x1 + delta;
-        hline<MODE>(ey1, x1, fy1, x_from, first);
-        ey1 += incr;
-        if (ey1 != ey2) {
-            p = (long long)SUB * dx;
-            int lift = (int)(p / dy), rem = (int)(p % dy);
-            if (rem < 0) { --lift; rem += dy; }
-            mod -= dy;
-            while (ey1 != ey2) {
-                delta = lift;
-                mod += rem;
-                if (mod >= 0) { mod -= dy; ++delta; }
-                const int x_to = x_from + delta;
-                hline<MODE>(ey1, x_from, SUB - first, x_to, first);
-                x_from = x_to;
-                ey1 += incr;
-            }
+        // (32-bit like AGG: |dx|, dy <= 1024 px x 256, so 256 |dx| and mod0 + k rem stay below 2^29)
+        int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
+        if (dy < 0) dy = -dy;
+        int delta0 = p / dy, mod0 = p % dy;
+        if (mod0 < 0) { --delta0; mod0 += dy; }
+        const int x_from0 = x1 + delta0;
+        p = SUB * dx;
+        int lift = p / dy, rem = p % dy;
+        if (rem < 0) { --lift; rem += dy; }
+        int xf = 0;
+        bool have = false;
+        for (int r = r0; r < r1; ++r) {
+            if (r == 0) { hline<MODE>(ey1, x1, fy1, x_from0, first); continue; }
+            const int j = r - 1;                              // middle row index (the last row is middle row nrows - 2)
+            if (!have) { xf = x_from0 + j * lift + (mod0 + j * rem) / dy; have = true; }
+            if (r == nrows - 1) { hline<MODE>(ey2, xf, SUB - first, x2, fy2); continue; }
+            const int xt = x_from0 + (j + 1) * lift + (mod0 + (j + 1) * rem) / dy;
+            hline<MODE>(ey1 + r * incr, xf, SUB - first, xt, first);
+            xf = xt;
         }
-        hline<MODE>(ey1, x_from, SUB - first, x2, fy2);
     }
 };
 
@@ -355,21 +354,27 @@ struct CellSink {
 struct EdgeClip {
     double bx1, by1, bx2, by2;
     const CellSink* c;
+    int part, nparts;            // this thread's share of the edge's rows
     __device__ __forceinline__ unsigned flags(double x, double y) const {
         return (unsigned)(x > bx2) | ((unsigned)(y > by2) << 1) | ((unsigned)(x < bx1) << 2) | ((unsigned)(y < by1) << 3);
     }
     __device__ __forceinline__ unsigned flags_y(double y) const { return ((unsigned)(y > by2) << 1) | ((unsigned)(y < by1) << 3); }
-    template <int MODE> __device__ void clip_y(double x1, double y1, double x2, double y2, unsigned f1, unsigned f2) const {
-        f1 &= 10; f2 &= 10;
-        if ((f1 | f2) == 0) { c->line<MODE>(iround(x1 * SUB), iround(y1 * SUB), iround(x2 * SUB), iround(y2 * SUB)); return; }
-        if (f1 == f2) return;
-        double tx1 = x1, ty1 = y1, tx2 = x2, ty2 = y2;
-        if (f1 & 8) { tx1 = x1 + (by1 - y1) * (x2 - x1) / (y2 - y1); ty1 = by1; }
-        if (f1 & 2) { tx1 = x1 + (by2 - y1) * (x2 - x1) / (y2 - y1); ty1 = by2; }
-        if (f2 & 8) { tx2 = x1 + (by1 - y1) * (x2 - x1) / (y2 - y1); ty2 = by1; }
-        if (f2 & 2) { tx2 = x1 + (by2 - y1) * (x2 - x1) / (y2 - y1); ty2 = by2; }
-        c->line<MODE>(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB));
+    // line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker.  Not inlined: an
+    // edge has up to three pieces at eleven call sites, and the walker inlined at all of them was 90 KB of code.
+    template <int MODE> __device__ __noinline__ void clip_y(double ax, double ay, double bx, double by, unsigned fa, unsigned fb) const {
+        fa &= 10; fb &= 10;
+        double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
+        if ((fa | fb) != 0) {
+            if (fa == fb) return;                          // invisible by y
+            if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
+            if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
+            if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
+            if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
+        }
+        c->line<MODE>(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
     }
+    // One edge = up to three pieces after clipping in x (the pieces on the clip box's left / right side are kept: they
+    // close the winding).
     template <int MODE> __device__ void edge(double x1, double y1, double x2, double y2) const {
         const unsigned f1 = flags(x1, y1), f2 = flags(x2, y2);
         if ((f1 & 10) == (f2 & 10) && (f1 & 10) != 0) return;      // invisible by y
@@ -422,64 +427,147 @@ __device__ __forceinline__ unsigned blend(unsigned p, unsigned grey, unsigned a8
     return (unsigned)((((int)(grey << 8) - (int)r) * (int)alpha + (int)(r << 8)) / (int)a);
 }
 
-struct PolyRef { int first, count; };   // vertices [first, first + count) of the line's vertex buffer: one closed polygon
+// ---------------------------------------------------------------------------------------------------------------
+// Three kernels.
+//   outline_kernel   one THREAD per line (all lines of the call, all CUs): samples -> PathSimplifier -> conv_stroke; the
+//                    closed outline polygons (up to MAXSUB per line) go to HBM
+//   coverage_kernel  one WORKGROUP per line at a time (persistent workgroups over a queue of ALL lines: the lines of an
+//                    image need no order here): cells in the LDS pool, sweep -> the line's coverage as one byte per
+//                    pixel of every touched row's cell range (the pool's packing) + a row table, in HBM
+//   blend_kernel     one THREAD per image row, 64 rows per workgroup, the row's pixels in LDS: the image's lines IN
+//                    INPUT ORDER (the 8-bit blend does not commute), then the four spines; one coalesced store
+// ---------------------------------------------------------------------------------------------------------------
+struct RowRef { int off; short xmin; short len; };       // a touched row of one polygon: alpha bytes [off, off + len), first pixel xmin
+struct Item { long long alpha_base; long long row_base; int ymin, ymax; };   // one polygon's coverage (ymax < ymin: none)
 
-// One workgroup rasterises one image.  scratch per workgroup: simplified points RT x MAXS, outline vertices RT x MAXV,
-// polygon tables, cover / area accumulators.
 struct RasterArgs {
-    const double* l; const long long* offsets; const double* tab; int batch; int size; int samples; unsigned a8;
-    unsigned char* out; int* queue; unsigned* flags;
-    V2* simp; V2* verts; int* polys;     // per workgroup: RT * MAXS, RT * MAXV, RT * (1 + 2 * MAXSUB)
-    int* cover; int* area;               // per workgroup: size * (size + 2) each, zero between lines
+    const double* l; const long long* offsets; const double* tab;
+    int batch; int size; int samples; unsigned a8; long long nlines; long long line0;   // this chunk: lines [line0, line0 + nlines)
+    unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
+    unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
+    V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, 1 + 2 * MAXSUB
+    unsigned char* alpha; unsigned long long alpha_cap;
+    RowRef* rows; unsigned long long rows_cap;
+    Item* items;                                         // per line MAXSUB, then 4 spine items
+    int first_image;                                     // images [first_image, first_image + batch) of the caller's batch
 };
 
-// sweep_scanline + render_scanline_aa_solid of one row: cells cell(0 .. len) (cover, area), first cell at pixel lo - 1
-template <class GetCell>
-__device__ __forceinline__ void sweep_row(GetCell cell, int lo, int hi, unsigned char* prow, int size, unsigned grey, unsigned a8) {
-    int cover = 0, span_from = 0;
-    bool span = false;
-    for (int xi = lo; xi <= hi; ++xi) {
-        int c, a;
-        cell(xi - lo, c, a);
-        if ((c | a) == 0) continue;
-        const int cx = xi - 1;                            // pixel x of cell index xi
-        if (span && cx > span_from) {                     // the run of whole pixels between two cells
-            const unsigned al = calc_alpha(cover << (SHIFT + 1));
-            if (al)
-                for (int xx = span_from < 0 ? 0 : span_from; xx < cx && xx < size; ++xx)
-                    prow[xx] = (unsigned char)blend(prow[xx], grey, a8, al);
+__global__ void raster_table_kernel(int ns, double* tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
+    const double step = (hi_a - lo_a) / (ns - 1);
+    const double al = (i == ns - 1) ? hi_a : lo_a + i * step;       // numpy.linspace
+    tab[3 * i] = al;
+    tab[3 * i + 1] = sin(al);
+    tab[3 * i + 2] = cos(al);
+}
+
+__global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;     // line of this chunk; the 4 spines follow the lines
+    if (g >= A.nlines + 4) return;
+    V2* sp = A.simp + (size_t)g * MAXS;
+    Outline o;
+    unsigned dummy = 0;
+    unsigned* fl = &dummy;
+    o.v = A.verts + (size_t)g * MAXV; o.n = 0; o.cap = MAXV; o.flags = fl;
+    int* pt = A.polys + g * (1 + 2 * MAXSUB);
+    const int size = A.size;
+    if (g >= A.nlines) {
+        // the axes' spines: left, right, bottom, top (matplotlib's drawing order): two-vertex rectilinear paths, snapped to
+        // pixel centres (PathSnapper: floor(v + 0.5) + 0.5 for a stroke whose width rounds to an odd number of pixels)
+        const int side = (int)(g - A.nlines);
+        const double s = (double)size, w_spine = 0.8 * 100.0 / 72.0;
+        const double x0 = (side == 1) ? s : 0.0, y0 = (side == 3) ? 0.0 : s;
+        const double x1 = (side == 0) ? 0.0 : s, y1 = (side == 2) ? s : 0.0;
+        sp[0].x = floor(x0 + 0.5) + 0.5; sp[0].y = floor(y0 + 0.5) + 0.5;
+        sp[1].x = floor(x1 + 0.5) + 0.5; sp[1].y = floor(y1 + 0.5) + 0.5;
+        stroke_outline(sp, 2, w_spine, o);
+        pt[0] = 1; pt[1] = 0; pt[2] = o.n;
+        return;
+    }
+    const double width_px = 100.0 / 72.0;                 // 1 pt at 100 dpi (matplotlib 1.5.1's default line width)
+    const long long gl = A.line0 + g;
+    const double la = A.l[3 * gl], lb = A.l[3 * gl + 1], lc = A.l[3 * gl + 2];
+    int npoly = 0;
+    Simplifier sm;
+    sm.init(sp, MAXS, fl);
+    const int ns = A.samples;
+    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
+    auto flush = [&]() {                                  // end of a sub-path: stroke what the simplifier kept
+        sm.end();
+        if (sm.n >= 2) {
+            const int first = o.n;
+            stroke_outline(sp, sm.n, width_px, o);
+            if (o.n - first >= 3) {
+                if (npoly < MAXSUB) { pt[1 + 2 * npoly] = first; pt[2 + 2 * npoly] = o.n - first; ++npoly; }
+                else dummy |= FLAG_OVERFLOW;
+            }
         }
-        cover += c;
-        int x = cx;
-        if (a) {
-            const unsigned al = calc_alpha((cover << (SHIFT + 1)) - a);
-            if (al && x >= 0 && x < size) prow[x] = (unsigned char)blend(prow[x], grey, a8, al);
-            ++x;
+        sm.n = 0;
+    };
+    // four samples are evaluated side by side (independent atan / division chains: the thread is alone with its latency),
+    // then fed to the simplifier in order
+    for (int i0 = 0; i0 < ns; i0 += 4) {
+        double xs[4], ys[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u < ns ? i0 + u : ns - 1;
+            const double al = A.tab[3 * i], sa = A.tab[3 * i + 1], ca = A.tab[3 * i + 2];
+            double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
+            be *= -1;                                                         // :65
+            xs[u] = (al - lo_a) / (hi_a - lo_a) * size;
+            ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
         }
-        span = true;
-        span_from = x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u >= ns) break;
+            const double x = xs[u], y = ys[u];
+            if (!(x == x) || !(y == y) || isinf(x) || isinf(y)) {             // PathNanRemover: breaks the path
+                if (sm.have) flush();
+                continue;
+            }
+            if (!sm.have) sm.begin(x, y); else sm.feed(x, y);
+        }
+    }
+    if (sm.have) flush();
+    pt[0] = npoly;
+    if (dummy) {                                          // which image the line belongs to: binary search in the offsets
+        int lo = 0, hi = A.batch;
+        while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (A.offsets[A.first_image + mid] <= gl) lo = mid; else hi = mid; }
+        atomicOr(A.flags + A.first_image + lo, dummy);
     }
 }
 
-// One closed polygon: cells, then one thread per touched row sweeps and blends.  img: the image in HBM; every row is
-// read and written by one thread only (the same thread for every polygon), lines are ordered by the barriers.
-__device__ void raster_polygon(const V2* v, int n, unsigned grey, unsigned a8, const CellSink& sink, unsigned char* img,
-                               int size, int* s_total) {
+// cells of one polygon -> coverage bytes.  Same passes as before (bounds, row scan, cells into the LDS pool); the sweep
+// writes alpha bytes in the pool's packing instead of blending.
+__device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int size, int* s_total, long long* s_base,
+                                 const RasterArgs& A, Item* item) {
+    const bool probe = threadIdx.x == 0 && blockIdx.x == 0;
+    long long tp = probe ? wall_clock64() : 0;
+    auto lap = [&](int slot) { if (probe) { const long long now = wall_clock64(); atomicAdd(A.ctr + 8 + slot, (int)(now - tp)); tp = now; } };
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = &sink;
-    // pass 1: the rows' cell ranges
-    for (int k = threadIdx.x; k < n; k += RT) {
+    int K = (4 * RT) / (n > 0 ? n : 1);
+    K = K < 1 ? 1 : (K > 32 ? 32 : K);
+    ec.nparts = K;
+    const int items = n * K;
+    for (int it = threadIdx.x; it < items; it += RT) {    // pass 1: the rows' cell ranges
+        const int k = it / K;
+        ec.part = it - k * K;
         const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
         ec.edge<BOUNDS>(a.x, a.y, b.x, b.y);
     }
     __syncthreads();
-    // exclusive prefix sum of the ranges' lengths over the rows (one wave, 16 rows per lane at size <= 1024)
+    lap(0);
+    // exclusive prefix sum of the ranges' lengths over the rows (one wave), first / last touched row
     if (threadIdx.x < 64) {
         const int per = (size + 63) / 64;
         const int y0 = threadIdx.x * per;
-        int sum = 0;
+        int sum = 0, ymin = 0x7fffffff, ymax = -1;
         for (int y = y0; y < y0 + per && y < size; ++y) {
             const int len = sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
+            if (len) { ymin = ymin < y ? ymin : y; ymax = y; }
             sum += len;
         }
         int incl = sum;
@@ -492,166 +580,161 @@ __device__ void raster_polygon(const V2* v, int n, unsigned grey, unsigned a8, c
             sink.rowoff[y] = off;
             off += sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
         }
-        if (threadIdx.x == 63) *s_total = incl;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(ymin, o), b = __shfl_xor(ymax, o);
+            ymin = a < ymin ? a : ymin;
+            ymax = b > ymax ? b : ymax;
+        }
+        if (threadIdx.x == 63) {
+            s_total[0] = incl; s_total[1] = ymin; s_total[2] = ymax;
+            long long ab = -1, rb = -1;
+            if (incl > 0) {                               // space in the call's coverage pools (bump allocation)
+                ab = (long long)atomicAdd(A.bump, (unsigned long long)incl);
+                rb = (long long)atomicAdd(A.bump + 1, (unsigned long long)(ymax - ymin + 1));
+                if ((unsigned long long)ab + incl > A.alpha_cap || (unsigned long long)rb + (ymax - ymin + 1) > A.rows_cap) ab = -1;
+            }
+            s_base[0] = ab; s_base[1] = rb;
+        }
     }
     __syncthreads();
-    const bool pooled = *s_total <= POOL;
-    // pass 2: the cells
-    if (pooled) {
-        for (int k = threadIdx.x; k < n; k += RT) {
+    lap(1);
+    const int total = s_total[0], ymin = s_total[1], ymax = s_total[2];
+    const long long ab = s_base[0], rb = s_base[1];
+    const bool ok = ab >= 0;                              // (a polygon past the call's HBM pools is dropped and flagged)
+    // The pool holds the cell ranges of a BAND of rows at a time: all touched rows when they fit (the usual case), else as
+    // many consecutive rows as fit -- a curve with an interior extremum crosses the rows beside it twice, far apart, and a
+    // row's range spans both crossings.
+    int ys = ok ? ymin : size;
+    while (ys <= ymax && ys < size) {
+        int ye = ys + 1;                                  // (uniform: every thread walks the same prefix sums)
+        const int boff = sink.rowoff[ys];
+        if (total <= POOL) ye = ymax + 1;                  // everything fits: one band
+        else while (ye <= ymax && sink.rowoff[ye] + (sink.rowmax[ye] >= sink.rowmin[ye] ? sink.rowmax[ye] - sink.rowmin[ye] + 1 : 0) - boff <= POOL) ++ye;
+        CellSink band = sink;
+        band.blo = ys; band.bhi = ye; band.boff = boff;
+        ec.c = &band;
+        for (int it = threadIdx.x; it < items; it += RT) {    // pass 2: the cells of the band's rows
+            const int k = it / K;
+            ec.part = it - k * K;
             const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
             ec.edge<POOLED>(a.x, a.y, b.x, b.y);
         }
-    } else {
-        for (int k = threadIdx.x; k < n; k += RT) {
-            const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
-            ec.edge<GLOBAL>(a.x, a.y, b.x, b.y);
+        __syncthreads();
+        lap(2);
+        for (int y = ys + threadIdx.x; y < ye; y += RT) {
+            const int lo = sink.rowmin[y], hi = sink.rowmax[y];
+            RowRef r;
+            r.off = sink.rowoff[y]; r.xmin = (short)(lo - 1); r.len = (short)(hi >= lo ? hi - lo + 1 : 0);
+            if (hi < lo) { r.xmin = 0; r.len = 0; }
+            A.rows[rb + (y - ymin)] = r;
+            if (hi >= lo) {
+                int* pc = sink.pcover + sink.rowoff[y] - boff;
+                int* pa = sink.parea + sink.rowoff[y] - boff;
+                unsigned char* dst = A.alpha + ab + sink.rowoff[y];
+                int R = 0;
+                for (int q = 0; q <= hi - lo; ++q) {          // the per-pixel form of sweep_scanline (see blend_kernel)
+                    const int c = pc[q], a = pa[q];
+                    pc[q] = 0; pa[q] = 0;
+                    R += c;
+                    unsigned al = 0;
+                    if (a) al = calc_alpha((R << (SHIFT + 1)) - a);
+                    else if (q < hi - lo) al = calc_alpha(R << (SHIFT + 1));
+                    dst[q] = (unsigned char)al;
+                }
+            }
         }
+        __syncthreads();
+        lap(3);
+        ys = ye;
     }
-    __syncthreads();
-    const int ldc = size + 2;
-    for (int y = threadIdx.x; y < size; y += RT) {
-        const int lo = sink.rowmin[y], hi = sink.rowmax[y];
-        if (hi < lo) continue;
-        unsigned char* prow = img + (size_t)y * size;
-        if (pooled) {
-            int* pc = sink.pcover + sink.rowoff[y];
-            int* pa = sink.parea + sink.rowoff[y];
-            sweep_row([&](int q, int& c, int& a) { c = pc[q]; a = pa[q]; pc[q] = 0; pa[q] = 0; }, lo, hi, prow, size, grey, a8);
-        } else {
-            int* crow = sink.cover + (size_t)y * ldc + lo;
-            int* arow = sink.area + (size_t)y * ldc + lo;
-            sweep_row([&](int q, int& c, int& a) { c = atomicExch(crow + q, 0); a = atomicExch(arow + q, 0); }, lo, hi, prow,
-                      size, grey, a8);
-        }
-        sink.rowmin[y] = 0x7fffffff;
-        sink.rowmax[y] = -1;
+    for (int y = threadIdx.x; y < size; y += RT) { sink.rowmin[y] = 0x7fffffff; sink.rowmax[y] = -1; }
+    if (threadIdx.x == 0) {
+        item->alpha_base = ok ? ab : 0; item->row_base = ok ? rb : 0;
+        item->ymin = ok ? ymin : 0; item->ymax = ok ? ymax : -1;
+        (void)total;
     }
     __syncthreads();
 }
 
-// sin / cos of the sample angles: the same 10 000 values for every line of every image
-__global__ void raster_table_kernel(int ns, double* tab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
-    const double step = (hi_a - lo_a) / (ns - 1);
-    const double al = (i == ns - 1) ? hi_a : lo_a + i * step;       // numpy.linspace
-    tab[3 * i] = al;
-    tab[3 * i + 1] = sin(al);
-    tab[3 * i + 2] = cos(al);
-}
-
-__global__ __launch_bounds__(RT) void raster_kernel(RasterArgs A) {
+__global__ __launch_bounds__(RT) void coverage_kernel(RasterArgs A) {
     __shared__ int s_rowmin[1024], s_rowmax[1024], s_rowoff[1024];
     __shared__ int s_pcover[POOL], s_parea[POOL];
-    __shared__ int s_img, s_total;
+    __shared__ int s_line, s_total[4];
+    __shared__ long long s_base[2];
     const int size = A.size;
-    const int wg = blockIdx.x;
-    V2* simp = A.simp + (size_t)wg * RT * MAXS;
-    V2* verts = A.verts + (size_t)wg * RT * MAXV;
-    int* polys = A.polys + (size_t)wg * RT * (1 + 2 * MAXSUB);
     CellSink sink;
-    sink.cover = A.cover + (size_t)wg * size * (size + 2);
-    sink.area = A.area + (size_t)wg * size * (size + 2);
+    sink.cover = nullptr; sink.area = nullptr;
     sink.rowmin = s_rowmin; sink.rowmax = s_rowmax; sink.rowoff = s_rowoff; sink.size = size;
     sink.pcover = s_pcover; sink.parea = s_parea;
     for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; }
     for (int q = threadIdx.x; q < POOL; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
-    const double width_px = 100.0 / 72.0;                 // 1 pt at 100 dpi (matplotlib 1.5.1's default line width)
+    __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) s_img = atomicAdd(A.queue, 1);
+        if (threadIdx.x == 0) s_line = atomicAdd(A.ctr, 1);
         __syncthreads();
-        const int img_i = s_img;
+        const long long g = s_line;
         __syncthreads();
-        if (img_i >= A.batch) break;
-        unsigned char* img = A.out + (size_t)img_i * size * size;
-        for (int p = threadIdx.x; p < size * size; p += RT) img[p] = 0;
-        const long long lo = A.offsets[img_i], hi = A.offsets[img_i + 1];
-        unsigned* fl = A.flags + img_i;
-        if (threadIdx.x == 0) *fl = 0;
-        __syncthreads();
-        for (long long base = lo; base < hi; base += RT) {
-            const int nb = (int)((hi - base) < RT ? (hi - base) : RT);
-            const long long t_a = wall_clock64();
-            // ---- phase A: thread t -> outline of line base + t ----
-            if ((int)threadIdx.x < nb) {
-                const int t = threadIdx.x;
-                const double la = A.l[3 * (base + t)], lb = A.l[3 * (base + t) + 1], lc = A.l[3 * (base + t) + 2];
-                V2* sp = simp + (size_t)t * MAXS;
-                Outline o;
-                o.v = verts + (size_t)t * MAXV; o.n = 0; o.cap = MAXV; o.flags = fl;
-                int* pt = polys + t * (1 + 2 * MAXSUB);
-                int npoly = 0;
-                Simplifier s;
-                s.init(sp, MAXS, fl);
-                const int ns = A.samples;
-                const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
-                auto flush = [&]() {                      // end of a sub-path: stroke what the simplifier kept
-                    s.end();
-                    if (s.n >= 2) {
-                        const int first = o.n;
-                        stroke_outline(sp, s.n, width_px, o);
-                        if (o.n - first >= 3) {
-                            if (npoly < MAXSUB) { pt[1 + 2 * npoly] = first; pt[2 + 2 * npoly] = o.n - first; ++npoly; }
-                            else atomicOr(fl, FLAG_OVERFLOW);
-                        }
-                    }
-                    s.n = 0;
-                };
-                for (int i = 0; i < ns; ++i) {
-                    const double al = A.tab[3 * i], sa = A.tab[3 * i + 1], ca = A.tab[3 * i + 2];   // (wave-uniform loads)
-                    double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
-                    be *= -1;                                                         // :65
-                    const double x = (al - lo_a) / (hi_a - lo_a) * size;
-                    const double y = size - (be - lo_a) / (hi_a - lo_a) * size;
-                    if (!(x == x) || !(y == y) || isinf(x) || isinf(y)) {             // PathNanRemover: breaks the path
-                        if (s.have) flush();
-                        continue;
-                    }
-                    if (!s.have) s.begin(x, y); else s.feed(x, y);
+        if (g >= A.nlines + 4) break;
+        const int* pt = A.polys + g * (1 + 2 * MAXSUB);
+        const int npoly = pt[0];
+        for (int q = 0; q < MAXSUB; ++q) {
+            Item* item = A.items + g * MAXSUB + q;
+            if (q < npoly) {
+                polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, s_total, s_base, A, item);
+                if (item->ymax < item->ymin && threadIdx.x == 0 && g < A.nlines) {     // dropped: tell the line's image
+                    int lo = 0, hi = A.batch;
+                    const long long gl = A.line0 + g;
+                    while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (A.offsets[A.first_image + mid] <= gl) lo = mid; else hi = mid; }
+                    if (s_total[0] > 0) atomicOr(A.flags + A.first_image + lo, FLAG_OVERFLOW);
                 }
-                if (s.have) flush();
-                pt[0] = npoly;
-            }
-            __syncthreads();
-            const long long t_b = wall_clock64();
-            // ---- phase B: the lines of this batch in order ----
-            for (int t = 0; t < nb; ++t) {
-                const int* pt = polys + t * (1 + 2 * MAXSUB);
-                const int npoly = pt[0];
-                for (int q = 0; q < npoly; ++q)
-                    raster_polygon(verts + (size_t)t * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], 255u, A.a8, sink, img, size, &s_total);
-            }
-            if (threadIdx.x == 0 && blockIdx.x == 0) {     // device time of the two phases (100 MHz ticks), workgroup 0
-                atomicAdd(A.queue + 2, (int)(t_b - t_a));
-                atomicAdd(A.queue + 3, (int)(wall_clock64() - t_b));
+            } else if (threadIdx.x == 0) {
+                item->alpha_base = 0; item->row_base = 0; item->ymin = 0; item->ymax = -1;
             }
         }
-        // ---- the axes' spines over the lines: left, right, bottom, top (matplotlib's drawing order) ----
-        {
-            const double s = (double)size, w_spine = 0.8 * 100.0 / 72.0;
-            V2* sp = simp;                                // the scratch of thread 0's slot serves
-            V2* sv = verts;
-            for (int side = 0; side < 4; ++side) {
-                if (threadIdx.x == 0) {
-                    // two-vertex rectilinear paths, snapped to pixel centres (PathSnapper: floor(v + 0.5) + 0.5 for a stroke
-                    // whose width rounds to an odd number of pixels)
-                    const double x0 = (side == 1) ? s : 0.0, y0 = (side == 3) ? 0.0 : s;
-                    const double x1 = (side == 0) ? 0.0 : s, y1 = (side == 2) ? s : 0.0;
-                    sp[0].x = floor(x0 + 0.5) + 0.5; sp[0].y = floor(y0 + 0.5) + 0.5;
-                    sp[1].x = floor(x1 + 0.5) + 0.5; sp[1].y = floor(y1 + 0.5) + 0.5;
-                    Outline o;
-                    o.v = sv; o.n = 0; o.cap = MAXV; o.flags = fl;
-                    stroke_outline(sp, 2, w_spine, o);
-                    polys[0] = o.n;
-                }
-                __syncthreads();
-                raster_polygon(sv, polys[0], 0u, 255u, sink, img, size, &s_total);
-            }
-        }
-        __syncthreads();
     }
+}
+
+// The blend.  sweep_scanline + render_scanline_aa_solid per pixel: an entry of a row's cell range with area got
+// calculate_alpha((R << 9) - area), one without (no cell, or a cell of a vertical edge on the pixel boundary) lies in the
+// span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
+// coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
+constexpr int BROWS = 64;                                 // image rows per workgroup
+__global__ __launch_bounds__(BROWS) void blend_kernel(RasterArgs A) {
+    extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4]
+    const int size = A.size, ldp = (size + 3) & ~3;
+    const int img_i = blockIdx.y, y = blockIdx.x * BROWS + threadIdx.x;
+    unsigned char* row = s_px + (size_t)threadIdx.x * ldp;
+    for (int x = 0; x < ldp; x += 4) *reinterpret_cast<unsigned*>(row + x) = 0u;
+    const long long lo = A.offsets[A.first_image + img_i] - A.line0, hi = A.offsets[A.first_image + img_i + 1] - A.line0;
+    if (y < size) {
+        auto apply = [&](const Item& it, unsigned grey, unsigned a8) {
+            if (y < it.ymin || y > it.ymax) return;
+            const RowRef r = A.rows[it.row_base + (y - it.ymin)];
+            const unsigned char* al = A.alpha + it.alpha_base + r.off;
+            for (int q0 = 0; q0 < r.len; q0 += 8) {       // eight bytes requested together
+                unsigned av[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[u] = q0 + u < r.len ? al[q0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int x = r.xmin + q0 + u;
+                    if (av[u] && x >= 0 && x < size) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
+                }
+            }
+        };
+        for (long long g = lo; g < hi; ++g)
+            for (int q = 0; q < MAXSUB; ++q) {
+                const Item it = A.items[g * MAXSUB + q];  // (wave-uniform)
+                apply(it, 255u, A.a8);
+            }
+        for (int side = 0; side < 4; ++side) apply(A.items[(A.nlines + side) * MAXSUB], 0u, 255u);
+    }
+    __syncthreads();
+    // coalesced store of the workgroup's rows
+    unsigned char* out = A.out + (size_t)(A.first_image + img_i) * size * size;
+    const int row0 = blockIdx.x * BROWS;
+    for (int r = 0; r < BROWS && row0 + r < size; ++r)
+        for (int x = threadIdx.x; x < size; x += BROWS) out[(size_t)(row0 + r) * size + x] = s_px[(size_t)r * ldp + x];
 }
 
 }  // namespace
@@ -663,19 +746,25 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     if (!h || !l || !offsets || !out || batch < 1 || size < 8 || size > 1024 || !(alpha >= 0.0 && alpha <= 1.0))
         return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster: bad argument (size must be 8..1024, alpha 0..1)");
     VPK_HIP(h, hipSetDevice(h->device));
-    int wgs = h->num_cu < batch ? h->num_cu : batch;
-    // workspace: [offsets | queue + per-image flags | per workgroup: simplified points, outline vertices, polygon tables,
-    //             cover, area]
+    for (int b = 0; b < batch; ++b)
+        if (offsets[b + 1] < offsets[b]) return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster: offsets not monotone");
+    const int samples = 10000;                            // sphere_mapping.py:40
+    // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
+    const long long max_lines = 49152;
+    const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 + MAXSUB * sizeof(Item) +
+                            16384 + (size_t)(size + 8) * sizeof(RowRef);
+    long long chunk_lines = 0;
+    for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
+        b1 = b0 + 1;
+        while (b1 < batch && offsets[b1 + 1] - offsets[b0] <= max_lines) ++b1;
+        chunk_lines = std::max<long long>(chunk_lines, offsets[b1] - offsets[b0]);
+    }
     const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
-    const int samples = 10000;                            // sphere_mapping.py:40
     const size_t tb = vpk::em_align((size_t)samples * 3 * 8, 256);
-    const size_t simp_b = (size_t)RT * MAXS * sizeof(V2), vert_b = (size_t)RT * MAXV * sizeof(V2);
-    const size_t poly_b = vpk::em_align((size_t)RT * (1 + 2 * MAXSUB) * 4, 256);
-    const size_t acc_b = vpk::em_align((size_t)size * (size + 2) * 4, 256);
-    const size_t per_wg = simp_b + vert_b + poly_b + 2 * acc_b;
-    while (wgs > 1 && ob + fb + tb + (size_t)wgs * per_wg > h->total_mem / 4) wgs /= 2;
-    int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, ob + fb + tb + (size_t)wgs * per_wg, "hipMalloc(raster workspace)");
+    const size_t nl = (size_t)chunk_lines + 4;
+    const size_t need = ob + fb + tb + nl * per_line + 4096;
+    int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
     char* base = (char*)h->raster_hdr;
     // offsets [host] -> device: caller-owned pageable memory, so the copy is waited for
@@ -683,28 +772,68 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     VPK_HIP(h, hipMemcpyAsync(base, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, h->stream));
     VPK_HIP(h, hipStreamSynchronize(h->stream));
     VPK_HIP(h, hipMemsetAsync(base + ob, 0, fb, h->stream));
-    RasterArgs A;
     hipLaunchKernelGGL(raster_table_kernel, dim3((samples + 255) / 256), dim3(256), 0, h->stream, samples, (double*)(base + ob + fb));
-    A.l = l; A.offsets = (const long long*)base; A.tab = (const double*)(base + ob + fb); A.batch = batch; A.size = size;
-    A.samples = samples;
+    RasterArgs A;
+    A.l = l; A.offsets = (const long long*)base; A.tab = (const double*)(base + ob + fb); A.size = size; A.samples = samples;
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround
-    A.out = out; A.queue = (int*)(base + ob); A.flags = (unsigned*)(base + ob + 256);
+    A.out = out; A.ctr = (int*)(base + ob); A.bump = (unsigned long long*)(base + ob + 64); A.flags = (unsigned*)(base + ob + 256);
     char* p = base + ob + fb + tb;
-    A.simp = (V2*)p; p += (size_t)wgs * simp_b;
-    A.verts = (V2*)p; p += (size_t)wgs * vert_b;
-    A.polys = (int*)p; p += (size_t)wgs * poly_b;
-    A.cover = (int*)p; p += (size_t)wgs * acc_b;
-    A.area = (int*)p;
-    VPK_HIP(h, hipMemsetAsync(A.cover, 0, 2 * (size_t)wgs * acc_b, h->stream));    // the sweeps leave them zero again
-    hipLaunchKernelGGL(raster_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
-    VPK_HIP(h, hipGetLastError());
-    if (getenv("VPK_RASTER_TIMES")) {                     // development: where workgroup 0 spent its time
-        int q[8];
-        VPK_HIP(h, hipStreamSynchronize(h->stream));
-        VPK_HIP(h, hipMemcpy(q, A.queue, sizeof(q), hipMemcpyDeviceToHost));
-        fprintf(stderr, "vpk_sphere_raster: workgroup 0: outlines %.2f ms, cells + blending %.2f ms (%d images on %d workgroups)\n",
-                q[2] * 1e-5, q[3] * 1e-5, batch, wgs);
+    A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
+    A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
+    A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
+    A.items = (Item*)p; p += vpk::em_align(nl * MAXSUB * sizeof(Item), 256);
+    A.alpha = (unsigned char*)p; A.alpha_cap = nl * 16384; p += vpk::em_align(nl * 16384, 256);
+    A.rows = (RowRef*)p; A.rows_cap = nl * (size_t)(size + 8);
+    if (!h->raster_ready) {
+        VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(blend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       BROWS * 1024));
+        h->raster_ready = true;
     }
+    const int ldp = (size + 3) & ~3;
+    for (int b0 = 0, b1; b0 < batch; b0 = b1) {
+        b1 = b0 + 1;
+        while (b1 < batch && offsets[b1 + 1] - offsets[b0] <= max_lines) ++b1;
+        A.first_image = b0; A.batch = b1 - b0; A.line0 = offsets[b0]; A.nlines = offsets[b1] - offsets[b0];
+        VPK_HIP(h, hipMemsetAsync(base + ob, 0, 256, h->stream));          // queue + bump counters of this chunk
+        const long long nt = A.nlines + 4;
+        const bool times = getenv("VPK_RASTER_TIMES") != nullptr;      // development: per-kernel device time
+        hipEvent_t ev[4] = {};
+        if (times) for (int q = 0; q < 4; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
+        if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
+        hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
+        if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
+        const int wgs = (int)std::min<long long>(nt, (long long)h->num_cu);
+        hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
+        if (times) VPK_HIP(h, hipEventRecord(ev[2], h->stream));
+        hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS), (size_t)BROWS * ldp, h->stream, A);
+        if (times) VPK_HIP(h, hipEventRecord(ev[3], h->stream));
+        VPK_HIP(h, hipGetLastError());
+        if (times) {
+            float ms[3];
+            VPK_HIP(h, hipEventSynchronize(ev[3]));
+            for (int q = 0; q < 3; ++q) VPK_HIP(h, hipEventElapsedTime(&ms[q], ev[q], ev[q + 1]));
+            unsigned long long bump[2];
+            VPK_HIP(h, hipMemcpy(bump, A.bump, 16, hipMemcpyDeviceToHost));
+            int dbg[16];
+            VPK_HIP(h, hipMemcpy(dbg, A.ctr, sizeof(dbg), hipMemcpyDeviceToHost));
+            fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
+                    "and %.0f rows per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
+                    A.nlines, ms[0], ms[1], ms[2], (double)bump[0] / nt, (double)bump[1] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
+                    dbg[11] * 1e-5);
+            for (int q = 0; q < 4; ++q) (void)hipEventDestroy(ev[q]);
+        }
+    }
+    return VPK_OK;
+}
+
+/* per-image flags of the last vpk_sphere_raster call on this handle (bit 0: a line's outline or coverage exceeded the
+ * kernel's buffers and was truncated / dropped); waits for the call to finish */
+int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out) {
+    if (!h || !flags_out || batch < 1 || !h->raster_hdr) return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster_flags: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    VPK_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
+    VPK_HIP(h, hipMemcpy(flags_out, (char*)h->raster_hdr + ob + 256, (size_t)batch * 4, hipMemcpyDeviceToHost));
     return VPK_OK;
 }
 
