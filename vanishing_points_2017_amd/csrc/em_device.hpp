@@ -944,16 +944,32 @@ VPK_DEV int rs_panel_doubles(int jch, int W) { return 8 * rs_sstride(jch, W) + 3
 VPK_DEV int rs_row(int n, int jch, int S, int W) { const int sl = n / jch; return sl * S + (n - sl * jch) * W; }
 // Which smoother the next smooth() takes for M hypotheses -- decided in ONE place because the E-step writes the panel in
 // that smoother's layout.  0: none in LDS (wsrc in HBM), 1: smooth_full's [line][W], 2: smooth_rows' sliced layout.
+// VPs per pass of smooth_rows when the whole panel does not fit: the widest multiple of 8 (<= 32) whose sliced panel and
+// the reduction scratch fit the LDS budget; 0 = not even 8
+VPK_DEV int rs_wfit(const EmCtx& c) {
+    const int jch = rs_jchunk(c.N);
+    for (int w = 32; w >= MT; w -= MT)
+        if (rs_panel_doubles(jch, w) + 8 * RS_RED_DOUBLES <= c.wt_doubles) return w;
+    return 0;
+}
+// Which smoother the next smooth() takes for M hypotheses -- decided in ONE place because the E-step writes the panel in
+// that smoother's layout.  0: none in LDS (wsrc in HBM; smooth_full in passes or smooth_blocks), 1: smooth_full's
+// [line][W], 2: smooth_rows' sliced layout, 3: wsrc in HBM, smooth_rows in passes of rs_wfit() VPs.
 VPK_DEV int smooth_plan(const EmCtx& c, int M) {
     const int N = c.N;
-    if (!c.prm.use_weights || M <= 0 || M > 32) return 0;
+    if (!c.prm.use_weights || M <= 0) return 0;
     const int Wp = ((M + MT - 1) / MT) * MT;
-    if (WAVE == 64 && nwaves() == 8 && c.smoother == 0) {
-        const int colw = N > WAVE ? 2 * WAVE : WAVE;               // smooth_full's column groups: when they divide evenly
-        const bool direct = (((N + colw - 1) / colw) % 8) == 0;    // among the waves it sums ALL rows in one chain
-        if (!direct && rs_panel_doubles(rs_jchunk(N), Wp) + 8 * RS_RED_DOUBLES <= c.wt_doubles) return 2;
+    const bool rows_ok = WAVE == 64 && nwaves() == 8 && c.smoother == 0;
+    const int colw = N > WAVE ? 2 * WAVE : WAVE;                   // smooth_full's column groups: when they divide evenly
+    const bool direct = (((N + colw - 1) / colw) % 8) == 0;        // among the waves it sums ALL rows in one chain
+    if (M <= 32) {
+        if (rows_ok && !direct && rs_panel_doubles(rs_jchunk(N), Wp) + 8 * RS_RED_DOUBLES <= c.wt_doubles) return 2;
+        if ((long long)N * Wp <= c.wt_doubles) return 1;
     }
-    return ((long long)N * Wp <= c.wt_doubles) ? 1 : 0;
+    // In passes: smooth_rows keeps smooth_full's eight-slice order, so it may stand in wherever smooth_full would run
+    // (a panel of at least 8 VPs fits the OLD layout: wfit >= 8), never for smooth_blocks (one chain per column).
+    if (rows_ok && !direct && (c.wt_doubles / N) / MT >= 1 && rs_wfit(c) >= MT) return 3;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1007,7 +1023,7 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     // Wp = M rounded to the VP tile) as well as to HBM, and smooth_full skips its staging pass.
     const int Wp = ((M + MT - 1) / MT) * MT;
     const int plan = smooth_plan(c, M);                      // 1: [line][Wp] for smooth_full, 2: slice by slice for smooth_rows
-    const bool panel = plan != 0;
+    const bool panel = plan == 1 || plan == 2;
     const int rs_jch = rs_jchunk(N), rs_S = rs_sstride(rs_jch, Wp);
     double* wt = WT();
     // one thread per line; the VP loop is unrolled four deep with the four sqrt/div/exp chains written
@@ -1362,19 +1378,21 @@ VPK_DEVFN void zero_tail_rows(EmCtx& c) {
 // slice's row ONCE and the FMAs take them through DPP row_newbcast (fmac8_row_bcast).  Per lane and row of a slice:
 // one 8-byte lsim load (a row of 16 lanes = one 128-byte line), one or two 8-byte LDS reads, W FMAs.
 template <int NT>
-VPK_DEVFN void smooth_rows(EmCtx& c) {
+VPK_DEVFN void smooth_rows(EmCtx& c, int m0) {
     Shared& sh = SH();
     constexpr int W = NT * MT;
     constexpr int UNR = 4;                          // rows per load batch and slice; two batches are in flight
-    const int N = uniform_int(c.N), M = uniform_int(sh.M);
+    const int N = uniform_int(c.N);
+    m0 = uniform_int(m0);
+    const int M = uniform_int(sh.M) - m0 < W ? uniform_int(sh.M) - m0 : W;    // VPs of this pass: [m0, m0 + M)
     const double bias = c.prm.wbias;
     double* wt = WT();
     long long tq_ = clock_ticks();
     const int jch = rs_jchunk(N), S = rs_sstride(jch, W);
-    if (sh.ibuf[5] != RS_PANEL_FLAG + W) {          // no E-step left the panel in place (vpk_weight_matrix): stage it
+    if (m0 != 0 || sh.ibuf[5] != RS_PANEL_FLAG + W) {   // not left in place by the E-step (passes; vpk_weight_matrix): stage it
         for (int p = tid(); p < N * W; p += nthreads()) {
             const int j = p / W, m = p - j * W;
-            wt[rs_row(j, jch, S, W) + m] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m] : 0.0;
+            wt[rs_row(j, jch, S, W) + m] = (m < M) ? c.wsrc[(size_t)j * c.mcap + m0 + m] : 0.0;
         }
         for (int p = N * W + tid(); p < 8 * jch * W; p += nthreads()) {   // rows a short or empty slice does not have
             const int j = p / W;
@@ -1494,7 +1512,7 @@ VPK_DEVFN void smooth_rows(EmCtx& c) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sum += rr_[q];                                      // fixed order
                 const int t = t0 + d;
-                if (t < M && k < N) wout[(size_t)t * ldn + k] = (wk[t] + blw * sum) / dn;
+                if (t < M && k < N) wout[(size_t)(m0 + t) * ldn + k] = (wk[t] + blw * sum) / dn;
                 wave_lds_order();
             }
         }
@@ -1527,11 +1545,16 @@ VPK_DEVFN void smooth_dispatch(EmCtx& c) {
         return;
     }
     if (M == 0) return;
-    if (WAVE == 64 && (sh.ibuf[5] >= RS_PANEL_FLAG || smooth_plan(c, M) == 2)) {   // (an E-step's panel decides; none: the plan)
-        if (M <= 8) smooth_rows<1>(c);
-        else if (M <= 16) smooth_rows<2>(c);
-        else if (M <= 24) smooth_rows<3>(c);
-        else smooth_rows<4>(c);
+    const int plan = smooth_plan(c, M);
+    if (WAVE == 64 && (sh.ibuf[5] >= RS_PANEL_FLAG || plan == 2 || plan == 3)) {   // (an E-step's panel decides; none: the plan)
+        const int wpass = plan == 3 ? rs_wfit(c) : 32;      // VPs per pass
+        for (int m0 = 0; m0 < M; m0 += wpass) {
+            const int mm = (M - m0) < wpass ? (M - m0) : wpass;
+            if (mm <= 8) smooth_rows<1>(c, m0);
+            else if (mm <= 16) smooth_rows<2>(c, m0);
+            else if (mm <= 24) smooth_rows<3>(c, m0);
+            else smooth_rows<4>(c, m0);
+        }
         return;
     }
     // single-pass kernel on as many VPs as the LDS panel holds (N x wfit doubles, wfit a multiple of the VP
