@@ -2,8 +2,10 @@
 
     python oracle/check_agg_raster.py [n_lines]
 
-Renders seeded lines one at a time and as whole sets with the reference's own sphere_line_plot (sphere_mapping.py:36-72,
-loaded through oracle/ref_shim.py) and with the restatement, and reports the pixels that differ."""
+Renders seeded lines -- ordinary scene lines, near-vertical / flat / far-off / steep curves, degenerate ones (b = 0, all
+zero) -- one at a time and as whole sets (also at size 250 and alpha 0.5) with the reference's own sphere_line_plot
+(sphere_mapping.py:36-72, loaded through oracle/ref_shim.py) and with the restatement, and reports the pixels that
+differ.  Last run (matplotlib 3.10.8): 0 of 200 single lines, 0 pixels of the three sets."""
 import sys
 import time
 
@@ -24,25 +26,34 @@ def main():
     matplotlib.use("Agg")
     sm = ref_shim.load_reference(["sphere_mapping"])["sphere_mapping"]
     from vanishing_points_2017_amd import synth
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    sc = synth.make_scene(4242, max(n, 40), 3, raster=None)
-    bad_lines = 0
-    for i in range(n):
-        want = mpl_raster(sm, sc["l"][i:i + 1])
-        got = agg_raster.raster(sc["l"][i:i + 1])
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    rs = np.random.RandomState(5)
+    lines = list(synth.make_scene(4242, 40, 3, raster=None)["l"])
+    for k in range(n):                       # ordinary, near-vertical, flat, far-off and steep curves
+        scale = [(1, 1, 1), (1, 1e-3, 1), (1e-3, 1, 1e-3), (1, 1, 30), (10, 0.1, 0.1)][k % 5]
+        lines.append(rs.randn(3) * np.array(scale))
+    lines += [np.array(o, dtype=float) for o in ([1, 0.0, 0.3], [1, 1e-9, 0.3], [0.0, 1.0, 0.0], [0.3, -1e-6, -2.0], [1, 1, 1e6],
+                                                 [5, 0.01, 0.01], [0, 0, 1.0], [0.0, 0.0, 0.0], [1, -1, 0], [0, 1, 1])]
+    bad = 0
+    for i, l in enumerate(lines):
+        want = mpl_raster(sm, l[None])
+        got = agg_raster.raster(l[None])
         d = np.abs(want.astype(int) - got.astype(int))
         if d.max() > 0:
-            bad_lines += 1
-            ys, xs = np.nonzero(d)
-            print("line %d: %d pixels differ (max %d), e.g. (y=%d, x=%d): mpl %d, restatement %d; nonzero %d vs %d" % (
-                i, len(ys), d.max(), ys[0], xs[0], want[ys[0], xs[0]], got[ys[0], xs[0]], (want > 0).sum(), (got > 0).sum()))
-    print("single lines: %d of %d differ" % (bad_lines, n))
-    t = time.time()
-    want = mpl_raster(sm, sc["l"][:40])
-    t1 = time.time()
-    got = agg_raster.raster(sc["l"][:40])
-    d = np.abs(want.astype(int) - got.astype(int))
-    print("40 lines at once: %d pixels differ (max %d); matplotlib %.1f s, restatement %.1f s" % ((d > 0).sum(), d.max(), t1 - t, time.time() - t1))
+            bad += 1
+            print("line %d %s: %d pixels differ (max %d)" % (i, l, (d > 0).sum(), d.max()))
+    print("single lines: %d of %d differ" % (bad, len(lines)))
+    L = np.array(lines)
+    import matplotlib as mpl
+    for size, alpha in ((500, 0.1), (250, 0.1), (500, 0.5)):
+        mpl.rcParams["lines.linewidth"] = 1.0
+        t = time.time()
+        want = sm.sphere_line_plot(L.copy(), size, alpha=alpha, f=1.0)
+        t1 = time.time()
+        got = agg_raster.raster(L, size=size, alpha=alpha)
+        d = np.abs(want.astype(int) - got.astype(int))
+        print("%d lines at once, size %d, alpha %.1f: %d pixels differ (max %d); matplotlib %.1f s, restatement %.1f s" % (
+            len(L), size, alpha, (d > 0).sum(), d.max(), t1 - t, time.time() - t1))
 
 
 if __name__ == "__main__":
