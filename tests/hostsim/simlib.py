@@ -145,3 +145,37 @@ def mstep(l, w):
     D = ctypes.c_double
     lib().sim_mstep(n, m, _p(l, D), _p(w, D), _p(vp, D))
     return vp
+
+
+# ---- the rasteriser's arithmetic (csrc/raster_device.hpp) -----------------------------------------------------------------
+RASTER_SO = os.path.join(BUILD, "libvpk_hostsim_raster.so")
+RASTER_SRC = [os.path.join(HERE, "sim_raster.cpp"),
+              os.path.join(HERE, "..", "..", "vanishing_points_2017_amd", "csrc", "raster_device.hpp")]
+_raster_lib = None
+
+
+def raster_lib():
+    global _raster_lib
+    if _raster_lib is not None:
+        return _raster_lib
+    os.makedirs(BUILD, exist_ok=True)
+    stale = (not os.path.exists(RASTER_SO)) or any(os.path.getmtime(s) > os.path.getmtime(RASTER_SO) for s in RASTER_SRC)
+    if stale:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", RASTER_SRC[0], "-o", RASTER_SO])
+    _raster_lib = ctypes.CDLL(RASTER_SO)
+    _raster_lib.sim_raster.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.POINTER(ctypes.c_uint8)]
+    _raster_lib.sim_edge_shares.argtypes = [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_int]
+    return _raster_lib
+
+
+def sim_raster(lines, size=250, alpha=0.1):
+    """The product's stroke / cell / blend arithmetic run serially on the host: uint8 [size, size] and the overflow flags."""
+    l = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((size, size), dtype=np.uint8)
+    flags = raster_lib().sim_raster(_p(l, ctypes.c_double), l.shape[0], size, float(alpha), _p(out, ctypes.c_uint8))
+    return out, flags
+
+
+def sim_edge_shares(x1, y1, x2, y2, size, k):
+    return raster_lib().sim_edge_shares(x1, y1, x2, y2, size, k)

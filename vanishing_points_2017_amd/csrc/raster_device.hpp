@@ -1,0 +1,430 @@
+// raster_device.hpp -- the arithmetic of the Agg-faithful sphere rasteriser (see vpk_raster.hip for the pipeline and its
+// sources): PathSimplifier, conv_stroke, the cell walker with the clip box, calculate_alpha and the plain blender, as
+// plain structs and functions.  Compiled by hipcc into the kernels of vpk_raster.hip and -- unmodified, with RDEV empty and
+// the atomics plain -- by g++ into the test-only host build tests/hostsim/sim_raster.cpp, so that the CPU suite runs the
+// product's own code against the reference's rasters.
+#ifndef VPK_RASTER_DEVICE_HPP_
+#define VPK_RASTER_DEVICE_HPP_
+
+#include <math.h>
+
+#ifdef __HIPCC__
+#define RDEV __device__
+#define RDEV_INLINE __device__ __forceinline__
+#define RDEV_NOINLINE __device__ __noinline__
+#define RS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define RS_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define RS_ATOMIC_MAX(p, v) atomicMax((p), (v))
+#else
+#define RDEV
+#define RDEV_INLINE inline
+#define RDEV_NOINLINE
+#define RS_ATOMIC_ADD(p, v) (*(p) += (v))
+#define RS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define RS_ATOMIC_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+#endif
+
+namespace vpk_raster {
+
+constexpr int RT = 512;                 // threads per workgroup
+constexpr int MAXS = 384;               // simplified points kept per line (typical: 30-100)
+constexpr int MAXV = 1024;              // outline vertices per line (typical: 60-200)
+constexpr int MAXSUB = 4;               // sub-paths per line (a NaN sample breaks the path)
+constexpr int SUB = 256, SHIFT = 8;     // agg::poly_subpixel_scale / _shift
+constexpr double PI_D = 3.14159265358979323846;
+constexpr unsigned FLAG_OVERFLOW = 1u;  // a line produced more points / vertices / sub-paths than the buffers hold
+
+struct V2 { double x, y; };
+
+RDEV_INLINE int iround(double v) { return (int)(v < 0.0 ? v - 0.5 : v + 0.5); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// PathSimplifier (matplotlib src/path_converters.h) as a push machine: feed() the vertices, it emit()s the kept ones
+// ---------------------------------------------------------------------------------------------------------------
+struct Simplifier {
+    V2* out; int n, cap; unsigned* flags;
+    double thr2;
+    double lastx, lasty, origdx, origdy, orig_norm2, fwd_max, bwd_max, nextx, nexty, nbx, nby, startx, starty;
+    bool last_fwd, last_bwd, clipped, have;
+    RDEV void init(V2* o, int capacity, unsigned* fl) {
+        out = o; n = 0; cap = capacity; flags = fl;
+        thr2 = (1.0 / 9.0) * (1.0 / 9.0);
+        have = false;
+    }
+    RDEV void emit(double x, double y) {
+        if (n < cap) { out[n].x = x; out[n].y = y; ++n; } else { *flags |= FLAG_OVERFLOW; }
+    }
+    RDEV void begin(double x, double y) {      // move_to
+        lastx = x; lasty = y; orig_norm2 = 0.0; bwd_max = 0.0; clipped = true; have = true;
+        origdx = origdy = fwd_max = nextx = nexty = nbx = nby = startx = starty = 0.0;
+        last_fwd = last_bwd = false;
+    }
+    RDEV void feed(double x, double y) {       // line_to
+        if (orig_norm2 == 0.0) {
+            if (clipped) { emit(lastx, lasty); clipped = false; }
+            origdx = x - lastx; origdy = y - lasty;
+            orig_norm2 = origdx * origdx + origdy * origdy;
+            fwd_max = orig_norm2; bwd_max = 0.0; last_fwd = true; last_bwd = false;
+            startx = lastx; starty = lasty;
+            nextx = lastx = x; nexty = lasty = y;
+            return;
+        }
+        const double totdx = x - startx, totdy = y - starty;
+        const double totdot = origdx * totdx + origdy * totdy;
+        const double paradx = totdot * origdx / orig_norm2, parady = totdot * origdy / orig_norm2;
+        const double perpdx = totdx - paradx, perpdy = totdy - parady;
+        const double perp2 = perpdx * perpdx + perpdy * perpdy;
+        if (perp2 < thr2) {
+            const double para2 = paradx * paradx + parady * parady;
+            last_fwd = last_bwd = false;
+            if (totdot > 0.0) {
+                if (para2 > fwd_max) { last_fwd = true; fwd_max = para2; nextx = x; nexty = y; }
+            } else {
+                if (para2 > bwd_max) { last_bwd = true; bwd_max = para2; nbx = x; nby = y; }
+            }
+            lastx = x; lasty = y;
+            return;
+        }
+        // _push: the run ends here
+        double ex, ey;                                  // the last point written
+        if (bwd_max > 0.0) {
+            if (last_fwd) { emit(nbx, nby); emit(nextx, nexty); ex = nextx; ey = nexty; }
+            else { emit(nextx, nexty); emit(nbx, nby); ex = nbx; ey = nby; }
+        } else { emit(nextx, nexty); ex = nextx; ey = nexty; }
+        if (clipped || (!last_fwd && !last_bwd)) { emit(lastx, lasty); ex = lastx; ey = lasty; }
+        origdx = x - lastx; origdy = y - lasty;
+        orig_norm2 = origdx * origdx + origdy * origdy;
+        fwd_max = orig_norm2; last_fwd = true;
+        startx = ex; starty = ey;
+        lastx = nextx = x; lasty = nexty = y;
+        bwd_max = 0.0; last_bwd = false; clipped = false;
+    }
+    RDEV void end() {                           // path_cmd_stop
+        if (!have) return;
+        if (orig_norm2 != 0.0) {
+            emit(nextx, nexty);
+            if (bwd_max > 0.0) emit(nbx, nby);
+        }
+        emit(lastx, lasty);
+        have = false;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// agg::conv_stroke (agg_vcgen_stroke.cpp + agg_math_stroke.h): square caps, round joins, inner miter, scale 1
+// ---------------------------------------------------------------------------------------------------------------
+struct Outline {
+    V2* v; int n, cap; unsigned* flags;
+    RDEV void add(double x, double y) {
+        if (n < cap) { v[n].x = x; v[n].y = y; ++n; } else { *flags |= FLAG_OVERFLOW; }
+    }
+};
+
+RDEV bool calc_intersection(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy,
+                                  double* x, double* y) {
+    const double num = (ay - cy) * (dx - cx) - (ax - cx) * (dy - cy);
+    const double den = (bx - ax) * (dy - cy) - (by - ay) * (dx - cx);
+    if (fabs(den) < 1.0e-30) return false;
+    const double r = num / den;
+    *x = ax + r * (bx - ax);
+    *y = ay + r * (by - ay);
+    return true;
+}
+RDEV_INLINE double cross3(double x1, double y1, double x2, double y2, double x, double y) {
+    return (x - x2) * (y2 - y1) - (y - y2) * (x2 - x1);
+}
+
+struct Stroker {
+    double w, w_abs, w_eps;
+    RDEV void init(double width) { w = width * 0.5; w_abs = fabs(w); w_eps = w / 1024.0; }
+    RDEV void cap(Outline& o, const V2& v0, const V2& v1, double len) const {
+        double dx1 = (v1.y - v0.y) / len, dy1 = (v1.x - v0.x) / len;
+        dx1 *= w; dy1 *= w;
+        const double dx2 = dy1, dy2 = dx1;               // square cap
+        o.add(v0.x - dx1 - dx2, v0.y + dy1 - dy2);
+        o.add(v0.x + dx1 - dx2, v0.y - dy1 - dy2);
+    }
+    RDEV void miter(Outline& o, const V2& v0, const V2& v1, const V2& v2, double dx1, double dy1, double dx2,
+                          double dy2, double mlimit) const {
+        const double lim = w_abs * mlimit;
+        bool exceeded = true;
+        double xi, yi;
+        if (calc_intersection(v0.x + dx1, v0.y - dy1, v1.x + dx1, v1.y - dy1, v1.x + dx2, v1.y - dy2, v2.x + dx2,
+                              v2.y - dy2, &xi, &yi)) {
+            const double di = sqrt((xi - v1.x) * (xi - v1.x) + (yi - v1.y) * (yi - v1.y));
+            if (di <= lim) { o.add(xi, yi); exceeded = false; }
+        } else {
+            const double x2 = v1.x + dx1, y2 = v1.y - dy1;
+            if ((cross3(v0.x, v0.y, v1.x, v1.y, x2, y2) < 0.0) == (cross3(v1.x, v1.y, v2.x, v2.y, x2, y2) < 0.0)) {
+                o.add(v1.x + dx1, v1.y - dy1);
+                exceeded = false;
+            }
+        }
+        if (exceeded) {                                  // miter_join_revert
+            o.add(v1.x + dx1, v1.y - dy1);
+            o.add(v1.x + dx2, v1.y - dy2);
+        }
+    }
+    RDEV void arc(Outline& o, double x, double y, double dx1, double dy1, double dx2, double dy2) const {
+        double a1 = atan2(dy1, dx1), a2 = atan2(dy2, dx2);
+        double da = acos(w_abs / (w_abs + 0.125)) * 2;
+        o.add(x + dx1, y + dy1);
+        if (a1 > a2) a2 += 2 * PI_D;
+        const int n = (int)((a2 - a1) / da);
+        da = (a2 - a1) / (n + 1);
+        a1 += da;
+        for (int i = 0; i < n; ++i) {
+            o.add(x + cos(a1) * w, y + sin(a1) * w);
+            a1 += da;
+        }
+        o.add(x + dx2, y + dy2);
+    }
+    RDEV void join(Outline& o, const V2& v0, const V2& v1, const V2& v2, double len1, double len2) const {
+        const double dx1 = w * (v1.y - v0.y) / len1, dy1 = w * (v1.x - v0.x) / len1;
+        const double dx2 = w * (v2.y - v1.y) / len2, dy2 = w * (v2.x - v1.x) / len2;
+        const double cp = cross3(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+        if (cp != 0 && (cp > 0) == (w > 0)) {            // inner join: inner_miter
+            double limit = (len1 < len2 ? len1 : len2) / w_abs;
+            if (limit < 1.01) limit = 1.01;
+            miter(o, v0, v1, v2, dx1, dy1, dx2, dy2, limit);
+            return;
+        }
+        double dx = (dx1 + dx2) / 2, dy = (dy1 + dy2) / 2;
+        const double dbevel = sqrt(dx * dx + dy * dy);
+        if ((w_abs - dbevel) < w_eps) {                  // no visible bevel: one point
+            if (calc_intersection(v0.x + dx1, v0.y - dy1, v1.x + dx1, v1.y - dy1, v1.x + dx2, v1.y - dy2, v2.x + dx2,
+                                  v2.y - dy2, &dx, &dy))
+                o.add(dx, dy);
+            else
+                o.add(v1.x + dx1, v1.y - dy1);
+            return;
+        }
+        arc(o, v1.x, v1.y, dx1, -dy1, dx2, -dy2);        // round join
+    }
+};
+
+// vcgen_stroke on an open polyline p[0..n): vertex_sequence<vertex_dist> drops a vertex that coincides with its
+// predecessor (in place), then cap, joins forward, cap, joins backward.  Returns the number of outline vertices added.
+RDEV void stroke_outline(V2* p, int n, double width, Outline& o) {
+    int m = 0;                                           // compacted length
+    for (int i = 0; i < n; ++i) {
+        if (m > 1) {
+            const double d = sqrt((p[m - 1].x - p[m - 2].x) * (p[m - 1].x - p[m - 2].x) +
+                                  (p[m - 1].y - p[m - 2].y) * (p[m - 1].y - p[m - 2].y));
+            if (!(d > 1e-14)) --m;
+        }
+        p[m++] = p[i];
+    }
+    while (m > 1) {                                      // close(false): trailing coincident vertices go
+        const double d = sqrt((p[m - 1].x - p[m - 2].x) * (p[m - 1].x - p[m - 2].x) +
+                              (p[m - 1].y - p[m - 2].y) * (p[m - 1].y - p[m - 2].y));
+        if (d > 1e-14) break;
+        --m;
+    }
+    if (m < 2) return;
+    Stroker st;
+    st.init(width);
+    auto dist = [&](int a, int b) {
+        return sqrt((p[b].x - p[a].x) * (p[b].x - p[a].x) + (p[b].y - p[a].y) * (p[b].y - p[a].y));
+    };
+    st.cap(o, p[0], p[1], dist(0, 1));
+    for (int i = 1; i < m - 1; ++i) st.join(o, p[i - 1], p[i], p[i + 1], dist(i - 1, i), dist(i, i + 1));
+    st.cap(o, p[m - 1], p[m - 2], dist(m - 2, m - 1));
+    for (int i = m - 2; i > 0; --i) st.join(o, p[i + 1], p[i], p[i - 1], dist(i, i + 1), dist(i - 1, i));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rasterizer_cells_aa::line / render_hline: cells of one edge, added with integer atomics
+// ---------------------------------------------------------------------------------------------------------------
+// Where the cells of the line being drawn live.  Default: an LDS pool -- a stroke touches a few thousand pixels, so the
+// polygon's edges are walked twice: pass 1 (BOUNDS) only records every row's first / last cell, a prefix sum over the rows
+// packs the rows' cell ranges into the pool, pass 2 (POOL) adds the cells there with LDS atomics.  A polygon whose ranges
+// do not fit the pool (GLOBAL) uses image-sized accumulators in HBM / L2 with global atomics instead.
+constexpr int POOL = 12288;             // cells (cover, area) of one polygon in LDS: 96 KB
+enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
+
+struct CellSink {
+    int* cover; int* area;              // GLOBAL: [size][size + 2], x shifted by one (cells at x = -1 and x = size exist)
+    int* pcover; int* parea;            // POOLED: LDS pool
+    int* rowmin; int* rowmax; int* rowoff;   // LDS, per row
+    int size;
+    int blo, bhi, boff;                 // POOLED: the band of rows [blo, bhi) the pool holds now; pool index = rowoff - boff
+    template <int MODE> RDEV_INLINE void add(int ex, int ey, int c, int a) const {
+        if ((c | a) == 0) return;
+        if (ey < 0 || ey >= size || ex < -1 || ex > size) return;
+        if (MODE == BOUNDS) {
+            RS_ATOMIC_MIN(rowmin + ey, ex + 1);
+            RS_ATOMIC_MAX(rowmax + ey, ex + 1);
+        } else if (MODE == POOLED) {
+            if (ey < blo || ey >= bhi) return;
+            const int idx = rowoff[ey] - boff + (ex + 1 - rowmin[ey]);
+            if (c) RS_ATOMIC_ADD(pcover + idx, c);
+            if (a) RS_ATOMIC_ADD(parea + idx, a);
+        } else {
+            const size_t idx = (size_t)ey * (size + 2) + ex + 1;
+            if (c) RS_ATOMIC_ADD(cover + idx, c);
+            if (a) RS_ATOMIC_ADD(area + idx, a);
+        }
+    }
+    template <int MODE> RDEV_NOINLINE void hline(int ey, int x1, int y1, int x2, int y2) const {
+        int ex1 = x1 >> SHIFT;
+        const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
+        if (y1 == y2) return;
+        if (ex1 == ex2) {
+            const int delta = y2 - y1;
+            add<MODE>(ex1, ey, delta, (fx1 + fx2) * delta);
+            return;
+        }
+        int p = (SUB - fx1) * (y2 - y1), first = SUB, incr = 1, dx = x2 - x1;
+        if (dx < 0) { p = fx1 * (y2 - y1); first = 0; incr = -1; dx = -dx; }
+        int delta = p / dx, mod = p % dx;
+        if (mod < 0) { --delta; mod += dx; }
+        add<MODE>(ex1, ey, delta, (fx1 + first) * delta);
+        ex1 += incr;
+        y1 += delta;
+        if (ex1 != ex2) {
+            p = SUB * (y2 - y1 + delta);
+            int lift = p / dx, rem = p % dx;
+            if (rem < 0) { --lift; rem += dx; }
+            mod -= dx;
+            while (ex1 != ex2) {
+                delta = lift;
+                mod += rem;
+                if (mod >= 0) { mod -= dx; ++delta; }
+                add<MODE>(ex1, ey, delta, SUB * delta);
+                y1 += delta;
+                ex1 += incr;
+            }
+        }
+        delta = y2 - y1;
+        add<MODE>(ex1, ey, delta, (fx2 + SUB - first) * delta);
+    }
+    // rasterizer_cells_aa::line for the rows [part * nrows / nparts, (part + 1) * nrows / nparts) of the edge only: a long
+    // edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
+    // the running remainder wraps); after k middle rows the remainder has wrapped floor((mod0 + k rem) / dy) times, so
+    // any row's (x_from, x_to) follows in closed form and a thread can start in the middle of the edge with exactly the
+    // state the sequential walk has there.
+    template <int MODE> RDEV_NOINLINE void line(int x1, int y1, int x2, int y2, int part, int nparts) const {
+        const int dx = x2 - x1;
+        int dy = y2 - y1;
+        const int ey1 = y1 >> SHIFT, ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
+        if (ey1 == ey2) { if (part == 0) hline<MODE>(ey1, x1, fy1, x2, fy2); return; }
+        const int incr = dy < 0 ? -1 : 1;
+        const int nrows = (ey2 - ey1) * incr + 1;
+        const int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
+        if (r0 >= r1) return;
+        const int first = dy < 0 ? 0 : SUB;
+        if (dx == 0) {
+            const int ex = x1 >> SHIFT;
+            const int two_fx = (x1 - (ex << SHIFT)) << 1;
+            for (int r = r0; r < r1; ++r) {
+                int delta;
+                if (r == 0) delta = first - fy1;
+                else if (r == nrows - 1) delta = fy2 - SUB + first;
+                else delta = first + first - SUB;
+                add<MODE>(ex, ey1 + r * incr, delta, two_fx * delta);
+            }
+            return;
+        }
+        // (32-bit like AGG: |dx|, dy <= 1024 px x 256, so 256 |dx| and mod0 + k rem stay below 2^29)
+        int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
+        if (dy < 0) dy = -dy;
+        int delta0 = p / dy, mod0 = p % dy;
+        if (mod0 < 0) { --delta0; mod0 += dy; }
+        const int x_from0 = x1 + delta0;
+        p = SUB * dx;
+        int lift = p / dy, rem = p % dy;
+        if (rem < 0) { --lift; rem += dy; }
+        int xf = 0;
+        bool have = false;
+        for (int r = r0; r < r1; ++r) {
+            if (r == 0) { hline<MODE>(ey1, x1, fy1, x_from0, first); continue; }
+            const int j = r - 1;                              // middle row index (the last row is middle row nrows - 2)
+            if (!have) { xf = x_from0 + j * lift + (mod0 + j * rem) / dy; have = true; }
+            if (r == nrows - 1) { hline<MODE>(ey2, xf, SUB - first, x2, fy2); continue; }
+            const int xt = x_from0 + (j + 1) * lift + (mod0 + (j + 1) * rem) / dy;
+            hline<MODE>(ey1 + r * incr, xf, SUB - first, xt, first);
+            xf = xt;
+        }
+    }
+};
+
+// rasterizer_sl_clip<ras_conv_dbl>::line_to for ONE edge (the clipper's only state is the previous vertex)
+struct EdgeClip {
+    double bx1, by1, bx2, by2;
+    const CellSink* c;
+    int part, nparts;            // this thread's share of the edge's rows
+    RDEV_INLINE unsigned flags(double x, double y) const {
+        return (unsigned)(x > bx2) | ((unsigned)(y > by2) << 1) | ((unsigned)(x < bx1) << 2) | ((unsigned)(y < by1) << 3);
+    }
+    RDEV_INLINE unsigned flags_y(double y) const { return ((unsigned)(y > by2) << 1) | ((unsigned)(y < by1) << 3); }
+    // line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker.  Not inlined: an
+    // edge has up to three pieces at eleven call sites, and the walker inlined at all of them was 90 KB of code.
+    template <int MODE> RDEV_NOINLINE void clip_y(double ax, double ay, double bx, double by, unsigned fa, unsigned fb) const {
+        fa &= 10; fb &= 10;
+        double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
+        if ((fa | fb) != 0) {
+            if (fa == fb) return;                          // invisible by y
+            if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
+            if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
+            if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
+            if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
+        }
+        c->line<MODE>(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
+    }
+    // One edge = up to three pieces after clipping in x (the pieces on the clip box's left / right side are kept: they
+    // close the winding).
+    template <int MODE> RDEV void edge(double x1, double y1, double x2, double y2) const {
+        const unsigned f1 = flags(x1, y1), f2 = flags(x2, y2);
+        if ((f1 & 10) == (f2 & 10) && (f1 & 10) != 0) return;      // invisible by y
+        double y3, y4;
+        unsigned f3, f4;
+        switch (((f1 & 5) << 1) | (f2 & 5)) {
+        case 0: clip_y<MODE>(x1, y1, x2, y2, f1, f2); break;
+        case 1:
+            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
+            clip_y<MODE>(x1, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx2, y2, f3, f2); break;
+        case 2:
+            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
+            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, x2, y2, f3, f2); break;
+        case 3: clip_y<MODE>(bx2, y1, bx2, y2, f1, f2); break;
+        case 4:
+            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
+            clip_y<MODE>(x1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx1, y2, f3, f2); break;
+        case 6:
+            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
+            f3 = flags_y(y3); f4 = flags_y(y4);
+            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx1, y4, f3, f4); clip_y<MODE>(bx1, y4, bx1, y2, f4, f2); break;
+        case 8:
+            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
+            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, x2, y2, f3, f2); break;
+        case 9:
+            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
+            f3 = flags_y(y3); f4 = flags_y(y4);
+            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx2, y4, f3, f4); clip_y<MODE>(bx2, y4, bx2, y2, f4, f2); break;
+        case 12: clip_y<MODE>(bx1, y1, bx1, y2, f1, f2); break;
+        default: break;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// blend: fixed_blender_rgba_plain on an opaque grey pixel (R = G = B, A = 255); rgba8::multiply for the cover
+// ---------------------------------------------------------------------------------------------------------------
+RDEV_INLINE unsigned calc_alpha(int a) {
+    int cover = a >> (SHIFT * 2 + 1 - 8);
+    if (cover < 0) cover = -cover;
+    return cover > 255 ? 255u : (unsigned)cover;
+}
+RDEV_INLINE unsigned blend(unsigned p, unsigned grey, unsigned a8, unsigned cover) {
+    if (a8 == 255 && cover == 255) return grey;          // opaque colour at full coverage: the pixel is copied
+    const unsigned t = a8 * cover + 128;
+    const unsigned alpha = ((t >> 8) + t) >> 8;
+    if (alpha == 0) return p;
+    const unsigned r = p * 255u;
+    const unsigned a = ((alpha + 255u) << 8) - alpha * 255u;
+    return (unsigned)((((int)(grey << 8) - (int)r) * (int)alpha + (int)(r << 8)) / (int)a);
+}
+
+}  // namespace vpk_raster
+#endif
