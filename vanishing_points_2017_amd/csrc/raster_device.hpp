@@ -240,7 +240,7 @@ RDEV void stroke_outline(V2* p, int n, double width, Outline& o) {
 // polygon's edges are walked twice: pass 1 (BOUNDS) only records every row's first / last cell, a prefix sum over the rows
 // packs the rows' cell ranges into the pool, pass 2 (POOL) adds the cells there with LDS atomics.  A polygon whose ranges
 // do not fit the pool (GLOBAL) uses image-sized accumulators in HBM / L2 with global atomics instead.
-constexpr int POOL = 12288;             // cells (cover, area) of one polygon in LDS: 96 KB
+constexpr int POOL = 8192;              // cells (cover, area) of one polygon in LDS: 64 KB (two workgroups per CU)
 enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
 
 struct CellSink {

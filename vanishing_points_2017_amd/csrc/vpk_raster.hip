@@ -233,18 +233,24 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
             if (hi >= lo) {
                 int* pc = sink.pcover + sink.rowoff[y] - boff;
                 int* pa = sink.parea + sink.rowoff[y] - boff;
-                unsigned char* dst = A.alpha + ab + sink.rowoff[y];
                 int R = 0;
                 for (int q = 0; q <= hi - lo; ++q) {          // the per-pixel form of sweep_scanline (see blend_kernel)
                     const int c = pc[q], a = pa[q];
-                    pc[q] = 0; pa[q] = 0;
+                    pa[q] = 0;
                     R += c;
                     unsigned al = 0;
                     if (a) al = calc_alpha((R << (SHIFT + 1)) - a);
                     else if (q < hi - lo) al = calc_alpha(R << (SHIFT + 1));
-                    dst[q] = (unsigned char)al;
+                    pc[q] = (int)al;                          // the row's alphas stay in the pool ...
                 }
             }
+        }
+        __syncthreads();
+        {   // ... and leave it in one coalesced copy (the pool is zero again afterwards)
+            const int last = ye - 1;
+            const int bend = sink.rowoff[last] + (sink.rowmax[last] >= sink.rowmin[last] ? sink.rowmax[last] - sink.rowmin[last] + 1 : 0);
+            unsigned char* dst = A.alpha + ab + boff;
+            for (int q = threadIdx.x; q < bend - boff; q += RT) { dst[q] = (unsigned char)sink.pcover[q]; sink.pcover[q] = 0; }
         }
         __syncthreads();
         lap(3);
@@ -301,27 +307,33 @@ __global__ __launch_bounds__(RT) void coverage_kernel(RasterArgs A) {
 // calculate_alpha((R << 9) - area), one without (no cell, or a cell of a vertical edge on the pixel boundary) lies in the
 // span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
 // coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
-constexpr int BROWS = 64;                                 // image rows per workgroup
-__global__ __launch_bounds__(BROWS) void blend_kernel(RasterArgs A) {
+constexpr int BROWS = 64, BSEG = 4;                       // image rows per workgroup; column segments per row (one wave each)
+__global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4]
     const int size = A.size, ldp = (size + 3) & ~3;
-    const int img_i = blockIdx.y, y = blockIdx.x * BROWS + threadIdx.x;
-    unsigned char* row = s_px + (size_t)threadIdx.x * ldp;
-    for (int x = 0; x < ldp; x += 4) *reinterpret_cast<unsigned*>(row + x) = 0u;
+    const int rr = threadIdx.x & (BROWS - 1), seg = threadIdx.x / BROWS;
+    const int img_i = blockIdx.y, y = blockIdx.x * BROWS + rr;
+    unsigned char* row = s_px + (size_t)rr * ldp;
+    // a thread owns the pixels [x0, x1) of its row: rows with long cell ranges (curves running along the row) are shared
+    // by four waves, and a workgroup keeps four waves in flight against the latency of the item -> row -> alpha loads
+    const int segw = ((size + BSEG - 1) / BSEG + 3) & ~3;
+    const int x0 = seg * segw, x1 = x0 + segw < size ? x0 + segw : size;
+    for (int x = x0; x < x0 + segw && x < ldp; x += 4) *reinterpret_cast<unsigned*>(row + x) = 0u;
     const long long lo = A.offsets[A.first_image + img_i] - A.line0, hi = A.offsets[A.first_image + img_i + 1] - A.line0;
     if (y < size) {
         auto apply = [&](const Item& it, unsigned grey, unsigned a8) {
             if (y < it.ymin || y > it.ymax) return;
             const RowRef r = A.rows[it.row_base + (y - it.ymin)];
             const unsigned char* al = A.alpha + it.alpha_base + r.off;
-            for (int q0 = 0; q0 < r.len; q0 += 8) {       // eight bytes requested together
+            const int qlo = x0 - r.xmin > 0 ? x0 - r.xmin : 0, qhi = x1 - r.xmin < r.len ? x1 - r.xmin : r.len;
+            for (int q0 = qlo; q0 < qhi; q0 += 8) {       // eight bytes requested together
                 unsigned av[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) av[u] = q0 + u < r.len ? al[q0 + u] : 0u;
+                for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? al[q0 + u] : 0u;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int x = r.xmin + q0 + u;
-                    if (av[u] && x >= 0 && x < size) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
+                    if (av[u]) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
                 }
             }
         };
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(BROWS) void blend_kernel(RasterArgs A) {
     unsigned char* out = A.out + (size_t)(A.first_image + img_i) * size * size;
     const int row0 = blockIdx.x * BROWS;
     for (int r = 0; r < BROWS && row0 + r < size; ++r)
-        for (int x = threadIdx.x; x < size; x += BROWS) out[(size_t)(row0 + r) * size + x] = s_px[(size_t)r * ldp + x];
+        for (int x = threadIdx.x; x < size; x += BROWS * BSEG) out[(size_t)(row0 + r) * size + x] = s_px[(size_t)r * ldp + x];
 }
 
 }  // namespace
@@ -405,10 +417,10 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
-        const int wgs = (int)std::min<long long>(nt, (long long)h->num_cu);
+        const int wgs = (int)std::min<long long>(nt, 2ll * h->num_cu);      // two workgroups fit a CU (LDS: 76 KB each)
         hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[2], h->stream));
-        hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS), (size_t)BROWS * ldp, h->stream, A);
+        hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS * BSEG), (size_t)BROWS * ldp, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[3], h->stream));
         VPK_HIP(h, hipGetLastError());
         if (times) {
