@@ -498,6 +498,7 @@ def run_workload(args, dist, rank, local_rank, world):
     sync_all()
     elapsed = time.perf_counter() - t0
     layer_ms = net.last_layer_ms()
+    out = {q: (v.clone() if torch.is_tensor(v) else v) for q, v in out.items()}   # the ring's buffers are reused by the legs below
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rt.tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -537,6 +538,76 @@ def run_workload(args, dist, rank, local_rank, world):
         net.set_precision(0)
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)
+    # The same K steps once more STARTING FROM THE LINES: every step first rasterises its batch (vpk_sphere_raster on a stream
+    # of its own; the CNN of the step waits for it on the device), i.e. sphere raster -> CNN -> EM, SURVEY 8d's full metric.
+    # Reported beside the headline number (whose inputs include the rasters, as the contract's "resident in HBM" says).
+    from_lines = None
+    if args.workload == "yud" and not sliced and not args.no_alt:
+        from vanishing_points_2017_amd import sphere_mapping, _lib
+        rt_r = get_runtime(local_rank, "raster")
+        offs = _lib.host_i64(d["offsets"])
+        size_px = int(d["sphere"].shape[-1])
+        with rt_r.on_stream():
+            spheres = [torch.empty_like(d["sphere"]) for _ in ring]
+            ev_r = [torch.cuda.Event(enable_timing=False) for _ in ring]
+            ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ring_r = [pipeline.Step(rt_cnn, lanes[j % n_lanes], dict(d, sphere=spheres[j]), params, l_in=l_pristine, max_vp=max_vp,
+                                records=dist is not None, image_ids=image_ids, timing=False) for j in range(len(ring))]
+        rt_r.synchronize()
+        ev_t[0].record(rt_r.stream)                      # the raster alone, once (also its workspace allocation and table)
+        sphere_mapping.raster_batch_device(rt_r, l_pristine, offs, size_px, 0.1, out=spheres[0])
+        rt_r.synchronize()
+        ev_t[0].record(rt_r.stream)
+        sphere_mapping.raster_batch_device(rt_r, l_pristine, offs, size_px, 0.1, out=spheres[0])
+        ev_t[1].record(rt_r.stream)
+        rt_r.synchronize()
+        raster_alone_ms = ev_t[0].elapsed_time(ev_t[1])
+        # the same batch once without any overlap (raster, then CNN, then EM, each waited for): what the pipelined steps must equal
+        with rt_cnn.on_stream():
+            resp0 = net.forward_device(spheres[0])
+        rt_cnn.synchronize()
+        with rt.on_stream():
+            plain = gem.em_batch_device(rt, d["offsets"], l_pristine.clone(), d["lp"], resp0.reshape(-1, 400), spheres[0],
+                                        d["init_vp"], params, max_vp=max_vp)
+        rt.synchronize()
+        plain = {q: plain[q].clone() for q in ("iterations", "status", "num_vp", "vp_assoc", "vp")}
+
+        def step_from_lines(k):
+            j = k % len(ring_r)
+            st = ring_r[j]
+            rt_r.stream.wait_event(st.guard)             # the EM that read this raster buffer last has finished
+            sphere_mapping.raster_batch_device(rt_r, l_pristine, offs, size_px, 0.1, out=spheres[j])
+            ev_r[j].record(rt_r.stream)
+            rt_cnn.stream.wait_event(ev_r[j])
+            o = st.enqueue()
+            if dist is not None:
+                with st.rt_em.on_stream():
+                    o = dict(o, records=sharding.gather_device(dist, st.records))
+            return o
+
+        def sync_lines():
+            rt_r.synchronize()
+            sync_all()
+
+        for k in range(max(args.warmup, len(ring_r))):
+            step_from_lines(k)
+        sync_lines()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            o_lines = step_from_lines(args.warmup + k)
+        sync_lines()
+        fl_elapsed = time.perf_counter() - t1
+        if dist is not None:
+            tmax = torch.tensor([fl_elapsed], dtype=torch.float64, device=rt.tdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            fl_elapsed = float(tmax.item())
+        from_lines = {"path": "vpk_sphere_raster (own stream) -> CNN -> EM per step; the step's inputs are the line sets only",
+                      "value": count * world * args.steps / fl_elapsed, "unit": "images/s",
+                      "ms_per_step": fl_elapsed / args.steps * 1e3, "steps": args.steps,
+                      "raster_alone_ms": raster_alone_ms, "raster_alone_images_per_s": count / raster_alone_ms * 1e3,
+                      "note": "the headline run's resident rasters are the workload generator's (synth.raster_numpy), these are the "
+                              "library's own (the reference's Agg pipeline, pixel-exact): the two runs' results are not comparable line by line",
+                      "results_equal_unpipelined_pass": bool(all(torch.equal(o_lines[q], plain[q]) for q in plain))}
     iters = out["iterations"].cpu().numpy()
     status = out["status"].cpu().numpy()
     nvp = out["num_vp"].cpu().numpy()
@@ -656,6 +727,8 @@ def run_workload(args, dist, rank, local_rank, world):
         }
         if alt:
             line["alt_precision"] = alt
+        if from_lines is not None:
+            line["from_lines"] = from_lines
         if args.workload == "yud":
             line["parity"] = reference_parity(rt, gem, scenes, d, l_pristine, params, max_vp, rank * count)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only

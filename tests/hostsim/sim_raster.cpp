@@ -74,13 +74,18 @@ extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, u
             }
             sm.n = 0;
         };
-        for (int i = 0; i < ns; ++i) {
-            const double al = (i == ns - 1) ? hi_a : lo_a + i * step;
-            double be = -atan((-la * sin(al) - lc * cos(al)) / lb);
-            be *= -1;
-            const double x = (al - lo_a) / (hi_a - lo_a) * size, y = size - (be - lo_a) / (hi_a - lo_a) * size;
-            if (!(x == x) || !(y == y) || isinf(x) || isinf(y)) { if (sm.have) flush(); continue; }
-            if (!sm.have) sm.begin(x, y); else sm.feed(x, y);
+        constexpr int OG = 8;                                     // groups, as outline_kernel feeds them
+        for (int i0 = 0; i0 < ns; i0 += OG) {
+            double xs[OG], ys[OG];
+            for (int u = 0; u < OG; ++u) {
+                const int i = i0 + u < ns ? i0 + u : ns - 1;
+                const double al = (i == ns - 1) ? hi_a : lo_a + i * step;
+                double be = -atan((-la * sin(al) - lc * cos(al)) / lb);
+                be *= -1;
+                xs[u] = (al - lo_a) / (hi_a - lo_a) * size;
+                ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
+            }
+            feed_group<OG>(sm, xs, ys, ns - i0, flush);
         }
         if (sm.have) flush();
     }

@@ -46,46 +46,44 @@ struct Simplifier {
     double thr2;
     double lastx, lasty, origdx, origdy, orig_norm2, fwd_max, bwd_max, nextx, nexty, nbx, nby, startx, starty;
     bool last_fwd, last_bwd, clipped, have;
-    RDEV void init(V2* o, int capacity, unsigned* fl) {
+    int epoch;                                  // counts the changes of the run's constants (start, orig*): see feed_group
+    RDEV_INLINE void init(V2* o, int capacity, unsigned* fl) {
         out = o; n = 0; cap = capacity; flags = fl;
         thr2 = (1.0 / 9.0) * (1.0 / 9.0);
-        have = false;
+        have = false; epoch = 0;
+        lastx = lasty = origdx = origdy = orig_norm2 = fwd_max = bwd_max = nextx = nexty = nbx = nby = startx = starty = 0.0;
+        last_fwd = last_bwd = clipped = false;
     }
-    RDEV void emit(double x, double y) {
+    RDEV_INLINE void emit(double x, double y) {
         if (n < cap) { out[n].x = x; out[n].y = y; ++n; } else { *flags |= FLAG_OVERFLOW; }
     }
-    RDEV void begin(double x, double y) {      // move_to
+    RDEV_INLINE void begin(double x, double y) {      // move_to
         lastx = x; lasty = y; orig_norm2 = 0.0; bwd_max = 0.0; clipped = true; have = true;
         origdx = origdy = fwd_max = nextx = nexty = nbx = nby = startx = starty = 0.0;
         last_fwd = last_bwd = false;
+        ++epoch;
     }
-    RDEV void feed(double x, double y) {       // line_to
-        if (orig_norm2 == 0.0) {
-            if (clipped) { emit(lastx, lasty); clipped = false; }
-            origdx = x - lastx; origdy = y - lasty;
-            orig_norm2 = origdx * origdx + origdy * origdy;
-            fwd_max = orig_norm2; bwd_max = 0.0; last_fwd = true; last_bwd = false;
-            startx = lastx; starty = lasty;
-            nextx = lastx = x; nexty = lasty = y;
-            return;
-        }
+    // The part of line_to that only reads the run's constants (its start and its first segment): where the vertex lies
+    // along and across the run.  Within a run these are independent from vertex to vertex -- feed_group evaluates them for
+    // a group of vertices side by side and feeds the results to the sequential part below.
+    RDEV_INLINE void metrics(double x, double y, double& totdot, double& perp2, double& para2) const {
         const double totdx = x - startx, totdy = y - starty;
-        const double totdot = origdx * totdx + origdy * totdy;
+        totdot = origdx * totdx + origdy * totdy;
         const double paradx = totdot * origdx / orig_norm2, parady = totdot * origdy / orig_norm2;
         const double perpdx = totdx - paradx, perpdy = totdy - parady;
-        const double perp2 = perpdx * perpdx + perpdy * perpdy;
-        if (perp2 < thr2) {
-            const double para2 = paradx * paradx + parady * parady;
-            last_fwd = last_bwd = false;
-            if (totdot > 0.0) {
-                if (para2 > fwd_max) { last_fwd = true; fwd_max = para2; nextx = x; nexty = y; }
-            } else {
-                if (para2 > bwd_max) { last_bwd = true; bwd_max = para2; nbx = x; nby = y; }
-            }
-            lastx = x; lasty = y;
-            return;
-        }
-        // _push: the run ends here
+        perp2 = perpdx * perpdx + perpdy * perpdy;
+        para2 = paradx * paradx + parady * parady;
+    }
+    RDEV_INLINE void first_segment(double x, double y) {
+        if (clipped) { emit(lastx, lasty); clipped = false; }
+        origdx = x - lastx; origdy = y - lasty;
+        orig_norm2 = origdx * origdx + origdy * origdy;
+        fwd_max = orig_norm2; bwd_max = 0.0; last_fwd = true; last_bwd = false;
+        startx = lastx; starty = lasty;
+        nextx = lastx = x; nexty = lasty = y;
+        ++epoch;
+    }
+    RDEV_INLINE void push(double x, double y) {   // _push: the run ends at this vertex
         double ex, ey;                                  // the last point written
         if (bwd_max > 0.0) {
             if (last_fwd) { emit(nbx, nby); emit(nextx, nexty); ex = nextx; ey = nexty; }
@@ -98,8 +96,29 @@ struct Simplifier {
         startx = ex; starty = ey;
         lastx = nextx = x; lasty = nexty = y;
         bwd_max = 0.0; last_bwd = false; clipped = false;
+        ++epoch;
     }
-    RDEV void end() {                           // path_cmd_stop
+    // the sequential part of line_to, given metrics() of the vertex under the CURRENT run constants
+    RDEV_INLINE void consume(double x, double y, double totdot, double perp2, double para2) {
+        if (orig_norm2 == 0.0) { first_segment(x, y); return; }
+        if (perp2 < thr2) {
+            last_fwd = last_bwd = false;
+            if (totdot > 0.0) {
+                if (para2 > fwd_max) { last_fwd = true; fwd_max = para2; nextx = x; nexty = y; }
+            } else {
+                if (para2 > bwd_max) { last_bwd = true; bwd_max = para2; nbx = x; nby = y; }
+            }
+            lastx = x; lasty = y;
+            return;
+        }
+        push(x, y);
+    }
+    RDEV_INLINE void feed(double x, double y) {       // line_to
+        double totdot = 0.0, perp2 = 0.0, para2 = 0.0;
+        if (orig_norm2 != 0.0) metrics(x, y, totdot, perp2, para2);
+        consume(x, y, totdot, perp2, para2);
+    }
+    RDEV_INLINE void end() {                           // path_cmd_stop
         if (!have) return;
         if (orig_norm2 != 0.0) {
             emit(nextx, nexty);
@@ -109,6 +128,32 @@ struct Simplifier {
         have = false;
     }
 };
+
+// G consecutive vertices of a path through PathNanRemover + PathSimplifier.  A thread is alone with the latency of its
+// arithmetic (one line per thread, fewer waves than SIMDs), and a vertex costs two divisions before the simplifier can
+// decide anything -- but those only depend on the run's constants, which change once in ~100 vertices.  So the metrics
+// of all G vertices are evaluated first, as G independent chains, under the constants of the moment; the sequential part
+// then takes them in order and re-evaluates a vertex's metrics only if a run ended (epoch changed) inside the group.
+// Same operations on the same operands as vertex-by-vertex feeding, hence the same bits.
+template <int G, typename Flush>
+RDEV_INLINE void feed_group(Simplifier& sm, const double (&xs)[G], const double (&ys)[G], int count, Flush&& flush) {
+    double td[G], pp[G], pa[G];
+    const int ep = sm.epoch;
+#pragma unroll
+    for (int u = 0; u < G; ++u) sm.metrics(xs[u], ys[u], td[u], pp[u], pa[u]);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        if (u >= count) break;
+        const double x = xs[u], y = ys[u];
+        if (!(x == x) || !(y == y) || isinf(x) || isinf(y)) {                 // PathNanRemover: breaks the path
+            if (sm.have) flush();
+            continue;
+        }
+        if (!sm.have) { sm.begin(x, y); continue; }
+        if (sm.epoch != ep) sm.metrics(x, y, td[u], pp[u], pa[u]);
+        sm.consume(x, y, td[u], pp[u], pa[u]);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // agg::conv_stroke (agg_vcgen_stroke.cpp + agg_math_stroke.h): square caps, round joins, inner miter, scale 1

@@ -2,6 +2,7 @@
 #ifndef VPK_INTERNAL_HPP_
 #define VPK_INTERNAL_HPP_
 
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string>
@@ -46,6 +47,8 @@ struct vpk_handle {
     bool raster_ready = false;
     void* raster_hdr = nullptr;
     size_t raster_hdr_bytes = 0;
+    std::vector<long long> raster_offsets;   // the offsets the device copy in raster_hdr holds (same batch again: no upload, no wait)
+    int raster_table_size = 0;               // canvas size the sample table in raster_hdr was made for
     bool em_ready = false;    // dynamic-LDS attribute set on the EM kernels
     // time-sliced EM launches (vpk_em_set_time_slice): images not finished within a launch's budget are parked
     // in device-side lists and resumed by the next launch; their slots outlive the launch

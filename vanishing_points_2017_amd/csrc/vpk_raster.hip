@@ -19,6 +19,8 @@
 // Decomposition: three kernels (outlines per line over all CUs, coverage per line over all CUs, ordered blend per image
 // row), described where they are defined below.
 #include "vpk_internal.hpp"
+#include <string.h>
+
 #include "raster_device.hpp"
 
 #include <algorithm>
@@ -55,15 +57,17 @@ struct RasterArgs {
     int first_image;                                     // images [first_image, first_image + batch) of the caller's batch
 };
 
-__global__ void raster_table_kernel(int ns, double* tab) {
+// per sample, the same for every line: sin / cos of alpha (sphere_mapping.py:61-63) and the pixel x of the sample
+__global__ void raster_table_kernel(int ns, int size, double* tab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
     const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
     const double step = (hi_a - lo_a) / (ns - 1);
     const double al = (i == ns - 1) ? hi_a : lo_a + i * step;       // numpy.linspace
-    tab[3 * i] = al;
-    tab[3 * i + 1] = sin(al);
-    tab[3 * i + 2] = cos(al);
+    tab[4 * i] = (al - lo_a) / (hi_a - lo_a) * size;                // the axes' transform of alpha (always finite)
+    tab[4 * i + 1] = sin(al);
+    tab[4 * i + 2] = cos(al);
+    tab[4 * i + 3] = 0.0;
 }
 
 __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
@@ -109,29 +113,21 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         }
         sm.n = 0;
     };
-    // four samples are evaluated side by side (independent atan / division chains: the thread is alone with its latency),
-    // then fed to the simplifier in order
-    for (int i0 = 0; i0 < ns; i0 += 4) {
-        double xs[4], ys[4];
+    // OG samples are evaluated side by side (independent division / atan chains: the thread is alone with its latency),
+    // then fed to the simplifier as a group (feed_group: the simplifier's own divisions side by side as well)
+    constexpr int OG = 8;
+    for (int i0 = 0; i0 < ns; i0 += OG) {
+        double xs[OG], ys[OG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < OG; ++u) {
             const int i = i0 + u < ns ? i0 + u : ns - 1;
-            const double al = A.tab[3 * i], sa = A.tab[3 * i + 1], ca = A.tab[3 * i + 2];
+            const double sa = A.tab[4 * i + 1], ca = A.tab[4 * i + 2];
             double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
             be *= -1;                                                         // :65
-            xs[u] = (al - lo_a) / (hi_a - lo_a) * size;
+            xs[u] = A.tab[4 * i];
             ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u >= ns) break;
-            const double x = xs[u], y = ys[u];
-            if (!(x == x) || !(y == y) || isinf(x) || isinf(y)) {             // PathNanRemover: breaks the path
-                if (sm.have) flush();
-                continue;
-            }
-            if (!sm.have) sm.begin(x, y); else sm.feed(x, y);
-        }
+        feed_group<OG>(sm, xs, ys, ns - i0, flush);
     }
     if (sm.have) flush();
     pt[0] = npoly;
@@ -376,18 +372,29 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     }
     const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
-    const size_t tb = vpk::em_align((size_t)samples * 3 * 8, 256);
+    const size_t tb = vpk::em_align((size_t)samples * 4 * 8, 256);
     const size_t nl = (size_t)chunk_lines + 4;
     const size_t need = ob + fb + tb + nl * per_line + 4096;
+    const void* had = h->raster_hdr;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
     char* base = (char*)h->raster_hdr;
-    // offsets [host] -> device: caller-owned pageable memory, so the copy is waited for
-    VPK_HIP(h, hipStreamSynchronize(h->stream));
-    VPK_HIP(h, hipMemcpyAsync(base, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    VPK_HIP(h, hipStreamSynchronize(h->stream));
+    // offsets [host] -> device.  Caller-owned pageable memory, so the copy is waited for -- but a pipeline rasterises the
+    // same batch structure again and again: when the device copy already holds these offsets nothing is uploaded and the
+    // call does not wait for anything (the sample table is kept the same way).
+    const bool same = had == h->raster_hdr && h->raster_offsets.size() == (size_t)batch + 1 &&
+                      memcmp(h->raster_offsets.data(), offsets, (size_t)(batch + 1) * 8) == 0;
+    if (!same) {
+        VPK_HIP(h, hipStreamSynchronize(h->stream));
+        VPK_HIP(h, hipMemcpyAsync(base, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        VPK_HIP(h, hipStreamSynchronize(h->stream));
+        h->raster_offsets.assign((const long long*)offsets, (const long long*)offsets + batch + 1);
+    }
     VPK_HIP(h, hipMemsetAsync(base + ob, 0, fb, h->stream));
-    hipLaunchKernelGGL(raster_table_kernel, dim3((samples + 255) / 256), dim3(256), 0, h->stream, samples, (double*)(base + ob + fb));
+    if (!same || h->raster_table_size != size) {
+        hipLaunchKernelGGL(raster_table_kernel, dim3((samples + 255) / 256), dim3(256), 0, h->stream, samples, size, (double*)(base + ob + fb));
+        h->raster_table_size = size;
+    }
     RasterArgs A;
     A.l = l; A.offsets = (const long long*)base; A.tab = (const double*)(base + ob + fb); A.size = size; A.samples = samples;
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround

@@ -7,13 +7,16 @@ import numpy as np
 from .runtime import get_runtime
 
 
-def raster_batch_device(rt, l, offsets, size=500, alpha=0.1):
-    """l: device tensor (sum N x 3, f64); offsets: host int64 (B+1).  Returns uint8 (B,size,size)."""
+def raster_batch_device(rt, l, offsets, size=500, alpha=0.1, out=None):
+    """l: device tensor (sum N x 3, f64); offsets: host int64 (B+1).  Returns uint8 (B,size,size) -- ``out`` if given.
+    Asynchronous on rt's stream; a call with the offsets of the previous call on this handle does not wait for anything."""
     t = rt.torch
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     batch = offsets.shape[0] - 1
     with rt.on_stream():
-        out = t.empty((batch, size, size), dtype=t.uint8, device=rt.tdev)
+        if out is None:
+            out = t.empty((batch, size, size), dtype=t.uint8, device=rt.tdev)
+        assert out.dtype == t.uint8 and out.is_contiguous() and tuple(out.shape) == (batch, size, size)
         rt.check(rt.lib.vpk_sphere_raster(rt.h, rt.ptr(l), offsets.ctypes.data_as(ctypes.c_void_p), batch,
                                           int(size), float(alpha), rt.ptr(out)))
     return out
