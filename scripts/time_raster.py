@@ -6,7 +6,10 @@ import torch
 from vanishing_points_2017_amd import synth, sphere_mapping
 from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
+only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for cfg, count in ((2, 102), (4, 512)):
+    if only and cfg != only:
+        continue
     scenes = list(synth.config_scenes(cfg, count=count, raster=None))
     counts = [s["l"].shape[0] for s in scenes]
     offsets = np.zeros(len(counts) + 1, dtype=np.int64); offsets[1:] = np.cumsum(counts)

@@ -12,16 +12,23 @@
 #define RDEV __device__
 #define RDEV_INLINE __device__ __forceinline__
 #define RDEV_NOINLINE __device__ __noinline__
-#define RS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define RS_ATOMIC_MIN(p, v) atomicMin((p), (v))
-#define RS_ATOMIC_MAX(p, v) atomicMax((p), (v))
+// the per-polygon accumulators live in LDS: pointers typed with the LDS address space make the accesses ds_* instructions
+// (through generic pointers -- a sink handed to a noinline function -- they were flat_* instructions: LDS by way of the
+// vector-memory address path, a round trip several times longer, with the waves parked on it 80 % of the time)
+#define RS_LDS __attribute__((address_space(3)))
+#define RS_ATOMIC_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RS_ATOMIC_MIN(p, v) (void)__hip_atomic_fetch_min((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RS_ATOMIC_MAX(p, v) (void)__hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RS_ATOMIC_ADD_GLOBAL(p, v) atomicAdd((p), (v))
 #else
 #define RDEV
 #define RDEV_INLINE inline
 #define RDEV_NOINLINE
+#define RS_LDS
 #define RS_ATOMIC_ADD(p, v) (*(p) += (v))
 #define RS_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
 #define RS_ATOMIC_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+#define RS_ATOMIC_ADD_GLOBAL(p, v) (*(p) += (v))
 #endif
 
 namespace vpk_raster {
@@ -285,169 +292,177 @@ RDEV void stroke_outline(V2* p, int n, double width, Outline& o) {
 // polygon's edges are walked twice: pass 1 (BOUNDS) only records every row's first / last cell, a prefix sum over the rows
 // packs the rows' cell ranges into the pool, pass 2 (POOL) adds the cells there with LDS atomics.  A polygon whose ranges
 // do not fit the pool (GLOBAL) uses image-sized accumulators in HBM / L2 with global atomics instead.
-constexpr int POOL = 8192;              // cells (cover, area) of one polygon in LDS: 64 KB (two workgroups per CU)
+constexpr int POOL = 7936;              // cells (cover, area) of one polygon in LDS: 62 KB (two workgroups per CU)
 enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
 
+typedef RS_LDS int* lds_int_ptr;
 struct CellSink {
     int* cover; int* area;              // GLOBAL: [size][size + 2], x shifted by one (cells at x = -1 and x = size exist)
-    int* pcover; int* parea;            // POOLED: LDS pool
-    int* rowmin; int* rowmax; int* rowoff;   // LDS, per row
+    lds_int_ptr pcover, parea;          // POOLED: LDS pool
+    lds_int_ptr rowmin, rowmax, rowoff; // LDS, per row
     int size;
     int blo, bhi, boff;                 // POOLED: the band of rows [blo, bhi) the pool holds now; pool index = rowoff - boff
-    template <int MODE> RDEV_INLINE void add(int ex, int ey, int c, int a) const {
-        if ((c | a) == 0) return;
-        if (ey < 0 || ey >= size || ex < -1 || ex > size) return;
-        if (MODE == BOUNDS) {
-            RS_ATOMIC_MIN(rowmin + ey, ex + 1);
-            RS_ATOMIC_MAX(rowmax + ey, ex + 1);
-        } else if (MODE == POOLED) {
-            if (ey < blo || ey >= bhi) return;
-            const int idx = rowoff[ey] - boff + (ex + 1 - rowmin[ey]);
-            if (c) RS_ATOMIC_ADD(pcover + idx, c);
-            if (a) RS_ATOMIC_ADD(parea + idx, a);
-        } else {
-            const size_t idx = (size_t)ey * (size + 2) + ex + 1;
-            if (c) RS_ATOMIC_ADD(cover + idx, c);
-            if (a) RS_ATOMIC_ADD(area + idx, a);
-        }
-    }
-    template <int MODE> RDEV_NOINLINE void hline(int ey, int x1, int y1, int x2, int y2) const {
-        int ex1 = x1 >> SHIFT;
-        const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
-        if (y1 == y2) return;
-        if (ex1 == ex2) {
-            const int delta = y2 - y1;
-            add<MODE>(ex1, ey, delta, (fx1 + fx2) * delta);
-            return;
-        }
-        int p = (SUB - fx1) * (y2 - y1), first = SUB, incr = 1, dx = x2 - x1;
-        if (dx < 0) { p = fx1 * (y2 - y1); first = 0; incr = -1; dx = -dx; }
-        int delta = p / dx, mod = p % dx;
-        if (mod < 0) { --delta; mod += dx; }
-        add<MODE>(ex1, ey, delta, (fx1 + first) * delta);
-        ex1 += incr;
-        y1 += delta;
-        if (ex1 != ex2) {
-            p = SUB * (y2 - y1 + delta);
-            int lift = p / dx, rem = p % dx;
-            if (rem < 0) { --lift; rem += dx; }
-            mod -= dx;
-            while (ex1 != ex2) {
-                delta = lift;
-                mod += rem;
-                if (mod >= 0) { mod -= dx; ++delta; }
-                add<MODE>(ex1, ey, delta, SUB * delta);
-                y1 += delta;
-                ex1 += incr;
-            }
-        }
-        delta = y2 - y1;
-        add<MODE>(ex1, ey, delta, (fx2 + SUB - first) * delta);
-    }
-    // rasterizer_cells_aa::line for the rows [part * nrows / nparts, (part + 1) * nrows / nparts) of the edge only: a long
-    // edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
-    // the running remainder wraps); after k middle rows the remainder has wrapped floor((mod0 + k rem) / dy) times, so
-    // any row's (x_from, x_to) follows in closed form and a thread can start in the middle of the edge with exactly the
-    // state the sequential walk has there.
-    template <int MODE> RDEV_NOINLINE void line(int x1, int y1, int x2, int y2, int part, int nparts) const {
-        const int dx = x2 - x1;
-        int dy = y2 - y1;
-        const int ey1 = y1 >> SHIFT, ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
-        if (ey1 == ey2) { if (part == 0) hline<MODE>(ey1, x1, fy1, x2, fy2); return; }
-        const int incr = dy < 0 ? -1 : 1;
-        const int nrows = (ey2 - ey1) * incr + 1;
-        const int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
-        if (r0 >= r1) return;
-        const int first = dy < 0 ? 0 : SUB;
-        if (dx == 0) {
-            const int ex = x1 >> SHIFT;
-            const int two_fx = (x1 - (ex << SHIFT)) << 1;
-            for (int r = r0; r < r1; ++r) {
-                int delta;
-                if (r == 0) delta = first - fy1;
-                else if (r == nrows - 1) delta = fy2 - SUB + first;
-                else delta = first + first - SUB;
-                add<MODE>(ex, ey1 + r * incr, delta, two_fx * delta);
-            }
-            return;
-        }
-        // (32-bit like AGG: |dx|, dy <= 1024 px x 256, so 256 |dx| and mod0 + k rem stay below 2^29)
-        int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
-        if (dy < 0) dy = -dy;
-        int delta0 = p / dy, mod0 = p % dy;
-        if (mod0 < 0) { --delta0; mod0 += dy; }
-        const int x_from0 = x1 + delta0;
-        p = SUB * dx;
-        int lift = p / dy, rem = p % dy;
-        if (rem < 0) { --lift; rem += dy; }
-        int xf = 0;
-        bool have = false;
-        for (int r = r0; r < r1; ++r) {
-            if (r == 0) { hline<MODE>(ey1, x1, fy1, x_from0, first); continue; }
-            const int j = r - 1;                              // middle row index (the last row is middle row nrows - 2)
-            if (!have) { xf = x_from0 + j * lift + (mod0 + j * rem) / dy; have = true; }
-            if (r == nrows - 1) { hline<MODE>(ey2, xf, SUB - first, x2, fy2); continue; }
-            const int xt = x_from0 + (j + 1) * lift + (mod0 + (j + 1) * rem) / dy;
-            hline<MODE>(ey1 + r * incr, xf, SUB - first, xt, first);
-            xf = xt;
-        }
-    }
 };
+// (the sink travels BY VALUE through the noinline walkers below: a pointer to it would be a pointer into the caller's
+//  private memory, and every field access a scratch load)
+template <int MODE> RDEV_INLINE void cell_add(const CellSink& s, int ex, int ey, int c, int a) {
+    if ((c | a) == 0) return;
+    if (ey < 0 || ey >= s.size || ex < -1 || ex > s.size) return;
+    if (MODE == BOUNDS) {
+        RS_ATOMIC_MIN(s.rowmin + ey, ex + 1);
+        RS_ATOMIC_MAX(s.rowmax + ey, ex + 1);
+    } else if (MODE == POOLED) {
+        if (ey < s.blo || ey >= s.bhi) return;
+        const int idx = s.rowoff[ey] - s.boff + (ex + 1 - s.rowmin[ey]);
+        if (c) RS_ATOMIC_ADD(s.pcover + idx, c);
+        if (a) RS_ATOMIC_ADD(s.parea + idx, a);
+    } else {
+        const size_t idx = (size_t)ey * (s.size + 2) + ex + 1;
+        if (c) RS_ATOMIC_ADD_GLOBAL(s.cover + idx, c);
+        if (a) RS_ATOMIC_ADD_GLOBAL(s.area + idx, a);
+    }
+}
+template <int MODE> RDEV_NOINLINE void cell_hline(const CellSink s, int ey, int x1, int y1, int x2, int y2) {
+    int ex1 = x1 >> SHIFT;
+    const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
+    if (y1 == y2) return;
+    if (ex1 == ex2) {
+        const int delta = y2 - y1;
+        cell_add<MODE>(s, ex1, ey, delta, (fx1 + fx2) * delta);
+        return;
+    }
+    int p = (SUB - fx1) * (y2 - y1), first = SUB, incr = 1, dx = x2 - x1;
+    if (dx < 0) { p = fx1 * (y2 - y1); first = 0; incr = -1; dx = -dx; }
+    int delta = p / dx, mod = p % dx;
+    if (mod < 0) { --delta; mod += dx; }
+    cell_add<MODE>(s, ex1, ey, delta, (fx1 + first) * delta);
+    ex1 += incr;
+    y1 += delta;
+    if (ex1 != ex2) {
+        p = SUB * (y2 - y1 + delta);
+        int lift = p / dx, rem = p % dx;
+        if (rem < 0) { --lift; rem += dx; }
+        mod -= dx;
+        while (ex1 != ex2) {
+            delta = lift;
+            mod += rem;
+            if (mod >= 0) { mod -= dx; ++delta; }
+            cell_add<MODE>(s, ex1, ey, delta, SUB * delta);
+            y1 += delta;
+            ex1 += incr;
+        }
+    }
+    delta = y2 - y1;
+    cell_add<MODE>(s, ex1, ey, delta, (fx2 + SUB - first) * delta);
+}
+// rasterizer_cells_aa::line for the rows [part * nrows / nparts, (part + 1) * nrows / nparts) of the edge only: a long
+// edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
+// the running remainder wraps); after k middle rows the remainder has wrapped floor((mod0 + k rem) / dy) times, so
+// any row's (x_from, x_to) follows in closed form and a thread can start in the middle of the edge with exactly the
+// state the sequential walk has there.
+template <int MODE> RDEV_NOINLINE void cell_line(const CellSink s, int x1, int y1, int x2, int y2, int part, int nparts) {
+    const int dx = x2 - x1;
+    int dy = y2 - y1;
+    const int ey1 = y1 >> SHIFT, ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
+    if (ey1 == ey2) { if (part == 0) cell_hline<MODE>(s, ey1, x1, fy1, x2, fy2); return; }
+    const int incr = dy < 0 ? -1 : 1;
+    const int nrows = (ey2 - ey1) * incr + 1;
+    const int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
+    if (r0 >= r1) return;
+    const int first = dy < 0 ? 0 : SUB;
+    if (dx == 0) {
+        const int ex = x1 >> SHIFT;
+        const int two_fx = (x1 - (ex << SHIFT)) << 1;
+        for (int r = r0; r < r1; ++r) {
+            int delta;
+            if (r == 0) delta = first - fy1;
+            else if (r == nrows - 1) delta = fy2 - SUB + first;
+            else delta = first + first - SUB;
+            cell_add<MODE>(s, ex, ey1 + r * incr, delta, two_fx * delta);
+        }
+        return;
+    }
+    // (32-bit like AGG: |dx|, dy <= 1024 px x 256, so 256 |dx| and mod0 + k rem stay below 2^29)
+    int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
+    if (dy < 0) dy = -dy;
+    int delta0 = p / dy, mod0 = p % dy;
+    if (mod0 < 0) { --delta0; mod0 += dy; }
+    const int x_from0 = x1 + delta0;
+    p = SUB * dx;
+    int lift = p / dy, rem = p % dy;
+    if (rem < 0) { --lift; rem += dy; }
+    int xf = 0;
+    bool have = false;
+    for (int r = r0; r < r1; ++r) {
+        if (r == 0) { cell_hline<MODE>(s, ey1, x1, fy1, x_from0, first); continue; }
+        const int j = r - 1;                              // middle row index (the last row is middle row nrows - 2)
+        if (!have) { xf = x_from0 + j * lift + (mod0 + j * rem) / dy; have = true; }
+        if (r == nrows - 1) { cell_hline<MODE>(s, ey2, xf, SUB - first, x2, fy2); continue; }
+        const int xt = x_from0 + (j + 1) * lift + (mod0 + (j + 1) * rem) / dy;
+        cell_hline<MODE>(s, ey1 + r * incr, xf, SUB - first, xt, first);
+        xf = xt;
+    }
+}
 
 // rasterizer_sl_clip<ras_conv_dbl>::line_to for ONE edge (the clipper's only state is the previous vertex)
+struct ClipBox { double bx1, by1, bx2, by2; };
+// line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker.  Not inlined: an
+// edge has up to three pieces at eleven call sites, and the walker inlined at all of them was 90 KB of code.
+template <int MODE> RDEV_NOINLINE void clip_y(const CellSink s, double by1, double by2, int part, int nparts,
+                                              double ax, double ay, double bx, double by, unsigned fa, unsigned fb) {
+    fa &= 10; fb &= 10;
+    double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
+    if ((fa | fb) != 0) {
+        if (fa == fb) return;                          // invisible by y
+        if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
+        if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
+        if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
+        if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
+    }
+    cell_line<MODE>(s, iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
+}
 struct EdgeClip {
     double bx1, by1, bx2, by2;
-    const CellSink* c;
+    CellSink c;
     int part, nparts;            // this thread's share of the edge's rows
     RDEV_INLINE unsigned flags(double x, double y) const {
         return (unsigned)(x > bx2) | ((unsigned)(y > by2) << 1) | ((unsigned)(x < bx1) << 2) | ((unsigned)(y < by1) << 3);
     }
     RDEV_INLINE unsigned flags_y(double y) const { return ((unsigned)(y > by2) << 1) | ((unsigned)(y < by1) << 3); }
-    // line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker.  Not inlined: an
-    // edge has up to three pieces at eleven call sites, and the walker inlined at all of them was 90 KB of code.
-    template <int MODE> RDEV_NOINLINE void clip_y(double ax, double ay, double bx, double by, unsigned fa, unsigned fb) const {
-        fa &= 10; fb &= 10;
-        double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
-        if ((fa | fb) != 0) {
-            if (fa == fb) return;                          // invisible by y
-            if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
-            if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
-            if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
-            if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
-        }
-        c->line<MODE>(iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
+    template <int MODE> RDEV_INLINE void piece(double ax, double ay, double bx, double by, unsigned fa, unsigned fb) const {
+        clip_y<MODE>(c, by1, by2, part, nparts, ax, ay, bx, by, fa, fb);
     }
     // One edge = up to three pieces after clipping in x (the pieces on the clip box's left / right side are kept: they
     // close the winding).
-    template <int MODE> RDEV void edge(double x1, double y1, double x2, double y2) const {
+    template <int MODE> RDEV_INLINE void edge(double x1, double y1, double x2, double y2) const {
         const unsigned f1 = flags(x1, y1), f2 = flags(x2, y2);
         if ((f1 & 10) == (f2 & 10) && (f1 & 10) != 0) return;      // invisible by y
         double y3, y4;
         unsigned f3, f4;
         switch (((f1 & 5) << 1) | (f2 & 5)) {
-        case 0: clip_y<MODE>(x1, y1, x2, y2, f1, f2); break;
+        case 0: piece<MODE>(x1, y1, x2, y2, f1, f2); break;
         case 1:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y<MODE>(x1, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx2, y2, f3, f2); break;
+            piece<MODE>(x1, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, bx2, y2, f3, f2); break;
         case 2:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, x2, y2, f3, f2); break;
-        case 3: clip_y<MODE>(bx2, y1, bx2, y2, f1, f2); break;
+            piece<MODE>(bx2, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, x2, y2, f3, f2); break;
+        case 3: piece<MODE>(bx2, y1, bx2, y2, f1, f2); break;
         case 4:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y<MODE>(x1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx1, y2, f3, f2); break;
+            piece<MODE>(x1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, bx1, y2, f3, f2); break;
         case 6:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
             f3 = flags_y(y3); f4 = flags_y(y4);
-            clip_y<MODE>(bx2, y1, bx2, y3, f1, f3); clip_y<MODE>(bx2, y3, bx1, y4, f3, f4); clip_y<MODE>(bx1, y4, bx1, y2, f4, f2); break;
+            piece<MODE>(bx2, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, bx1, y4, f3, f4); piece<MODE>(bx1, y4, bx1, y2, f4, f2); break;
         case 8:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, x2, y2, f3, f2); break;
+            piece<MODE>(bx1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, x2, y2, f3, f2); break;
         case 9:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
             f3 = flags_y(y3); f4 = flags_y(y4);
-            clip_y<MODE>(bx1, y1, bx1, y3, f1, f3); clip_y<MODE>(bx1, y3, bx2, y4, f3, f4); clip_y<MODE>(bx2, y4, bx2, y2, f4, f2); break;
-        case 12: clip_y<MODE>(bx1, y1, bx1, y2, f1, f2); break;
+            piece<MODE>(bx1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, bx2, y4, f3, f4); piece<MODE>(bx2, y4, bx2, y2, f4, f2); break;
+        case 12: piece<MODE>(bx1, y1, bx1, y2, f1, f2); break;
         default: break;
         }
     }

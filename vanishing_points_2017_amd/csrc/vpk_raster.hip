@@ -141,19 +141,51 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
 // cells of one polygon -> coverage bytes.  Same passes as before (bounds, row scan, cells into the LDS pool); the sweep
 // writes alpha bytes in the pool's packing instead of blending.
 __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int size, int* s_total, long long* s_base,
-                                 const RasterArgs& A, Item* item) {
+                                 unsigned short* s_eoff, const RasterArgs& A, Item* item) {
     const bool probe = threadIdx.x == 0 && blockIdx.x == 0;
     long long tp = probe ? wall_clock64() : 0;
     auto lap = [&](int slot) { if (probe) { const long long now = wall_clock64(); atomicAdd(A.ctr + 8 + slot, (int)(now - tp)); tp = now; } };
     EdgeClip ec;
-    ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = &sink;
-    int K = (4 * RT) / (n > 0 ? n : 1);
-    K = K < 1 ? 1 : (K > 32 ? 32 : K);
-    ec.nparts = K;
-    const int items = n * K;
+    ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = sink;
+    // Work items = (edge, share of its rows).  An outline has ~120 edges of which most cross one to three rows and a few
+    // thirty or more; an item costs the clipper's and the walker's set-up (divisions in double and in int) before its first
+    // cell, so an edge gets one share per ROWS_PER_ITEM rows it crosses -- not a fixed number of shares (with 4 RT / n
+    // shares per edge, 9 in 10 items were empty and the set-up was most of the kernel).  The shares' offsets: one wave's scan.
+    constexpr int ROWS_PER_ITEM = 4;
+    for (int k = threadIdx.x; k < n; k += RT) {
+        const double ya = v[k].y, yb = v[k + 1 < n ? k + 1 : 0].y;
+        double lo = ya < yb ? ya : yb, hi = ya < yb ? yb : ya;
+        lo = lo > 0.0 ? lo : 0.0;
+        hi = hi < (double)size ? hi : (double)size;
+        const int rows = hi >= lo ? (int)hi - (int)lo + 1 : 1;      // (an estimate is enough: any split gives the same cells)
+        int ke = (rows + ROWS_PER_ITEM - 1) / ROWS_PER_ITEM;
+        s_eoff[k] = (unsigned short)(ke > 32 ? 32 : ke);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int per = (n + 63) / 64, k0 = threadIdx.x * per;
+        int sum = 0;
+        for (int k = k0; k < k0 + per && k < n; ++k) sum += s_eoff[k];
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        int off = incl - sum;
+        for (int k = k0; k < k0 + per && k < n; ++k) { const int ke = s_eoff[k]; s_eoff[k] = (unsigned short)off; off += ke; }
+        if (threadIdx.x == 63) s_eoff[n] = (unsigned short)incl;
+    }
+    __syncthreads();
+    const int items = s_eoff[n];
+    auto item_edge = [&](int it) {                        // the edge whose shares contain item `it`: last k with eoff[k] <= it
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)s_eoff[mid] <= it) lo = mid; else hi = mid; }
+        return lo;
+    };
     for (int it = threadIdx.x; it < items; it += RT) {    // pass 1: the rows' cell ranges
-        const int k = it / K;
-        ec.part = it - k * K;
+        const int k = item_edge(it);
+        ec.part = it - s_eoff[k];
+        ec.nparts = s_eoff[k + 1] - s_eoff[k];
         const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
         ec.edge<BOUNDS>(a.x, a.y, b.x, b.y);
     }
@@ -211,10 +243,11 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         else while (ye <= ymax && sink.rowoff[ye] + (sink.rowmax[ye] >= sink.rowmin[ye] ? sink.rowmax[ye] - sink.rowmin[ye] + 1 : 0) - boff <= POOL) ++ye;
         CellSink band = sink;
         band.blo = ys; band.bhi = ye; band.boff = boff;
-        ec.c = &band;
+        ec.c = band;
         for (int it = threadIdx.x; it < items; it += RT) {    // pass 2: the cells of the band's rows
-            const int k = it / K;
-            ec.part = it - k * K;
+            const int k = item_edge(it);
+            ec.part = it - s_eoff[k];
+            ec.nparts = s_eoff[k + 1] - s_eoff[k];
             const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
             ec.edge<POOLED>(a.x, a.y, b.x, b.y);
         }
@@ -227,8 +260,8 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
             if (hi < lo) { r.xmin = 0; r.len = 0; }
             A.rows[rb + (y - ymin)] = r;
             if (hi >= lo) {
-                int* pc = sink.pcover + sink.rowoff[y] - boff;
-                int* pa = sink.parea + sink.rowoff[y] - boff;
+                lds_int_ptr pc = sink.pcover + sink.rowoff[y] - boff;
+                lds_int_ptr pa = sink.parea + sink.rowoff[y] - boff;
                 int R = 0;
                 for (int q = 0; q <= hi - lo; ++q) {          // the per-pixel form of sweep_scanline (see blend_kernel)
                     const int c = pc[q], a = pa[q];
@@ -261,16 +294,17 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     __syncthreads();
 }
 
-__global__ __launch_bounds__(RT) void coverage_kernel(RasterArgs A) {
+__global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 waves per SIMD: two workgroups per CU
     __shared__ int s_rowmin[1024], s_rowmax[1024], s_rowoff[1024];
     __shared__ int s_pcover[POOL], s_parea[POOL];
     __shared__ int s_line, s_total[4];
+    __shared__ unsigned short s_eoff[MAXV + 2];          // first work item of every edge of the polygon at hand
     __shared__ long long s_base[2];
     const int size = A.size;
     CellSink sink;
     sink.cover = nullptr; sink.area = nullptr;
-    sink.rowmin = s_rowmin; sink.rowmax = s_rowmax; sink.rowoff = s_rowoff; sink.size = size;
-    sink.pcover = s_pcover; sink.parea = s_parea;
+    sink.rowmin = (lds_int_ptr)s_rowmin; sink.rowmax = (lds_int_ptr)s_rowmax; sink.rowoff = (lds_int_ptr)s_rowoff; sink.size = size;
+    sink.pcover = (lds_int_ptr)s_pcover; sink.parea = (lds_int_ptr)s_parea;
     for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; }
     for (int q = threadIdx.x; q < POOL; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
     __syncthreads();
@@ -285,7 +319,7 @@ __global__ __launch_bounds__(RT) void coverage_kernel(RasterArgs A) {
         for (int q = 0; q < MAXSUB; ++q) {
             Item* item = A.items + g * MAXSUB + q;
             if (q < npoly) {
-                polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, s_total, s_base, A, item);
+                polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, s_total, s_base, s_eoff, A, item);
                 if (item->ymax < item->ymin && threadIdx.x == 0 && g < A.nlines) {     // dropped: tell the line's image
                     int lo = 0, hi = A.batch;
                     const long long gl = A.line0 + g;
