@@ -63,7 +63,7 @@ extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, u
     for (int g = 0; g < nlines; ++g) {
         const double la = l[3 * g], lb = l[3 * g + 1], lc = l[3 * g + 2];
         Simplifier sm;
-        sm.init(simp.data(), MAXS, &flags);
+        sm.init(simp.data(), MAXS);
         auto flush = [&]() {
             sm.end();
             if (sm.n >= 2) {
@@ -88,6 +88,7 @@ extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, u
             feed_group<OG>(sm, xs, ys, ns - i0, flush);
         }
         if (sm.have) flush();
+        flags |= sm.overflow;
     }
     const double s = (double)size, w_spine = 0.8 * 100.0 / 72.0;
     for (int side = 0; side < 4; ++side) {
@@ -132,7 +133,7 @@ extern "C" int sim_polygon_balance(const double* l3, int size, double* out) {
     std::vector<V2> simp(MAXS), verts(MAXV);
     unsigned flags = 0;
     Simplifier sm;
-    sm.init(simp.data(), MAXS, &flags);
+    sm.init(simp.data(), MAXS);
     for (int i = 0; i < ns; ++i) {
         const double al = (i == ns - 1) ? hi_a : lo_a + i * step;
         double be = -atan((-l3[0] * sin(al) - l3[2] * cos(al)) / l3[1]);

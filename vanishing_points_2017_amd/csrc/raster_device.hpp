@@ -49,20 +49,20 @@ RDEV_INLINE int iround(double v) { return (int)(v < 0.0 ? v - 0.5 : v + 0.5); }
 // PathSimplifier (matplotlib src/path_converters.h) as a push machine: feed() the vertices, it emit()s the kept ones
 // ---------------------------------------------------------------------------------------------------------------
 struct Simplifier {
-    V2* out; int n, cap; unsigned* flags;
+    V2* out; int n, cap; unsigned overflow;     // overflow: FLAG_OVERFLOW once a vertex did not fit `out`
     double thr2;
     double lastx, lasty, origdx, origdy, orig_norm2, fwd_max, bwd_max, nextx, nexty, nbx, nby, startx, starty;
     bool last_fwd, last_bwd, clipped, have;
     int epoch;                                  // counts the changes of the run's constants (start, orig*): see feed_group
-    RDEV_INLINE void init(V2* o, int capacity, unsigned* fl) {
-        out = o; n = 0; cap = capacity; flags = fl;
+    RDEV_INLINE void init(V2* o, int capacity) {
+        out = o; n = 0; cap = capacity; overflow = 0;
         thr2 = (1.0 / 9.0) * (1.0 / 9.0);
         have = false; epoch = 0;
         lastx = lasty = origdx = origdy = orig_norm2 = fwd_max = bwd_max = nextx = nexty = nbx = nby = startx = starty = 0.0;
         last_fwd = last_bwd = clipped = false;
     }
     RDEV_INLINE void emit(double x, double y) {
-        if (n < cap) { out[n].x = x; out[n].y = y; ++n; } else { *flags |= FLAG_OVERFLOW; }
+        if (n < cap) { out[n].x = x; out[n].y = y; ++n; } else { overflow |= FLAG_OVERFLOW; }
     }
     RDEV_INLINE void begin(double x, double y) {      // move_to
         lastx = x; lasty = y; orig_norm2 = 0.0; bwd_max = 0.0; clipped = true; have = true;
@@ -91,11 +91,16 @@ struct Simplifier {
         ++epoch;
     }
     RDEV_INLINE void push(double x, double y) {   // _push: the run ends at this vertex
-        double ex, ey;                                  // the last point written
-        if (bwd_max > 0.0) {
-            if (last_fwd) { emit(nbx, nby); emit(nextx, nexty); ex = nextx; ey = nexty; }
-            else { emit(nextx, nexty); emit(nbx, nby); ex = nbx; ey = nby; }
-        } else { emit(nextx, nexty); ex = nextx; ey = nexty; }
+        // (values first, then the choice: with the two orders written as two branches the compiler merges them into a
+        //  choice between the ADDRESSES of the fields, which pins next* / nb* to private memory -- a scratch store per
+        //  accepted vertex and a scratch round trip per run)
+        const double fx = nextx, fy = nexty, gx = nbx, gy = nby;
+        const bool both = bwd_max > 0.0, fwd_last = last_fwd;
+        const double ax = both && fwd_last ? gx : fx, ay = both && fwd_last ? gy : fy;     // first point written
+        const double cx = fwd_last ? fx : gx, cy = fwd_last ? fy : gy;                     // second one (if both)
+        emit(ax, ay);
+        if (both) emit(cx, cy);
+        double ex = both ? cx : ax, ey = both ? cy : ay;   // the last point written
         if (clipped || (!last_fwd && !last_bwd)) { emit(lastx, lasty); ex = lastx; ey = lasty; }
         origdx = x - lastx; origdy = y - lasty;
         orig_norm2 = origdx * origdx + origdy * origdy;
@@ -105,20 +110,22 @@ struct Simplifier {
         bwd_max = 0.0; last_bwd = false; clipped = false;
         ++epoch;
     }
-    // the sequential part of line_to, given metrics() of the vertex under the CURRENT run constants
+    // the sequential part of line_to, given metrics() of the vertex under the CURRENT run constants.  The usual case (the
+    // vertex stays within the run) is written without branches -- selects on values: 64 lines share a wave, and every
+    // divergent `if` costs the wave its exec-mask bookkeeping whether or not a lane takes it; the rare cases (first
+    // segment of a path, end of a run) sit behind ONE branch.
     RDEV_INLINE void consume(double x, double y, double totdot, double perp2, double para2) {
-        if (orig_norm2 == 0.0) { first_segment(x, y); return; }
-        if (perp2 < thr2) {
-            last_fwd = last_bwd = false;
-            if (totdot > 0.0) {
-                if (para2 > fwd_max) { last_fwd = true; fwd_max = para2; nextx = x; nexty = y; }
-            } else {
-                if (para2 > bwd_max) { last_bwd = true; bwd_max = para2; nbx = x; nby = y; }
-            }
-            lastx = x; lasty = y;
+        const bool started = orig_norm2 != 0.0;
+        if (!(started && perp2 < thr2)) {
+            if (!started) first_segment(x, y); else push(x, y);
             return;
         }
-        push(x, y);
+        const bool fwd_side = totdot > 0.0;
+        const bool nf = fwd_side && para2 > fwd_max, nb = !fwd_side && para2 > bwd_max;
+        last_fwd = nf; last_bwd = nb;
+        fwd_max = nf ? para2 : fwd_max; nextx = nf ? x : nextx; nexty = nf ? y : nexty;
+        bwd_max = nb ? para2 : bwd_max; nbx = nb ? x : nbx; nby = nb ? y : nby;
+        lastx = x; lasty = y;
     }
     RDEV_INLINE void feed(double x, double y) {       // line_to
         double totdot = 0.0, perp2 = 0.0, para2 = 0.0;

@@ -33,7 +33,10 @@ namespace {
 using namespace vpk_raster;
 
 // ---------------------------------------------------------------------------------------------------------------
-// Three kernels.
+// Four kernels.
+//   points_kernel    one thread per (line, block of 64 samples), every SIMD busy: beta(alpha) of all samples -> the
+//                    curves' pixel y, [sample][line] in HBM (8 bytes per sample: 2 GB per 25 000 lines, written and
+//                    read once; the simplifier below is a sequential machine per line, the samples are not)
 //   outline_kernel   one THREAD per line (all lines of the call, all CUs): samples -> PathSimplifier -> conv_stroke; the
 //                    closed outline polygons (up to MAXSUB per line) go to HBM
 //   coverage_kernel  one WORKGROUP per line at a time (persistent workgroups over a queue of ALL lines: the lines of an
@@ -51,6 +54,7 @@ struct RasterArgs {
     unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
     unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
     V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, 1 + 2 * MAXSUB
+    double* ys; long long ldl;                           // the curves' pixel y: [sample][ldl lines]
     unsigned char* alpha; unsigned long long alpha_cap;
     RowRef* rows; unsigned long long rows_cap;
     Item* items;                                         // per line MAXSUB, then 4 spine items
@@ -68,6 +72,32 @@ __global__ void raster_table_kernel(int ns, int size, double* tab) {
     tab[4 * i + 1] = sin(al);
     tab[4 * i + 2] = cos(al);
     tab[4 * i + 3] = 0.0;
+}
+
+constexpr int PBLOCK = 64;                               // samples per thread of points_kernel
+__global__ __launch_bounds__(64) void points_kernel(RasterArgs A) {
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (g >= A.nlines) return;
+    const long long gl = A.line0 + g;
+    const double la = A.l[3 * gl], lb = A.l[3 * gl + 1], lc = A.l[3 * gl + 2];
+    const int size = A.size, ns = A.samples;
+    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
+    const int i0 = blockIdx.y * PBLOCK, i1 = i0 + PBLOCK < ns ? i0 + PBLOCK : ns;
+    double* dst = A.ys + (size_t)i0 * A.ldl + g;
+    for (int i = i0; i < i1; i += 4) {                    // four independent division / atan chains side by side
+        double y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int iu = i + u < ns ? i + u : ns - 1;
+            const double sa = A.tab[4 * iu + 1], ca = A.tab[4 * iu + 2];      // (wave-uniform: scalar loads)
+            double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
+            be *= -1;                                                         // :65
+            y[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u < i1) dst[(size_t)(i - i0 + u) * A.ldl] = y[u];
+    }
 }
 
 __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
@@ -95,12 +125,10 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
     }
     const double width_px = 100.0 / 72.0;                 // 1 pt at 100 dpi (matplotlib 1.5.1's default line width)
     const long long gl = A.line0 + g;
-    const double la = A.l[3 * gl], lb = A.l[3 * gl + 1], lc = A.l[3 * gl + 2];
     int npoly = 0;
     Simplifier sm;
-    sm.init(sp, MAXS, fl);
+    sm.init(sp, MAXS);
     const int ns = A.samples;
-    const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
     auto flush = [&]() {                                  // end of a sub-path: stroke what the simplifier kept
         sm.end();
         if (sm.n >= 2) {
@@ -113,24 +141,23 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         }
         sm.n = 0;
     };
-    // OG samples are evaluated side by side (independent division / atan chains: the thread is alone with its latency),
-    // then fed to the simplifier as a group (feed_group: the simplifier's own divisions side by side as well)
+    // OG samples are fetched together (points_kernel made them; one coalesced 512-byte row per sample and wave), then fed
+    // to the simplifier as a group (feed_group: the simplifier's own divisions side by side)
     constexpr int OG = 8;
+    const double* ysrc = A.ys + g;
     for (int i0 = 0; i0 < ns; i0 += OG) {
         double xs[OG], ys[OG];
 #pragma unroll
         for (int u = 0; u < OG; ++u) {
             const int i = i0 + u < ns ? i0 + u : ns - 1;
-            const double sa = A.tab[4 * i + 1], ca = A.tab[4 * i + 2];
-            double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
-            be *= -1;                                                         // :65
             xs[u] = A.tab[4 * i];
-            ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
+            ys[u] = ysrc[(size_t)i * A.ldl];
         }
         feed_group<OG>(sm, xs, ys, ns - i0, flush);
     }
     if (sm.have) flush();
     pt[0] = npoly;
+    dummy |= sm.overflow;
     if (dummy) {                                          // which image the line belongs to: binary search in the offsets
         int lo = 0, hi = A.batch;
         while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (A.offsets[A.first_image + mid] <= gl) lo = mid; else hi = mid; }
@@ -397,7 +424,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
     const long long max_lines = 49152;
     const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 + MAXSUB * sizeof(Item) +
-                            16384 + (size_t)(size + 8) * sizeof(RowRef);
+                            16384 + (size_t)(size + 8) * sizeof(RowRef) + (size_t)samples * sizeof(double);
     long long chunk_lines = 0;
     for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
         b1 = b0 + 1;
@@ -408,7 +435,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
     const size_t tb = vpk::em_align((size_t)samples * 4 * 8, 256);
     const size_t nl = (size_t)chunk_lines + 4;
-    const size_t need = ob + fb + tb + nl * per_line + 4096;
+    const size_t need = ob + fb + tb + nl * per_line + 64 * (size_t)samples * sizeof(double) + 8192;
     const void* had = h->raster_hdr;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
@@ -434,6 +461,8 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround
     A.out = out; A.ctr = (int*)(base + ob); A.bump = (unsigned long long*)(base + ob + 64); A.flags = (unsigned*)(base + ob + 256);
     char* p = base + ob + fb + tb;
+    A.ldl = (long long)((nl + 63) / 64 * 64);
+    A.ys = (double*)p; p += vpk::em_align((size_t)samples * A.ldl * sizeof(double), 256);
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
     A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
@@ -453,9 +482,11 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         VPK_HIP(h, hipMemsetAsync(base + ob, 0, 256, h->stream));          // queue + bump counters of this chunk
         const long long nt = A.nlines + 4;
         const bool times = getenv("VPK_RASTER_TIMES") != nullptr;      // development: per-kernel device time
-        hipEvent_t ev[4] = {};
-        if (times) for (int q = 0; q < 4; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
+        hipEvent_t ev[5] = {};
+        if (times) for (int q = 0; q < 5; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
         if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
+        hipLaunchKernelGGL(points_kernel, dim3((unsigned)((A.nlines + 63) / 64), (samples + PBLOCK - 1) / PBLOCK), dim3(64), 0, h->stream, A);
+        if (times) VPK_HIP(h, hipEventRecord(ev[4], h->stream));
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
         const int wgs = (int)std::min<long long>(nt, 2ll * h->num_cu);      // two workgroups fit a CU (LDS: 76 KB each)
@@ -465,18 +496,19 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         if (times) VPK_HIP(h, hipEventRecord(ev[3], h->stream));
         VPK_HIP(h, hipGetLastError());
         if (times) {
-            float ms[3];
+            float ms[3], ms_points = 0.f;
             VPK_HIP(h, hipEventSynchronize(ev[3]));
             for (int q = 0; q < 3; ++q) VPK_HIP(h, hipEventElapsedTime(&ms[q], ev[q], ev[q + 1]));
+            VPK_HIP(h, hipEventElapsedTime(&ms_points, ev[0], ev[4]));
             unsigned long long bump[2];
             VPK_HIP(h, hipMemcpy(bump, A.bump, 16, hipMemcpyDeviceToHost));
             int dbg[16];
             VPK_HIP(h, hipMemcpy(dbg, A.ctr, sizeof(dbg), hipMemcpyDeviceToHost));
-            fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
+            fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: points %.2f + outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
                     "and %.0f rows per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
-                    A.nlines, ms[0], ms[1], ms[2], (double)bump[0] / nt, (double)bump[1] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
+                    A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)bump[0] / nt, (double)bump[1] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
                     dbg[11] * 1e-5);
-            for (int q = 0; q < 4; ++q) (void)hipEventDestroy(ev[q]);
+            for (int q = 0; q < 5; ++q) (void)hipEventDestroy(ev[q]);
         }
     }
     return VPK_OK;
