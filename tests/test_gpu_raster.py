@@ -69,3 +69,26 @@ def test_initial_vps_and_em_from_the_lines_alone(name):
     kw = {k: v for k, v in em_kwargs(g).items() if k != "init_vp"}
     res = gem.em_batch([{"l": g["l"].copy(), "lp": g["lp"], "cnn_response": g["cnn_response"], "sphere_image": ras}], **kw)[0]
     check_em_result(res, g)
+
+
+def test_wave_parallel_simplifier_equals_the_sequential_machine(monkeypatch):
+    """simplify_kernel (one wave per line, 64 samples at a time, runs folded with reductions) against the vertex-by-vertex
+    machine of raster_device.hpp run for every line (VPK_RASTER_SEQUENTIAL=1): same pixels on 1 500 random lines -- steep,
+    flat, through the poles, tiny and huge coefficients -- and on lines with non-finite samples (always sequential)."""
+    from vanishing_points_2017_amd import sphere_mapping
+    rng = np.random.default_rng(2024)
+    sets = []
+    for k in range(6):
+        l = rng.normal(size=(250, 3))
+        l[:, 1] *= 10.0 ** rng.uniform(-6, 1, size=250)            # b small: steep curves, jumps across the canvas
+        l[:, 2] *= 10.0 ** rng.uniform(-3, 3, size=250)
+        if k == 5:
+            l[::7, 1] = 0.0                                        # vertical lines: atan(+-inf), NaN where the numerator is 0 too
+            l[3::50] = 0.0
+        sets.append(l)
+    fast = sphere_mapping.raster_batch(sets, size=500, alpha=0.1)
+    monkeypatch.setenv("VPK_RASTER_SEQUENTIAL", "1")
+    slow = sphere_mapping.raster_batch(sets, size=500, alpha=0.1)
+    monkeypatch.delenv("VPK_RASTER_SEQUENTIAL")
+    assert np.array_equal(fast, slow), "%d pixels differ" % (fast != slow).sum()
+    assert fast.max() > 100                                        # (lines do pile up: the comparison is not of empty canvases)

@@ -34,9 +34,7 @@ using namespace vpk_raster;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Four kernels.
-//   points_kernel    one thread per (line, block of 64 samples), every SIMD busy: beta(alpha) of all samples -> the
-//                    curves' pixel y, [sample][line] in HBM (8 bytes per sample: 2 GB per 25 000 lines, written and
-//                    read once; the simplifier below is a sequential machine per line, the samples are not)
+//   simplify_kernel  one WAVE per line, lanes = samples: samples -> PathSimplifier's kept points (see the kernel)
 //   outline_kernel   one THREAD per line (all lines of the call, all CUs): samples -> PathSimplifier -> conv_stroke; the
 //                    closed outline polygons (up to MAXSUB per line) go to HBM
 //   coverage_kernel  one WORKGROUP per line at a time (persistent workgroups over a queue of ALL lines: the lines of an
@@ -54,7 +52,7 @@ struct RasterArgs {
     unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
     unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
     V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, 1 + 2 * MAXSUB
-    double* ys; long long ldl;                           // the curves' pixel y: [sample][ldl lines]
+    int* seq; int* nsimp; int force_seq;                 // per line: 1 = left to the sequential machine; points kept by simplify_kernel
     unsigned char* alpha; unsigned long long alpha_cap;
     RowRef* rows; unsigned long long rows_cap;
     Item* items;                                         // per line MAXSUB, then 4 spine items
@@ -74,30 +72,143 @@ __global__ void raster_table_kernel(int ns, int size, double* tab) {
     tab[4 * i + 3] = 0.0;
 }
 
-constexpr int PBLOCK = 64;                               // samples per thread of points_kernel
-__global__ __launch_bounds__(64) void points_kernel(RasterArgs A) {
-    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (g >= A.nlines) return;
+// ---------------------------------------------------------------------------------------------------------------
+// simplify_kernel: samples -> PathSimplifier with one WAVE per line, lanes = 64 consecutive samples.
+//
+// The simplifier is a sequential machine, but its state only changes shape when a run ends (about 60 times in 10 000
+// samples); in between, what a vertex contributes -- its distance across and along the run -- depends on the run's
+// constants alone.  So a wave evaluates 64 samples at once (the curve's beta(alpha), the axes' transform, the
+// simplifier's metrics), finds the first lane that ends the run (ballot), folds the lanes before it into the state
+// with two max-reductions (the farthest vertex forwards / backwards: strict `>` in sequence = the FIRST lane that
+// attains the maximum, if that beats the incoming one; the two `last_*` flags = whether the last folded lane is that
+// lane), performs the run's end in wave-uniform code, and goes on with the remaining lanes under the new run's constants.
+// Same operations on the same operands as the vertex-by-vertex machine (raster_device.hpp: Simplifier), so the same
+// points.  A line with a non-finite sample (b = 0 and friends: PathNanRemover breaks the path there) is left to the
+// sequential machine in outline_kernel (seq[g] = 1).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_value(double v, int lane) {          // lane: wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
+    const long long g = blockIdx.x;
+    const int lane = threadIdx.x;
     const long long gl = A.line0 + g;
     const double la = A.l[3 * gl], lb = A.l[3 * gl + 1], lc = A.l[3 * gl + 2];
     const int size = A.size, ns = A.samples;
     const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
-    const int i0 = blockIdx.y * PBLOCK, i1 = i0 + PBLOCK < ns ? i0 + PBLOCK : ns;
-    double* dst = A.ys + (size_t)i0 * A.ldl + g;
-    for (int i = i0; i < i1; i += 4) {                    // four independent division / atan chains side by side
-        double y[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int iu = i + u < ns ? i + u : ns - 1;
-            const double sa = A.tab[4 * iu + 1], ca = A.tab[4 * iu + 2];      // (wave-uniform: scalar loads)
-            double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
-            be *= -1;                                                         // :65
-            y[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
+    V2* out = A.simp + (size_t)g * MAXS;
+    if (A.force_seq) { if (lane == 0) A.seq[g] = 1; return; }
+    // the machine's state (every lane holds the same values)
+    const double thr2 = (1.0 / 9.0) * (1.0 / 9.0);
+    double lastx = 0, lasty = 0, origdx = 0, origdy = 0, orig_norm2 = 0, fwd_max = 0, bwd_max = 0, nextx = 0, nexty = 0, nbx = 0,
+           nby = 0, startx = 0, starty = 0;
+    bool last_fwd = false, last_bwd = false, clipped = true;
+    int n = 0, overflow = 0;
+    auto emit = [&](double x, double y) {
+        if (n < MAXS) { if (lane == 0) { out[n].x = x; out[n].y = y; } ++n; } else overflow = 1;
+    };
+    for (int c0 = 0; c0 < ns; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < ns;
+        const int ic = valid ? i : ns - 1;
+        const double sa = A.tab[4 * ic + 1], ca = A.tab[4 * ic + 2], x = A.tab[4 * ic];
+        double be = -atan((-la * sa - lc * ca) / lb);                         // sphere_mapping.py:63
+        be *= -1;                                                             // :65
+        const double y = size - (be - lo_a) / (hi_a - lo_a) * size;
+        if (__ballot(valid && (!(y == y) || isinf(y))) != 0ull) {            // PathNanRemover's business: the sequential machine
+            if (lane == 0) A.seq[g] = 1;
+            return;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i + u < i1) dst[(size_t)(i - i0 + u) * A.ldl] = y[u];
+        unsigned long long pending = __ballot(valid);
+        if (c0 == 0) {                                                        // move_to
+            lastx = lane_value(x, 0); lasty = lane_value(y, 0);
+            orig_norm2 = 0.0; bwd_max = 0.0; clipped = true;
+            pending &= ~1ull;
+        }
+        while (pending != 0ull) {
+            if (uniform(orig_norm2 == 0.0)) {                                 // the run's first segment
+                const int j = uniform(__builtin_ctzll(pending));
+                const double px = lane_value(x, j), py = lane_value(y, j);
+                if (clipped) { emit(lastx, lasty); clipped = false; }
+                origdx = px - lastx; origdy = py - lasty;
+                orig_norm2 = origdx * origdx + origdy * origdy;
+                fwd_max = orig_norm2; bwd_max = 0.0; last_fwd = true; last_bwd = false;
+                startx = lastx; starty = lasty;
+                nextx = lastx = px; nexty = lasty = py;
+                pending &= ~(1ull << j);
+                continue;
+            }
+            // metrics of every lane's vertex under the run's constants (Simplifier::metrics)
+            const double totdx = x - startx, totdy = y - starty;
+            const double totdot = origdx * totdx + origdy * totdy;
+            const double paradx = totdot * origdx / orig_norm2, parady = totdot * origdy / orig_norm2;
+            const double perpdx = totdx - paradx, perpdy = totdy - parady;
+            const double perp2 = perpdx * perpdx + perpdy * perpdy;
+            const double para2 = paradx * paradx + parady * parady;
+            const bool mine = (pending >> lane) & 1ull;
+            const unsigned long long brk = __ballot(mine && !(perp2 < thr2));
+            const int jb = brk ? uniform(__builtin_ctzll(brk)) : 64;
+            const unsigned long long inrun = jb < 64 ? (pending & ((1ull << jb) - 1ull)) : pending;
+            if (inrun != 0ull) {
+                const bool in = (inrun >> lane) & 1ull;
+                const int jl = uniform(63 - __builtin_clzll(inrun));          // the last vertex folded in
+                const bool fwd_el = in && totdot > 0.0, bwd_el = in && !(totdot > 0.0);
+                bool lf = false, lbk = false;
+                if (__ballot(fwd_el) != 0ull) {
+                    const double m = wave_max(fwd_el ? para2 : -1.0);
+                    if (uniform(m > fwd_max)) {
+                        const int jf = uniform(__builtin_ctzll(__ballot(fwd_el && para2 == m)));
+                        fwd_max = m; nextx = lane_value(x, jf); nexty = lane_value(y, jf);
+                        lf = jf == jl;
+                    }
+                }
+                if (__ballot(bwd_el) != 0ull) {
+                    const double m = wave_max(bwd_el ? para2 : -1.0);
+                    if (uniform(m > bwd_max)) {
+                        const int jk = uniform(__builtin_ctzll(__ballot(bwd_el && para2 == m)));
+                        bwd_max = m; nbx = lane_value(x, jk); nby = lane_value(y, jk);
+                        lbk = jk == jl;
+                    }
+                }
+                last_fwd = lf; last_bwd = lbk;
+                lastx = lane_value(x, jl); lasty = lane_value(y, jl);
+            }
+            if (jb < 64) {                                                    // _push: the run ends at lane jb's vertex
+                const double px = lane_value(x, jb), py = lane_value(y, jb);
+                const bool both = bwd_max > 0.0;
+                const double ax = both && last_fwd ? nbx : nextx, ay = both && last_fwd ? nby : nexty;
+                const double cx = last_fwd ? nextx : nbx, cy = last_fwd ? nexty : nby;
+                emit(ax, ay);
+                if (both) emit(cx, cy);
+                double ex = both ? cx : ax, ey = both ? cy : ay;
+                if (clipped || (!last_fwd && !last_bwd)) { emit(lastx, lasty); ex = lastx; ey = lasty; }
+                origdx = px - lastx; origdy = py - lasty;
+                orig_norm2 = origdx * origdx + origdy * origdy;
+                fwd_max = orig_norm2; last_fwd = true;
+                startx = ex; starty = ey;
+                lastx = nextx = px; lasty = nexty = py;
+                bwd_max = 0.0; last_bwd = false; clipped = false;
+                pending &= ~((2ull << jb) - 1ull);
+            } else {
+                pending = 0ull;
+            }
+        }
     }
+    // path_cmd_stop
+    if (orig_norm2 != 0.0) {
+        emit(nextx, nexty);
+        if (bwd_max > 0.0) emit(nbx, nby);
+    }
+    emit(lastx, lasty);
+    if (lane == 0) { A.seq[g] = 0; A.nsimp[g] = n | (overflow ? 0x40000000 : 0); }
 }
 
 __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
@@ -141,19 +252,36 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         }
         sm.n = 0;
     };
-    // OG samples are fetched together (points_kernel made them; one coalesced 512-byte row per sample and wave), then fed
-    // to the simplifier as a group (feed_group: the simplifier's own divisions side by side)
-    constexpr int OG = 8;
-    const double* ysrc = A.ys + g;
-    for (int i0 = 0; i0 < ns; i0 += OG) {
-        double xs[OG], ys[OG];
+    if (A.seq[g]) {
+        // the sequential machine (lines with non-finite samples; VPK_RASTER_SEQUENTIAL=1: every line): OG samples are
+        // evaluated side by side (independent division / atan chains), then fed to the simplifier as a group
+        const double la = A.l[3 * gl], lb = A.l[3 * gl + 1], lc = A.l[3 * gl + 2];
+        const double lo_a = -PI_D / 2, hi_a = PI_D / 2;
+        constexpr int OG = 4;
+        for (int i0 = 0; i0 < ns; i0 += OG) {
+            double xs[OG], ys[OG];
 #pragma unroll
-        for (int u = 0; u < OG; ++u) {
-            const int i = i0 + u < ns ? i0 + u : ns - 1;
-            xs[u] = A.tab[4 * i];
-            ys[u] = ysrc[(size_t)i * A.ldl];
+            for (int u = 0; u < OG; ++u) {
+                const int i = i0 + u < ns ? i0 + u : ns - 1;
+                const double sa = A.tab[4 * i + 1], ca = A.tab[4 * i + 2];
+                double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
+                be *= -1;                                                         // :65
+                xs[u] = A.tab[4 * i];
+                ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
+            }
+            feed_group<OG>(sm, xs, ys, ns - i0, flush);
         }
-        feed_group<OG>(sm, xs, ys, ns - i0, flush);
+    } else {
+        // simplify_kernel kept the line's points: one finished path
+        const int k = A.nsimp[g];
+        sm.n = k & 0xffff;
+        if (k & 0x40000000) dummy |= FLAG_OVERFLOW;
+        sm.have = false;
+        if (sm.n >= 2) {
+            stroke_outline(sp, sm.n, width_px, o);
+            if (o.n >= 3) { pt[1] = 0; pt[2] = o.n; npoly = 1; }
+        }
+        sm.n = 0;
     }
     if (sm.have) flush();
     pt[0] = npoly;
@@ -424,7 +552,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
     const long long max_lines = 49152;
     const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 + MAXSUB * sizeof(Item) +
-                            16384 + (size_t)(size + 8) * sizeof(RowRef) + (size_t)samples * sizeof(double);
+                            16384 + (size_t)(size + 8) * sizeof(RowRef) + 8;
     long long chunk_lines = 0;
     for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
         b1 = b0 + 1;
@@ -435,7 +563,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
     const size_t tb = vpk::em_align((size_t)samples * 4 * 8, 256);
     const size_t nl = (size_t)chunk_lines + 4;
-    const size_t need = ob + fb + tb + nl * per_line + 64 * (size_t)samples * sizeof(double) + 8192;
+    const size_t need = ob + fb + tb + nl * per_line + 8192;
     const void* had = h->raster_hdr;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
@@ -461,8 +589,9 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround
     A.out = out; A.ctr = (int*)(base + ob); A.bump = (unsigned long long*)(base + ob + 64); A.flags = (unsigned*)(base + ob + 256);
     char* p = base + ob + fb + tb;
-    A.ldl = (long long)((nl + 63) / 64 * 64);
-    A.ys = (double*)p; p += vpk::em_align((size_t)samples * A.ldl * sizeof(double), 256);
+    A.seq = (int*)p; p += vpk::em_align(nl * 4, 256);
+    A.nsimp = (int*)p; p += vpk::em_align(nl * 4, 256);
+    A.force_seq = getenv("VPK_RASTER_SEQUENTIAL") != nullptr;   // development / tests: every line through the sequential machine
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
     A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
@@ -485,7 +614,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         hipEvent_t ev[5] = {};
         if (times) for (int q = 0; q < 5; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
         if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
-        hipLaunchKernelGGL(points_kernel, dim3((unsigned)((A.nlines + 63) / 64), (samples + PBLOCK - 1) / PBLOCK), dim3(64), 0, h->stream, A);
+        hipLaunchKernelGGL(simplify_kernel, dim3((unsigned)A.nlines), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[4], h->stream));
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
@@ -504,7 +633,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
             VPK_HIP(h, hipMemcpy(bump, A.bump, 16, hipMemcpyDeviceToHost));
             int dbg[16];
             VPK_HIP(h, hipMemcpy(dbg, A.ctr, sizeof(dbg), hipMemcpyDeviceToHost));
-            fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: points %.2f + outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
+            fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: simplify %.2f + outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
                     "and %.0f rows per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
                     A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)bump[0] / nt, (double)bump[1] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
                     dbg[11] * 1e-5);
