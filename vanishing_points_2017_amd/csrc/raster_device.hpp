@@ -299,7 +299,7 @@ RDEV void stroke_outline(V2* p, int n, double width, Outline& o) {
 // polygon's edges are walked twice: pass 1 (BOUNDS) only records every row's first / last cell, a prefix sum over the rows
 // packs the rows' cell ranges into the pool, pass 2 (POOL) adds the cells there with LDS atomics.  A polygon whose ranges
 // do not fit the pool (GLOBAL) uses image-sized accumulators in HBM / L2 with global atomics instead.
-constexpr int POOL = 7936;              // cells (cover, area) of one polygon in LDS: 62 KB (two workgroups per CU)
+constexpr int POOL = 7040;              // cells (cover, area) of one polygon in LDS: 55 KB (two workgroups per CU)
 enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
 
 typedef RS_LDS int* lds_int_ptr;

@@ -52,6 +52,7 @@ struct RasterArgs {
     unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
     unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
     V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, 1 + 2 * MAXSUB
+    int probe;                                           // VPK_RASTER_TIMES: workgroup 0 of coverage_kernel times its phases
     int* seq; int* nsimp; int force_seq;                 // per line: 1 = left to the sequential machine; points kept by simplify_kernel
     unsigned char* alpha; unsigned long long alpha_cap;
     RowRef* rows; unsigned long long rows_cap;
@@ -293,13 +294,21 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
     }
 }
 
-// cells of one polygon -> coverage bytes.  Same passes as before (bounds, row scan, cells into the LDS pool); the sweep
-// writes alpha bytes in the pool's packing instead of blending.
-__device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int size, int* s_total, long long* s_base,
-                                 unsigned short* s_eoff, const RasterArgs& A, Item* item) {
-    const bool probe = threadIdx.x == 0 && blockIdx.x == 0;
+// cells of one polygon -> coverage bytes: bounds pass, row scan, cells into the LDS pool, sweep -> alpha bytes in the pool's
+// packing.  A workgroup spends most of a polygon waiting -- on barriers and on memory round trips -- so the round trips
+// are kept off the critical path: the vertices are fetched once (LDS), a thread keeps its work item between the two
+// passes, the pools' space comes from ONE atomic, the next line's number is requested a polygon ahead.
+constexpr int LVERT = 256;                               // vertices of a polygon held in LDS (typical: 60-200)
+constexpr unsigned long long BUMP_ROWS_SHIFT = 40;       // the call's bump counter: alpha bytes | row refs << 40
+struct CovShared {
+    int* total; long long* base; unsigned short* eoff; V2* vert; int* tail;
+};
+__device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int size, const CovShared& S, const RasterArgs& A,
+                                 Item* item) {
+    const bool probe = A.probe && threadIdx.x == 0 && blockIdx.x == 0;
     long long tp = probe ? wall_clock64() : 0;
     auto lap = [&](int slot) { if (probe) { const long long now = wall_clock64(); atomicAdd(A.ctr + 8 + slot, (int)(now - tp)); tp = now; } };
+    unsigned short* s_eoff = S.eoff;
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = sink;
     // Work items = (edge, share of its rows).  An outline has ~120 edges of which most cross one to three rows and a few
@@ -307,8 +316,11 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     // cell, so an edge gets one share per ROWS_PER_ITEM rows it crosses -- not a fixed number of shares (with 4 RT / n
     // shares per edge, 9 in 10 items were empty and the set-up was most of the kernel).  The shares' offsets: one wave's scan.
     constexpr int ROWS_PER_ITEM = 4;
+    const bool inlds = n <= LVERT;
     for (int k = threadIdx.x; k < n; k += RT) {
-        const double ya = v[k].y, yb = v[k + 1 < n ? k + 1 : 0].y;
+        const V2 a = v[k];
+        const double ya = a.y, yb = v[k + 1 < n ? k + 1 : 0].y;
+        if (inlds) { S.vert[k] = a; if (k == 0) S.vert[n] = a; }
         double lo = ya < yb ? ya : yb, hi = ya < yb ? yb : ya;
         lo = lo > 0.0 ? lo : 0.0;
         hi = hi < (double)size ? hi : (double)size;
@@ -332,17 +344,23 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     }
     __syncthreads();
     const int items = s_eoff[n];
-    auto item_edge = [&](int it) {                        // the edge whose shares contain item `it`: last k with eoff[k] <= it
+    struct Work { int part, nparts; V2 a, b; };
+    auto work_item = [&](int it) {                        // the edge whose shares contain item `it`: last k with eoff[k] <= it
         int lo = 0, hi = n;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)s_eoff[mid] <= it) lo = mid; else hi = mid; }
-        return lo;
+        Work w;
+        w.part = it - s_eoff[lo];
+        w.nparts = s_eoff[lo + 1] - s_eoff[lo];
+        if (inlds) { w.a = S.vert[lo]; w.b = S.vert[lo + 1]; }
+        else { w.a = v[lo]; w.b = v[lo + 1 < n ? lo + 1 : 0]; }
+        return w;
     };
+    Work mine = {};                                       // this thread's first item: the same in both passes
+    if ((int)threadIdx.x < items) mine = work_item(threadIdx.x);
     for (int it = threadIdx.x; it < items; it += RT) {    // pass 1: the rows' cell ranges
-        const int k = item_edge(it);
-        ec.part = it - s_eoff[k];
-        ec.nparts = s_eoff[k + 1] - s_eoff[k];
-        const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
-        ec.edge<BOUNDS>(a.x, a.y, b.x, b.y);
+        const Work w = it == (int)threadIdx.x ? mine : work_item(it);
+        ec.part = w.part; ec.nparts = w.nparts;
+        ec.edge<BOUNDS>(w.a.x, w.a.y, w.b.x, w.b.y);
     }
     __syncthreads();
     lap(0);
@@ -372,20 +390,22 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
             ymax = b > ymax ? b : ymax;
         }
         if (threadIdx.x == 63) {
-            s_total[0] = incl; s_total[1] = ymin; s_total[2] = ymax;
+            S.total[0] = incl; S.total[1] = ymin; S.total[2] = ymax;
             long long ab = -1, rb = -1;
-            if (incl > 0) {                               // space in the call's coverage pools (bump allocation)
-                ab = (long long)atomicAdd(A.bump, (unsigned long long)incl);
-                rb = (long long)atomicAdd(A.bump + 1, (unsigned long long)(ymax - ymin + 1));
-                if ((unsigned long long)ab + incl > A.alpha_cap || (unsigned long long)rb + (ymax - ymin + 1) > A.rows_cap) ab = -1;
+            if (incl > 0) {                               // space in the call's coverage pools (bump allocation, one atomic)
+                const unsigned long long nrows = (unsigned long long)(ymax - ymin + 1);
+                const unsigned long long old = atomicAdd(A.bump, (unsigned long long)incl | (nrows << BUMP_ROWS_SHIFT));
+                ab = (long long)(old & ((1ull << BUMP_ROWS_SHIFT) - 1ull));
+                rb = (long long)(old >> BUMP_ROWS_SHIFT);
+                if ((unsigned long long)ab + incl > A.alpha_cap || (unsigned long long)rb + nrows > A.rows_cap) ab = -1;
             }
-            s_base[0] = ab; s_base[1] = rb;
+            S.base[0] = ab; S.base[1] = rb;
         }
     }
     __syncthreads();
     lap(1);
-    const int total = s_total[0], ymin = s_total[1], ymax = s_total[2];
-    const long long ab = s_base[0], rb = s_base[1];
+    const int total = S.total[0], ymin = S.total[1], ymax = S.total[2];
+    const long long ab = S.base[0], rb = S.base[1];
     const bool ok = ab >= 0;                              // (a polygon past the call's HBM pools is dropped and flagged)
     // The pool holds the cell ranges of a BAND of rows at a time: all touched rows when they fit (the usual case), else as
     // many consecutive rows as fit -- a curve with an interior extremum crosses the rows beside it twice, far apart, and a
@@ -400,41 +420,67 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         band.blo = ys; band.bhi = ye; band.boff = boff;
         ec.c = band;
         for (int it = threadIdx.x; it < items; it += RT) {    // pass 2: the cells of the band's rows
-            const int k = item_edge(it);
-            ec.part = it - s_eoff[k];
-            ec.nparts = s_eoff[k + 1] - s_eoff[k];
-            const V2 a = v[k], b = v[k + 1 < n ? k + 1 : 0];
-            ec.edge<POOLED>(a.x, a.y, b.x, b.y);
+            const Work w = it == (int)threadIdx.x ? mine : work_item(it);
+            ec.part = w.part; ec.nparts = w.nparts;
+            ec.edge<POOLED>(w.a.x, w.a.y, w.b.x, w.b.y);
         }
         __syncthreads();
         lap(2);
-        for (int y = ys + threadIdx.x; y < ye; y += RT) {
-            const int lo = sink.rowmin[y], hi = sink.rowmax[y];
-            RowRef r;
-            r.off = sink.rowoff[y]; r.xmin = (short)(lo - 1); r.len = (short)(hi >= lo ? hi - lo + 1 : 0);
-            if (hi < lo) { r.xmin = 0; r.len = 0; }
-            A.rows[rb + (y - ymin)] = r;
-            if (hi >= lo) {
-                lds_int_ptr pc = sink.pcover + sink.rowoff[y] - boff;
-                lds_int_ptr pa = sink.parea + sink.rowoff[y] - boff;
-                int R = 0;
-                for (int q = 0; q <= hi - lo; ++q) {          // the per-pixel form of sweep_scanline (see blend_kernel)
-                    const int c = pc[q], a = pa[q];
-                    pa[q] = 0;
-                    R += c;
-                    unsigned al = 0;
-                    if (a) al = calc_alpha((R << (SHIFT + 1)) - a);
-                    else if (q < hi - lo) al = calc_alpha(R << (SHIFT + 1));
-                    pc[q] = (int)al;                          // the row's alphas stay in the pool ...
+        // The sweep (the per-pixel form of sweep_scanline, see blend_kernel) over the band's pool entries, which are the
+        // rows' cell ranges back to back: every thread takes an equal run of consecutive entries -- not a row: rows are 1
+        // to 500 entries long --, the running cover at the start of its run being the covers of its row before it.
+        const int last = ye - 1;
+        const int bend = sink.rowoff[last] + (sink.rowmax[last] >= sink.rowmin[last] ? sink.rowmax[last] - sink.rowmin[last] + 1 : 0);
+        const int E = bend - boff, C = (E + RT - 1) / RT;
+        const int q0 = threadIdx.x * C, q1 = q0 + C < E ? q0 + C : E;
+        int y = ys, row_lo = 0, row_hi = 0;               // the row of entry q0: pool entries [row_lo, row_hi)
+        auto row_span = [&](int yy) {
+            const int len = sink.rowmax[yy] >= sink.rowmin[yy] ? sink.rowmax[yy] - sink.rowmin[yy] + 1 : 0;
+            row_lo = sink.rowoff[yy] - boff; row_hi = row_lo + len;
+        };
+        if (q0 < q1) {
+            int lo = ys, hi = ye;                         // last row whose offset is <= q0 (an empty row shares its successor's)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sink.rowoff[mid] - boff <= q0) lo = mid; else hi = mid; }
+            y = lo;
+            row_span(y);
+            int tail = 0, started = 0, yy = y, rhi = row_hi;
+            for (int q = q0; q < q1; ++q) {
+                if (q == rhi) {                           // the next non-empty row starts at this entry
+                    do { ++yy; rhi = sink.rowoff[yy] - boff + (sink.rowmax[yy] >= sink.rowmin[yy] ? sink.rowmax[yy] - sink.rowmin[yy] + 1 : 0); } while (q == rhi);
+                    tail = 0; started = 1;
                 }
+                tail += sink.pcover[q];
             }
+            if (q0 == row_lo) started = 1;
+            S.tail[2 * threadIdx.x] = tail; S.tail[2 * threadIdx.x + 1] = started;
+        }
+        __syncthreads();
+        if (q0 < q1) {
+            int R = 0;
+            if (q0 != row_lo)
+                for (int u = (int)threadIdx.x - 1; u >= 0; --u) { R += S.tail[2 * u]; if (S.tail[2 * u + 1]) break; }
+            for (int q = q0; q < q1; ++q) {
+                if (q == row_hi) { do { ++y; row_span(y); } while (q == row_hi); R = 0; }
+                const int c = sink.pcover[q], a = sink.parea[q];
+                sink.parea[q] = 0;
+                R += c;
+                unsigned al = 0;
+                if (a) al = calc_alpha((R << (SHIFT + 1)) - a);
+                else if (q + 1 < row_hi) al = calc_alpha(R << (SHIFT + 1));
+                sink.pcover[q] = (int)al;                 // the alphas stay in the pool ...
+            }
+        }
+        for (int yy = ys + threadIdx.x; yy < ye; yy += RT) {
+            const int lo = sink.rowmin[yy], hi = sink.rowmax[yy];
+            RowRef r;
+            r.off = sink.rowoff[yy]; r.xmin = (short)(lo - 1); r.len = (short)(hi >= lo ? hi - lo + 1 : 0);
+            if (hi < lo) { r.xmin = 0; r.len = 0; }
+            A.rows[rb + (yy - ymin)] = r;
         }
         __syncthreads();
         {   // ... and leave it in one coalesced copy (the pool is zero again afterwards)
-            const int last = ye - 1;
-            const int bend = sink.rowoff[last] + (sink.rowmax[last] >= sink.rowmin[last] ? sink.rowmax[last] - sink.rowmin[last] + 1 : 0);
             unsigned char* dst = A.alpha + ab + boff;
-            for (int q = threadIdx.x; q < bend - boff; q += RT) { dst[q] = (unsigned char)sink.pcover[q]; sink.pcover[q] = 0; }
+            for (int q = threadIdx.x; q < E; q += RT) { dst[q] = (unsigned char)sink.pcover[q]; sink.pcover[q] = 0; }
         }
         __syncthreads();
         lap(3);
@@ -444,47 +490,55 @@ __device__ void polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     if (threadIdx.x == 0) {
         item->alpha_base = ok ? ab : 0; item->row_base = ok ? rb : 0;
         item->ymin = ok ? ymin : 0; item->ymax = ok ? ymax : -1;
-        (void)total;
     }
     __syncthreads();
+    return ok || total == 0;
 }
 
 __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 waves per SIMD: two workgroups per CU
     __shared__ int s_rowmin[1024], s_rowmax[1024], s_rowoff[1024];
     __shared__ int s_pcover[POOL], s_parea[POOL];
-    __shared__ int s_line, s_total[4];
+    __shared__ int s_next, s_total[4];
     __shared__ unsigned short s_eoff[MAXV + 2];          // first work item of every edge of the polygon at hand
+    __shared__ V2 s_vert[LVERT + 1];                     // its vertices (closed: [n] = [0])
     __shared__ long long s_base[2];
     const int size = A.size;
     CellSink sink;
     sink.cover = nullptr; sink.area = nullptr;
     sink.rowmin = (lds_int_ptr)s_rowmin; sink.rowmax = (lds_int_ptr)s_rowmax; sink.rowoff = (lds_int_ptr)s_rowoff; sink.size = size;
     sink.pcover = (lds_int_ptr)s_pcover; sink.parea = (lds_int_ptr)s_parea;
+    CovShared S;
+    S.total = s_total; S.base = s_base; S.eoff = s_eoff; S.vert = s_vert;
+    __shared__ int s_tail[2 * RT];                       // the sweep's per-thread partial sums
+    S.tail = s_tail;
     for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; }
     for (int q = threadIdx.x; q < POOL; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
+    if (threadIdx.x == 0) s_next = atomicAdd(A.ctr, 1);
     __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) s_line = atomicAdd(A.ctr, 1);
-        __syncthreads();
-        const long long g = s_line;
+        const long long g = __builtin_amdgcn_readfirstlane(s_next);
         __syncthreads();
         if (g >= A.nlines + 4) break;
+        int nx = 0;
+        if (threadIdx.x == 0) nx = atomicAdd(A.ctr, 1);  // the line after this one: the round trip runs beside the work below
         const int* pt = A.polys + g * (1 + 2 * MAXSUB);
         const int npoly = pt[0];
         for (int q = 0; q < MAXSUB; ++q) {
             Item* item = A.items + g * MAXSUB + q;
             if (q < npoly) {
-                polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, s_total, s_base, s_eoff, A, item);
-                if (item->ymax < item->ymin && threadIdx.x == 0 && g < A.nlines) {     // dropped: tell the line's image
+                const bool ok = polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, S, A, item);
+                if (!ok && threadIdx.x == 0 && g < A.nlines) {                      // dropped: tell the line's image
                     int lo = 0, hi = A.batch;
                     const long long gl = A.line0 + g;
                     while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (A.offsets[A.first_image + mid] <= gl) lo = mid; else hi = mid; }
-                    if (s_total[0] > 0) atomicOr(A.flags + A.first_image + lo, FLAG_OVERFLOW);
+                    atomicOr(A.flags + A.first_image + lo, FLAG_OVERFLOW);
                 }
             } else if (threadIdx.x == 0) {
                 item->alpha_base = 0; item->row_base = 0; item->ymin = 0; item->ymax = -1;
             }
         }
+        if (threadIdx.x == 0) s_next = nx;
+        __syncthreads();
     }
 }
 
@@ -492,7 +546,7 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
 // calculate_alpha((R << 9) - area), one without (no cell, or a cell of a vertical edge on the pixel boundary) lies in the
 // span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
 // coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
-constexpr int BROWS = 64, BSEG = 4;                       // image rows per workgroup; column segments per row (one wave each)
+constexpr int BROWS = 64, BSEG = 8;                       // image rows per workgroup; column segments per row (one wave each)
 __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4]
     const int size = A.size, ldp = (size + 3) & ~3;
@@ -611,6 +665,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         VPK_HIP(h, hipMemsetAsync(base + ob, 0, 256, h->stream));          // queue + bump counters of this chunk
         const long long nt = A.nlines + 4;
         const bool times = getenv("VPK_RASTER_TIMES") != nullptr;      // development: per-kernel device time
+        A.probe = times ? 1 : 0;
         hipEvent_t ev[5] = {};
         if (times) for (int q = 0; q < 5; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
         if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
@@ -635,7 +690,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
             VPK_HIP(h, hipMemcpy(dbg, A.ctr, sizeof(dbg), hipMemcpyDeviceToHost));
             fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: simplify %.2f + outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
                     "and %.0f rows per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
-                    A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)bump[0] / nt, (double)bump[1] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
+                    A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)(bump[0] & ((1ull << BUMP_ROWS_SHIFT) - 1ull)) / nt, (double)(bump[0] >> BUMP_ROWS_SHIFT) / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
                     dbg[11] * 1e-5);
             for (int q = 0; q < 5; ++q) (void)hipEventDestroy(ev[q]);
         }
