@@ -329,10 +329,21 @@ template <int MODE> RDEV_INLINE void cell_add(const CellSink& s, int ex, int ey,
         if (a) RS_ATOMIC_ADD_GLOBAL(s.area + idx, a);
     }
 }
-template <int MODE> RDEV_NOINLINE void cell_hline(const CellSink s, int ey, int x1, int y1, int x2, int y2) {
+// render_hline: the cells of one row's piece of an edge.  BOUNDS: only the row's first / last cell are wanted, and a
+// superset will do (an entry of the row's range that no cell is added to sweeps to alpha 0): the piece's two end cells.
+template <int MODE> RDEV_INLINE void cell_hline(const CellSink& s, int ey, int x1, int y1, int x2, int y2) {
     int ex1 = x1 >> SHIFT;
     const int ex2 = x2 >> SHIFT, fx1 = x1 & (SUB - 1), fx2 = x2 & (SUB - 1);
     if (y1 == y2) return;
+    if (MODE == BOUNDS) {
+        if (ey < 0 || ey >= s.size) return;
+        int lo = ex1 < ex2 ? ex1 : ex2, hi = ex1 < ex2 ? ex2 : ex1;
+        if (hi < -1 || lo > s.size) return;
+        lo = lo < -1 ? -1 : lo; hi = hi > s.size ? s.size : hi;
+        RS_ATOMIC_MIN(s.rowmin + ey, lo + 1);
+        RS_ATOMIC_MAX(s.rowmax + ey, hi + 1);
+        return;
+    }
     if (ex1 == ex2) {
         const int delta = y2 - y1;
         cell_add<MODE>(s, ex1, ey, delta, (fx1 + fx2) * delta);
@@ -366,68 +377,47 @@ template <int MODE> RDEV_NOINLINE void cell_hline(const CellSink s, int ey, int 
 // edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
 // the running remainder wraps); after k middle rows the remainder has wrapped floor((mod0 + k rem) / dy) times, so
 // any row's (x_from, x_to) follows in closed form and a thread can start in the middle of the edge with exactly the
-// state the sequential walk has there.
-template <int MODE> RDEV_NOINLINE void cell_line(const CellSink s, int x1, int y1, int x2, int y2, int part, int nparts) {
+// state the sequential walk has there.  (AGG's separate code for vertical edges gives the cells the general formulas
+// give with dx = 0 -- a row's piece with x_from = x_to is one cell with area 2 fx delta --, so there is one path here.)
+// Everything is inlined into ONE call site per pass (the pieces of an edge are looped over, EdgeClip::edge): called
+// functions cost this kernel scratch round trips for their saved registers, several per item.
+template <int MODE> RDEV_INLINE void cell_line(const CellSink& s, int x1, int y1, int x2, int y2, int part, int nparts) {
     const int dx = x2 - x1;
     int dy = y2 - y1;
     const int ey1 = y1 >> SHIFT, ey2 = y2 >> SHIFT, fy1 = y1 & (SUB - 1), fy2 = y2 & (SUB - 1);
-    if (ey1 == ey2) { if (part == 0) cell_hline<MODE>(s, ey1, x1, fy1, x2, fy2); return; }
     const int incr = dy < 0 ? -1 : 1;
     const int nrows = (ey2 - ey1) * incr + 1;
-    const int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
+    int r0 = (int)((long long)part * nrows / nparts), r1 = (int)((long long)(part + 1) * nrows / nparts);
+    if (nrows == 1) { r0 = 0; r1 = part == 0 ? 1 : 0; }
     if (r0 >= r1) return;
     const int first = dy < 0 ? 0 : SUB;
-    if (dx == 0) {
-        const int ex = x1 >> SHIFT;
-        const int two_fx = (x1 - (ex << SHIFT)) << 1;
-        for (int r = r0; r < r1; ++r) {
-            int delta;
-            if (r == 0) delta = first - fy1;
-            else if (r == nrows - 1) delta = fy2 - SUB + first;
-            else delta = first + first - SUB;
-            cell_add<MODE>(s, ex, ey1 + r * incr, delta, two_fx * delta);
-        }
-        return;
-    }
     // (32-bit like AGG: |dx|, dy <= 1024 px x 256, so 256 |dx| and mod0 + k rem stay below 2^29)
-    int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
-    if (dy < 0) dy = -dy;
-    int delta0 = p / dy, mod0 = p % dy;
-    if (mod0 < 0) { --delta0; mod0 += dy; }
-    const int x_from0 = x1 + delta0;
-    p = SUB * dx;
-    int lift = p / dy, rem = p % dy;
-    if (rem < 0) { --lift; rem += dy; }
-    int xf = 0;
-    bool have = false;
+    int x_from0 = x2, lift = 0, rem = 0, mod0 = 0;
+    if (nrows > 1) {
+        int p = dy < 0 ? fy1 * dx : (SUB - fy1) * dx;
+        if (dy < 0) dy = -dy;
+        int delta0 = p / dy;
+        mod0 = p % dy;
+        if (mod0 < 0) { --delta0; mod0 += dy; }
+        x_from0 = x1 + delta0;
+        p = SUB * dx;
+        lift = p / dy; rem = p % dy;
+        if (rem < 0) { --lift; rem += dy; }
+    } else {
+        dy = 1;
+    }
+    int xf = r0 >= 1 ? x_from0 + (r0 - 1) * lift + (mod0 + (r0 - 1) * rem) / dy : x1;
     for (int r = r0; r < r1; ++r) {
-        if (r == 0) { cell_hline<MODE>(s, ey1, x1, fy1, x_from0, first); continue; }
-        const int j = r - 1;                              // middle row index (the last row is middle row nrows - 2)
-        if (!have) { xf = x_from0 + j * lift + (mod0 + j * rem) / dy; have = true; }
-        if (r == nrows - 1) { cell_hline<MODE>(s, ey2, xf, SUB - first, x2, fy2); continue; }
-        const int xt = x_from0 + (j + 1) * lift + (mod0 + (j + 1) * rem) / dy;
-        cell_hline<MODE>(s, ey1 + r * incr, xf, SUB - first, xt, first);
+        // the row's piece: (row, x and y-fraction where the edge enters it, x and y-fraction where it leaves)
+        const bool head = r == 0, tail = r == nrows - 1;
+        const int xt = tail ? x2 : (head ? x_from0 : x_from0 + r * lift + (mod0 + r * rem) / dy);
+        const int ya = head ? fy1 : SUB - first, yb = tail ? fy2 : first;
+        cell_hline<MODE>(s, ey1 + r * incr, xf, ya, xt, yb);
         xf = xt;
     }
 }
 
 // rasterizer_sl_clip<ras_conv_dbl>::line_to for ONE edge (the clipper's only state is the previous vertex)
-struct ClipBox { double bx1, by1, bx2, by2; };
-// line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker.  Not inlined: an
-// edge has up to three pieces at eleven call sites, and the walker inlined at all of them was 90 KB of code.
-template <int MODE> RDEV_NOINLINE void clip_y(const CellSink s, double by1, double by2, int part, int nparts,
-                                              double ax, double ay, double bx, double by, unsigned fa, unsigned fb) {
-    fa &= 10; fb &= 10;
-    double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
-    if ((fa | fb) != 0) {
-        if (fa == fb) return;                          // invisible by y
-        if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
-        if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
-        if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
-        if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
-    }
-    cell_line<MODE>(s, iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
-}
 struct EdgeClip {
     double bx1, by1, bx2, by2;
     CellSink c;
@@ -436,41 +426,61 @@ struct EdgeClip {
         return (unsigned)(x > bx2) | ((unsigned)(y > by2) << 1) | ((unsigned)(x < bx1) << 2) | ((unsigned)(y < by1) << 3);
     }
     RDEV_INLINE unsigned flags_y(double y) const { return ((unsigned)(y > by2) << 1) | ((unsigned)(y < by1) << 3); }
+    // line_clip_y: one piece of an edge (already clipped in x), clipped in y and handed to the cell walker
     template <int MODE> RDEV_INLINE void piece(double ax, double ay, double bx, double by, unsigned fa, unsigned fb) const {
-        clip_y<MODE>(c, by1, by2, part, nparts, ax, ay, bx, by, fa, fb);
+        fa &= 10; fb &= 10;
+        double tx1 = ax, ty1 = ay, tx2 = bx, ty2 = by;
+        if ((fa | fb) != 0) {
+            if (fa == fb) return;                          // invisible by y
+            if (fa & 8) { tx1 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty1 = by1; }
+            if (fa & 2) { tx1 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty1 = by2; }
+            if (fb & 8) { tx2 = ax + (by1 - ay) * (bx - ax) / (by - ay); ty2 = by1; }
+            if (fb & 2) { tx2 = ax + (by2 - ay) * (bx - ax) / (by - ay); ty2 = by2; }
+        }
+        cell_line<MODE>(c, iround(tx1 * SUB), iround(ty1 * SUB), iround(tx2 * SUB), iround(ty2 * SUB), part, nparts);
     }
     // One edge = up to three pieces after clipping in x (the pieces on the clip box's left / right side are kept: they
-    // close the winding).
+    // close the winding).  The pieces are listed first and walked by ONE loop (one inlined copy of the walker).
     template <int MODE> RDEV_INLINE void edge(double x1, double y1, double x2, double y2) const {
         const unsigned f1 = flags(x1, y1), f2 = flags(x2, y2);
         if ((f1 & 10) == (f2 & 10) && (f1 & 10) != 0) return;      // invisible by y
+        // piece i runs from (px[i], py[i]) to (px[i + 1], py[i + 1]) with y-flags pf[i], pf[i + 1] (held in scalars: an
+        // indexed array would live in scratch)
+        double px0 = x1, py0 = y1, px1 = x2, py1 = y2, px2 = 0, py2 = 0, px3 = 0, py3 = 0;
+        unsigned pf0 = f1, pf1 = f2, pf2 = 0, pf3 = 0;
+        int np = 1;
         double y3, y4;
-        unsigned f3, f4;
         switch (((f1 & 5) << 1) | (f2 & 5)) {
-        case 0: piece<MODE>(x1, y1, x2, y2, f1, f2); break;
+        case 0: break;
         case 1:
-            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            piece<MODE>(x1, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, bx2, y2, f3, f2); break;
+            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
+            px1 = bx2; py1 = y3; pf1 = flags_y(y3); px2 = bx2; py2 = y2; pf2 = f2; np = 2; break;
         case 2:
-            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            piece<MODE>(bx2, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, x2, y2, f3, f2); break;
-        case 3: piece<MODE>(bx2, y1, bx2, y2, f1, f2); break;
+            y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
+            px0 = bx2; px1 = bx2; py1 = y3; pf1 = flags_y(y3); px2 = x2; py2 = y2; pf2 = f2; np = 2; break;
+        case 3: px0 = bx2; px1 = bx2; break;
         case 4:
-            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            piece<MODE>(x1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, bx1, y2, f3, f2); break;
+            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
+            px1 = bx1; py1 = y3; pf1 = flags_y(y3); px2 = bx1; py2 = y2; pf2 = f2; np = 2; break;
         case 6:
             y3 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
-            f3 = flags_y(y3); f4 = flags_y(y4);
-            piece<MODE>(bx2, y1, bx2, y3, f1, f3); piece<MODE>(bx2, y3, bx1, y4, f3, f4); piece<MODE>(bx1, y4, bx1, y2, f4, f2); break;
+            px0 = bx2; px1 = bx2; py1 = y3; pf1 = flags_y(y3); px2 = bx1; py2 = y4; pf2 = flags_y(y4);
+            px3 = bx1; py3 = y2; pf3 = f2; np = 3; break;
         case 8:
-            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); f3 = flags_y(y3);
-            piece<MODE>(bx1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, x2, y2, f3, f2); break;
+            y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1);
+            px0 = bx1; px1 = bx1; py1 = y3; pf1 = flags_y(y3); px2 = x2; py2 = y2; pf2 = f2; np = 2; break;
         case 9:
             y3 = y1 + (bx1 - x1) * (y2 - y1) / (x2 - x1); y4 = y1 + (bx2 - x1) * (y2 - y1) / (x2 - x1);
-            f3 = flags_y(y3); f4 = flags_y(y4);
-            piece<MODE>(bx1, y1, bx1, y3, f1, f3); piece<MODE>(bx1, y3, bx2, y4, f3, f4); piece<MODE>(bx2, y4, bx2, y2, f4, f2); break;
-        case 12: piece<MODE>(bx1, y1, bx1, y2, f1, f2); break;
-        default: break;
+            px0 = bx1; px1 = bx1; py1 = y3; pf1 = flags_y(y3); px2 = bx2; py2 = y4; pf2 = flags_y(y4);
+            px3 = bx2; py3 = y2; pf3 = f2; np = 3; break;
+        case 12: px0 = bx1; px1 = bx1; break;
+        default: return;
+        }
+        for (int i = 0; i < np; ++i) {
+            const double ax = i == 0 ? px0 : (i == 1 ? px1 : px2), ay = i == 0 ? py0 : (i == 1 ? py1 : py2);
+            const double bx = i == 0 ? px1 : (i == 1 ? px2 : px3), by = i == 0 ? py1 : (i == 1 ? py2 : py3);
+            const unsigned fa = i == 0 ? pf0 : (i == 1 ? pf1 : pf2), fb = i == 0 ? pf1 : (i == 1 ? pf2 : pf3);
+            piece<MODE>(ax, ay, bx, by, fa, fb);
         }
     }
 };
