@@ -493,14 +493,19 @@ RDEV_INLINE unsigned calc_alpha(int a) {
     if (cover < 0) cover = -cover;
     return cover > 255 ? 255u : (unsigned)cover;
 }
-RDEV_INLINE unsigned blend(unsigned p, unsigned grey, unsigned a8, unsigned cover) {
-    if (a8 == 255 && cover == 255) return grey;          // opaque colour at full coverage: the pixel is copied
+RDEV_INLINE unsigned cover_alpha(unsigned a8, unsigned cover) {   // rgba8::multiply(colour alpha, cover)
     const unsigned t = a8 * cover + 128;
-    const unsigned alpha = ((t >> 8) + t) >> 8;
+    return ((t >> 8) + t) >> 8;
+}
+RDEV_INLINE unsigned blend_alpha(unsigned p, unsigned grey, unsigned alpha) {
     if (alpha == 0) return p;
     const unsigned r = p * 255u;
     const unsigned a = ((alpha + 255u) << 8) - alpha * 255u;
     return (unsigned)((((int)(grey << 8) - (int)r) * (int)alpha + (int)(r << 8)) / (int)a);
+}
+RDEV_INLINE unsigned blend(unsigned p, unsigned grey, unsigned a8, unsigned cover) {
+    if (a8 == 255 && cover == 255) return grey;          // opaque colour at full coverage: the pixel is copied
+    return blend_alpha(p, grey, cover_alpha(a8, cover));
 }
 
 }  // namespace vpk_raster

@@ -547,20 +547,33 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
 // span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
 // coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
 constexpr int BROWS = 64, BSEG = 8;                       // image rows per workgroup; column segments per row (one wave each)
+constexpr unsigned BLEND_LUT_MAX_A8 = 63;                // colour alphas up to this blend through a table (17 KB of LDS at most)
 __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
-    extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4]
+    extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4], then the tables
     const int size = A.size, ldp = (size + 3) & ~3;
     const int rr = threadIdx.x & (BROWS - 1), seg = threadIdx.x / BROWS;
     const int img_i = blockIdx.y, y = blockIdx.x * BROWS + rr;
     unsigned char* row = s_px + (size_t)rr * ldp;
+    // The blend of a white line is a function of (pixel, cover) with few distinct colour alphas (26 * cover / 255 = 0..26
+    // at the reference's alpha 0.1): two table reads instead of the blender's multiplications and its division --
+    //   amul[cover] = multiply(a8, cover),   lut[alpha][pixel] = fixed_blender_rgba_plain(pixel, white, alpha)
+    unsigned char* amul = s_px + (size_t)BROWS * ldp;
+    unsigned char* lut = amul + 256;
+    const bool tables = A.a8 <= BLEND_LUT_MAX_A8;
+    if (tables) {
+        for (int q = threadIdx.x; q < 256; q += BROWS * BSEG) amul[q] = (unsigned char)cover_alpha(A.a8, (unsigned)q);
+        for (int q = threadIdx.x; q < (int)(A.a8 + 1) * 256; q += BROWS * BSEG)
+            lut[q] = (unsigned char)blend_alpha((unsigned)q & 255u, 255u, (unsigned)q >> 8);
+    }
     // a thread owns the pixels [x0, x1) of its row: rows with long cell ranges (curves running along the row) are shared
-    // by four waves, and a workgroup keeps four waves in flight against the latency of the item -> row -> alpha loads
+    // by the waves, and a workgroup keeps them all in flight against the latency of the item -> row -> alpha loads
     const int segw = ((size + BSEG - 1) / BSEG + 3) & ~3;
     const int x0 = seg * segw, x1 = x0 + segw < size ? x0 + segw : size;
     for (int x = x0; x < x0 + segw && x < ldp; x += 4) *reinterpret_cast<unsigned*>(row + x) = 0u;
     const long long lo = A.offsets[A.first_image + img_i] - A.line0, hi = A.offsets[A.first_image + img_i + 1] - A.line0;
+    __syncthreads();
     if (y < size) {
-        auto apply = [&](const Item& it, unsigned grey, unsigned a8) {
+        auto apply = [&](const Item& it, unsigned grey, unsigned a8, bool use_tables) {
             if (y < it.ymin || y > it.ymax) return;
             const RowRef r = A.rows[it.row_base + (y - it.ymin)];
             const unsigned char* al = A.alpha + it.alpha_base + r.off;
@@ -572,16 +585,21 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int x = r.xmin + q0 + u;
-                    if (av[u]) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
+                    if (av[u]) {
+                        if (use_tables) row[x] = lut[((unsigned)amul[av[u]] << 8) | row[x]];
+                        else row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
+                    }
                 }
             }
         };
-        for (long long g = lo; g < hi; ++g)
-            for (int q = 0; q < MAXSUB; ++q) {
-                const Item it = A.items[g * MAXSUB + q];  // (wave-uniform)
-                apply(it, 255u, A.a8);
+        for (long long g = lo; g < hi; ++g) {
+            const int npoly = A.polys[g * (1 + 2 * MAXSUB)];   // (wave-uniform)
+            for (int q = 0; q < npoly; ++q) {
+                const Item it = A.items[g * MAXSUB + q];
+                if (tables) apply(it, 255u, A.a8, true); else apply(it, 255u, A.a8, false);
             }
-        for (int side = 0; side < 4; ++side) apply(A.items[(A.nlines + side) * MAXSUB], 0u, 255u);
+        }
+        for (int side = 0; side < 4; ++side) apply(A.items[(A.nlines + side) * MAXSUB], 0u, 255u, false);
     }
     __syncthreads();
     // coalesced store of the workgroup's rows
@@ -654,7 +672,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.rows = (RowRef*)p; A.rows_cap = nl * (size_t)(size + 8);
     if (!h->raster_ready) {
         VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(blend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       BROWS * 1024));
+                                       BROWS * 1024 + 256 + (BLEND_LUT_MAX_A8 + 1) * 256));
         h->raster_ready = true;
     }
     const int ldp = (size + 3) & ~3;
@@ -676,7 +694,8 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         const int wgs = (int)std::min<long long>(nt, 2ll * h->num_cu);      // two workgroups fit a CU (LDS: 76 KB each)
         hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[2], h->stream));
-        hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS * BSEG), (size_t)BROWS * ldp, h->stream, A);
+        hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS * BSEG),
+                           (size_t)BROWS * ldp + 256 + (A.a8 <= BLEND_LUT_MAX_A8 ? (size_t)(A.a8 + 1) * 256 : 0), h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[3], h->stream));
         VPK_HIP(h, hipGetLastError());
         if (times) {
