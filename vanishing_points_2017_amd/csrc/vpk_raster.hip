@@ -163,7 +163,13 @@ __global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
                 const int jl = uniform(63 - __builtin_clzll(inrun));          // the last vertex folded in
                 const bool fwd_el = in && totdot > 0.0, bwd_el = in && !(totdot > 0.0);
                 bool lf = false, lbk = false;
-                if (__ballot(fwd_el) != 0ull) {
+                // (a curve usually runs on along its run: the last folded lane is the farthest one forwards, and one ballot
+                //  says so -- "no eligible lane reaches its para2" -- without the reduction)
+                const double pl = lane_value(para2, jl);
+                const bool jl_fwd = (__ballot(fwd_el) >> jl) & 1ull;
+                if (jl_fwd && __ballot(fwd_el && para2 >= pl) == (1ull << jl)) {
+                    if (uniform(pl > fwd_max)) { fwd_max = pl; nextx = lane_value(x, jl); nexty = lane_value(y, jl); lf = true; }
+                } else if (__ballot(fwd_el) != 0ull) {
                     const double m = wave_max(fwd_el ? para2 : -1.0);
                     if (uniform(m > fwd_max)) {
                         const int jf = uniform(__builtin_ctzll(__ballot(fwd_el && para2 == m)));
@@ -573,9 +579,13 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     const long long lo = A.offsets[A.first_image + img_i] - A.line0, hi = A.offsets[A.first_image + img_i + 1] - A.line0;
     __syncthreads();
     if (y < size) {
-        auto apply = [&](const Item& it, unsigned grey, unsigned a8, bool use_tables) {
-            if (y < it.ymin || y > it.ymax) return;
-            const RowRef r = A.rows[it.row_base + (y - it.ymin)];
+        auto fetch_row = [&](const Item& it) {            // the item's entry for this thread's row (len 0: not touched)
+            RowRef r;
+            r.off = 0; r.xmin = 0; r.len = 0;
+            if (y >= it.ymin && y <= it.ymax) r = A.rows[it.row_base + (y - it.ymin)];
+            return r;
+        };
+        auto apply_row = [&](const Item& it, const RowRef r, unsigned grey, unsigned a8, bool use_tables) {
             const unsigned char* al = A.alpha + it.alpha_base + r.off;
             const int qlo = x0 - r.xmin > 0 ? x0 - r.xmin : 0, qhi = x1 - r.xmin < r.len ? x1 - r.xmin : r.len;
             for (int q0 = qlo; q0 < qhi; q0 += 8) {       // eight bytes requested together
@@ -592,14 +602,35 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
                 }
             }
         };
+        // The image's lines in order.  A line costs a chain of round trips (polygon count and item: scalar loads; the
+        // row's entry; its alpha bytes), and the blend order forbids working on two lines at once -- but not FETCHING
+        // ahead: the scalars are requested two lines ahead, the row entry one line ahead (it is in flight while the
+        // current line's bytes are fetched and blended).
+        const Item none = {0, 0, 0, -1};
+        auto line_head = [&](long long g, int& np, Item& it) {
+            np = 0; it = none;
+            if (g < hi) { np = A.polys[g * (1 + 2 * MAXSUB)]; if (np > 0) it = A.items[g * MAXSUB]; }   // (wave-uniform)
+        };
+        int n1, n2, n3;
+        Item i1, i2, i3;
+        line_head(lo, n1, i1);
+        line_head(lo + 1, n2, i2);
+        RowRef r1 = fetch_row(i1);
         for (long long g = lo; g < hi; ++g) {
-            const int npoly = A.polys[g * (1 + 2 * MAXSUB)];   // (wave-uniform)
-            for (int q = 0; q < npoly; ++q) {
+            line_head(g + 2, n3, i3);
+            const RowRef r2 = fetch_row(i2);
+            if (tables) apply_row(i1, r1, 255u, A.a8, true); else apply_row(i1, r1, 255u, A.a8, false);
+            for (int q = 1; q < n1; ++q) {                // further sub-paths of the line (NaN breaks: rare)
                 const Item it = A.items[g * MAXSUB + q];
-                if (tables) apply(it, 255u, A.a8, true); else apply(it, 255u, A.a8, false);
+                const RowRef r = fetch_row(it);
+                if (tables) apply_row(it, r, 255u, A.a8, true); else apply_row(it, r, 255u, A.a8, false);
             }
+            i1 = i2; n1 = n2; r1 = r2; i2 = i3; n2 = n3;
         }
-        for (int side = 0; side < 4; ++side) apply(A.items[(A.nlines + side) * MAXSUB], 0u, 255u, false);
+        for (int side = 0; side < 4; ++side) {
+            const Item it = A.items[(A.nlines + side) * MAXSUB];
+            apply_row(it, fetch_row(it), 0u, 255u, false);
+        }
     }
     __syncthreads();
     // coalesced store of the workgroup's rows
