@@ -24,6 +24,12 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- pytho
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/cnn_mfma -o t -- python3 scripts/time_cnn.py --passes 6 102 > $R/cnn_mfma.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/yud_mfma -o t -- python3 bench.py --workload yud --steps 4 --warmup 2 --no-cpu-baseline --no-alt > $R/yud_mfma.log 2>&1
+# the rasteriser alone: the bench's 102 line sets, three calls (scripts/time_raster.py 2); counters in two passes
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/raster_trace -o t -- python3 scripts/time_raster.py 2 > $R/raster_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES -d $R/raster_pmc1 -o t -- python3 scripts/time_raster.py 2 > $R/raster_pmc1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $R/raster_pmc2 -o t -- python3 scripts/time_raster.py 2 > $R/raster_pmc2.log 2>&1
+python3 scripts/rocpd_stats.py $(find $R/raster_trace -name '*.db' | head -1) $R/summary/${N}_raster_kernel_stats.csv > $R/summary/${N}_raster_top.txt
+for k in simplify outline coverage blend; do for q in raster_pmc1 raster_pmc2; do python3 scripts/rocpd_pmc.py $(find $R/$q -name '*.db' | head -1) $k; done; done > $R/summary/${N}_raster_pmc.txt 2>&1
 python3 scripts/rocpd_stats.py $(find $R/yud_trace -name '*.db' | head -1) $R/summary/${N}_yud_kernel_stats.csv > $R/summary/${N}_yud_top.txt
 python3 scripts/rocpd_stats.py $(find $R/stress_trace -name '*.db' | head -1) $R/summary/${N}_stress_kernel_stats.csv > $R/summary/${N}_stress_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_trace -name '*.db' | head -1) $R/summary/${N}_cnn_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_top.txt
