@@ -35,19 +35,23 @@ using namespace vpk_raster;
 // ---------------------------------------------------------------------------------------------------------------
 // Four kernels.
 //   simplify_kernel  one WAVE per line, lanes = samples: samples -> PathSimplifier's kept points (see the kernel)
-//   outline_kernel   one THREAD per line (all lines of the call, all CUs): samples -> PathSimplifier -> conv_stroke; the
-//                    closed outline polygons (up to MAXSUB per line) go to HBM
+//   outline_kernel   one THREAD per line: conv_stroke on the kept points (and the sequential simplifier for the lines
+//                    simplify_kernel leaves to it); the closed outline polygons (up to MAXSUB per line) go to HBM
 //   coverage_kernel  one WORKGROUP per line at a time (persistent workgroups over a queue of ALL lines: the lines of an
 //                    image need no order here): cells in the LDS pool, sweep -> the line's coverage as one byte per
-//                    pixel of every touched row's cell range (the pool's packing) + a row table, in HBM
-//   blend_kernel     one THREAD per image row, 64 rows per workgroup, the row's pixels in LDS: the image's lines IN
+//                    pixel of every touched row's cell range (the pool's packing) + the dense row table, in HBM
+//   blend_kernel     16 image rows x 8 column segments per workgroup, the rows' pixels in LDS: the image's lines IN
 //                    INPUT ORDER (the 8-bit blend does not commute), then the four spines; one coalesced store
 // ---------------------------------------------------------------------------------------------------------------
-struct RowRef { int off; short xmin; short len; };       // a touched row of one polygon: alpha bytes [off, off + len), first pixel xmin
-struct Item { long long alpha_base; long long row_base; int ymin, ymax; };   // one polygon's coverage (ymax < ymin: none)
+// One polygon's coverage of one image row: alpha bytes [off, off + (len & ROW_LEN)) of the call's pool, first pixel xmin
+// (len & ROW_LEN == 0: the row is not touched).  The table is DENSE -- [line][sub-path][row] -- so that the blend can fetch
+// the entries of several lines at once without first reading anything about the lines; bits 12.. of `len` in sub-path 0 =
+// the line's further sub-paths (a NaN sample breaks the path: rare).
+struct RowEnt { unsigned off; short xmin; short len; };
+constexpr int ROW_LEN = 0xfff, ROW_MORE_SHIFT = 12;
 
 struct RasterArgs {
-    const double* l; const long long* offsets; const double* tab;
+    const double* l; const long long* offsets; const int* order; const double* tab;
     int batch; int size; int samples; unsigned a8; long long nlines; long long line0;   // this chunk: lines [line0, line0 + nlines)
     unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
     unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
@@ -55,8 +59,7 @@ struct RasterArgs {
     int probe;                                           // VPK_RASTER_TIMES: workgroup 0 of coverage_kernel times its phases
     int* seq; int* nsimp; int force_seq;                 // per line: 1 = left to the sequential machine; points kept by simplify_kernel
     unsigned char* alpha; unsigned long long alpha_cap;
-    RowRef* rows; unsigned long long rows_cap;
-    Item* items;                                         // per line MAXSUB, then 4 spine items
+    RowEnt* dense;                                       // [nlines + 4 spines][MAXSUB][size]
     int first_image;                                     // images [first_image, first_image + batch) of the caller's batch
 };
 
@@ -305,12 +308,11 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
 // are kept off the critical path: the vertices are fetched once (LDS), a thread keeps its work item between the two
 // passes, the pools' space comes from ONE atomic, the next line's number is requested a polygon ahead.
 constexpr int LVERT = 256;                               // vertices of a polygon held in LDS (typical: 60-200)
-constexpr unsigned long long BUMP_ROWS_SHIFT = 40;       // the call's bump counter: alpha bytes | row refs << 40
 struct CovShared {
     int* total; long long* base; unsigned short* eoff; V2* vert; int* tail;
 };
 __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int size, const CovShared& S, const RasterArgs& A,
-                                 Item* item) {
+                                 RowEnt* ent, int more) {
     const bool probe = A.probe && threadIdx.x == 0 && blockIdx.x == 0;
     long long tp = probe ? wall_clock64() : 0;
     auto lap = [&](int slot) { if (probe) { const long long now = wall_clock64(); atomicAdd(A.ctr + 8 + slot, (int)(now - tp)); tp = now; } };
@@ -397,13 +399,10 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         }
         if (threadIdx.x == 63) {
             S.total[0] = incl; S.total[1] = ymin; S.total[2] = ymax;
-            long long ab = -1, rb = -1;
-            if (incl > 0) {                               // space in the call's coverage pools (bump allocation, one atomic)
-                const unsigned long long nrows = (unsigned long long)(ymax - ymin + 1);
-                const unsigned long long old = atomicAdd(A.bump, (unsigned long long)incl | (nrows << BUMP_ROWS_SHIFT));
-                ab = (long long)(old & ((1ull << BUMP_ROWS_SHIFT) - 1ull));
-                rb = (long long)(old >> BUMP_ROWS_SHIFT);
-                if ((unsigned long long)ab + incl > A.alpha_cap || (unsigned long long)rb + nrows > A.rows_cap) ab = -1;
+            long long ab = -1, rb = 0;
+            if (incl > 0) {                               // space in the call's coverage pool (bump allocation)
+                ab = (long long)atomicAdd(A.bump, (unsigned long long)incl);
+                if ((unsigned long long)ab + incl > A.alpha_cap) ab = -1;
             }
             S.base[0] = ab; S.base[1] = rb;
         }
@@ -411,7 +410,7 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     __syncthreads();
     lap(1);
     const int total = S.total[0], ymin = S.total[1], ymax = S.total[2];
-    const long long ab = S.base[0], rb = S.base[1];
+    const long long ab = S.base[0];
     const bool ok = ab >= 0;                              // (a polygon past the call's HBM pools is dropped and flagged)
     // The pool holds the cell ranges of a BAND of rows at a time: all touched rows when they fit (the usual case), else as
     // many consecutive rows as fit -- a curve with an interior extremum crosses the rows beside it twice, far apart, and a
@@ -478,10 +477,10 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         }
         for (int yy = ys + threadIdx.x; yy < ye; yy += RT) {
             const int lo = sink.rowmin[yy], hi = sink.rowmax[yy];
-            RowRef r;
-            r.off = sink.rowoff[yy]; r.xmin = (short)(lo - 1); r.len = (short)(hi >= lo ? hi - lo + 1 : 0);
-            if (hi < lo) { r.xmin = 0; r.len = 0; }
-            A.rows[rb + (yy - ymin)] = r;
+            RowEnt r;
+            r.off = (unsigned)(ab + sink.rowoff[yy]); r.xmin = (short)(lo - 1); r.len = (short)((hi >= lo ? hi - lo + 1 : 0) | more);
+            if (hi < lo) { r.off = 0; r.xmin = 0; }
+            ent[yy] = r;
         }
         __syncthreads();
         {   // ... and leave it in one coalesced copy (the pool is zero again afterwards)
@@ -492,10 +491,9 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         lap(3);
         ys = ye;
     }
-    for (int y = threadIdx.x; y < size; y += RT) { sink.rowmin[y] = 0x7fffffff; sink.rowmax[y] = -1; }
-    if (threadIdx.x == 0) {
-        item->alpha_base = ok ? ab : 0; item->row_base = ok ? rb : 0;
-        item->ymin = ok ? ymin : 0; item->ymax = ok ? ymax : -1;
+    for (int y = threadIdx.x; y < size; y += RT) {
+        if (!ok || y < ymin || y > ymax) { RowEnt r; r.off = 0; r.xmin = 0; r.len = (short)more; ent[y] = r; }   // rows the polygon leaves alone
+        sink.rowmin[y] = 0x7fffffff; sink.rowmax[y] = -1;
     }
     __syncthreads();
     return ok || total == 0;
@@ -529,18 +527,20 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
         if (threadIdx.x == 0) nx = atomicAdd(A.ctr, 1);  // the line after this one: the round trip runs beside the work below
         const int* pt = A.polys + g * (1 + 2 * MAXSUB);
         const int npoly = pt[0];
-        for (int q = 0; q < MAXSUB; ++q) {
-            Item* item = A.items + g * MAXSUB + q;
+        const int more = (npoly > 1 ? npoly - 1 : 0) << ROW_MORE_SHIFT;
+        for (int q = 0; q < (npoly > 0 ? npoly : 1); ++q) {
+            RowEnt* ent = A.dense + ((size_t)g * MAXSUB + q) * size;
             if (q < npoly) {
-                const bool ok = polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, S, A, item);
+                const bool ok = polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, S, A, ent,
+                                                 q == 0 ? more : 0);
                 if (!ok && threadIdx.x == 0 && g < A.nlines) {                      // dropped: tell the line's image
                     int lo = 0, hi = A.batch;
                     const long long gl = A.line0 + g;
                     while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (A.offsets[A.first_image + mid] <= gl) lo = mid; else hi = mid; }
                     atomicOr(A.flags + A.first_image + lo, FLAG_OVERFLOW);
                 }
-            } else if (threadIdx.x == 0) {
-                item->alpha_base = 0; item->row_base = 0; item->ymin = 0; item->ymax = -1;
+            } else {                                      // a line that left no polygon: an empty sub-path 0
+                for (int y = threadIdx.x; y < size; y += RT) { RowEnt r; r.off = 0; r.xmin = 0; r.len = 0; ent[y] = r; }
             }
         }
         if (threadIdx.x == 0) s_next = nx;
@@ -552,13 +552,14 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
 // calculate_alpha((R << 9) - area), one without (no cell, or a cell of a vertical edge on the pixel boundary) lies in the
 // span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
 // coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
-constexpr int BROWS = 64, BSEG = 8;                       // image rows per workgroup; column segments per row (one wave each)
+constexpr int BROWS = 16, BSEG = 8;                       // image rows per workgroup x column segments per row: 128 threads
+                                                         // (measured: 64 x 8 1.12 ms, 32 x 8 0.98, 16 x 8 0.92, 16 x 16 1.01)
 constexpr unsigned BLEND_LUT_MAX_A8 = 63;                // colour alphas up to this blend through a table (17 KB of LDS at most)
 __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4], then the tables
     const int size = A.size, ldp = (size + 3) & ~3;
     const int rr = threadIdx.x & (BROWS - 1), seg = threadIdx.x / BROWS;
-    const int img_i = blockIdx.y, y = blockIdx.x * BROWS + rr;
+    const int img_i = A.order[A.first_image + blockIdx.y], y = blockIdx.x * BROWS + rr;   // images with many lines first
     unsigned char* row = s_px + (size_t)rr * ldp;
     // The blend of a white line is a function of (pixel, cover) with few distinct colour alphas (26 * cover / 255 = 0..26
     // at the reference's alpha 0.1): two table reads instead of the blender's multiplications and its division --
@@ -579,58 +580,117 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     const long long lo = A.offsets[A.first_image + img_i] - A.line0, hi = A.offsets[A.first_image + img_i + 1] - A.line0;
     __syncthreads();
     if (y < size) {
-        auto fetch_row = [&](const Item& it) {            // the item's entry for this thread's row (len 0: not touched)
-            RowRef r;
-            r.off = 0; r.xmin = 0; r.len = 0;
-            if (y >= it.ymin && y <= it.ymax) r = A.rows[it.row_base + (y - it.ymin)];
-            return r;
+        const RowEnt* dl = A.dense + y;                   // this row's entries: dl[(line * MAXSUB + sub-path) * size]
+        const RowEnt none = {0u, 0, 0};
+        // eight consecutive pixels.  Through the tables every step is eight independent LDS reads (old pixels, colour alphas,
+        // new pixels: alpha 0 maps a pixel to itself), then the writes -- of the pixels with coverage only: a thread must not
+        // touch its neighbours' columns, not even to write back what it read.  (Eight `if (cover) pixel = ...` in a row
+        // are eight dependent read chains.)
+        auto blend8 = [&](const unsigned (&av)[8], int xbase, unsigned grey, unsigned a8, bool use_tables) {
+            if (use_tables) {
+                unsigned old[8], ca[8], nv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { old[u] = row[xbase + u]; ca[u] = amul[av[u]]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nv[u] = lut[(ca[u] << 8) | old[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (av[u]) row[xbase + u] = (unsigned char)nv[u];
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = xbase + u;
+                if (av[u]) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
+            }
         };
-        auto apply_row = [&](const Item& it, const RowRef r, unsigned grey, unsigned a8, bool use_tables) {
-            const unsigned char* al = A.alpha + it.alpha_base + r.off;
-            const int qlo = x0 - r.xmin > 0 ? x0 - r.xmin : 0, qhi = x1 - r.xmin < r.len ? x1 - r.xmin : r.len;
-            for (int q0 = qlo; q0 < qhi; q0 += 8) {       // eight bytes requested together
+        auto seg_range = [&](const RowEnt& e, int& qlo, int& qhi) {   // the entry's bytes that fall into this thread's columns
+            const int len = e.len & ROW_LEN;
+            qlo = x0 - e.xmin > 0 ? x0 - e.xmin : 0;
+            qhi = x1 - e.xmin < len ? x1 - e.xmin : len;
+        };
+        // (loads are issued unconditionally -- a slot outside the range reads the pool's first byte and is masked afterwards --
+        //  so that the compiler can COUNT the loads in flight: a skipped load makes every later wait a wait for everything)
+        auto fetch8 = [&](const RowEnt& e, int q0, int qhi, unsigned (&av)[8]) {
+            const unsigned char* al = A.alpha + e.off;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = A.alpha[q0 + u < qhi ? (size_t)e.off + q0 + u : 0];
+            (void)al;
+        };
+        auto mask8 = [&](int q0, int qhi, unsigned (&av)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? av[u] : 0u;
+        };
+        auto rest = [&](const RowEnt& e, int qlo, int qhi, unsigned grey, unsigned a8, bool use_tables) {   // bytes past the first eight
+            for (int q0 = qlo + 8; q0 < qhi; q0 += 8) {
                 unsigned av[8];
+                fetch8(e, q0, qhi, av);
+                mask8(q0, qhi, av);
+                blend8(av, e.xmin + q0, grey, a8, use_tables);
+            }
+        };
+        auto whole = [&](const RowEnt& e, unsigned grey, unsigned a8, bool use_tables) {
+            int qlo, qhi;
+            seg_range(e, qlo, qhi);
+            if (qlo < qhi) {
+                unsigned av[8];
+                fetch8(e, qlo, qhi, av);
+                mask8(qlo, qhi, av);
+                blend8(av, e.xmin + qlo, grey, a8, use_tables);
+                rest(e, qlo, qhi, grey, a8, use_tables);
+            }
+        };
+        // The image's lines in order -- the blend does not commute -- but FETCHED ahead: the dense table needs no knowledge
+        // about a line to address its entry, so while group k (BL lines) is blended (LDS), the first eight alpha bytes of
+        // group k + 1 and the entries of group k + 2 are in flight.
+        constexpr int BL = 2;
+        const long long last = hi - 1;
+        auto entries = [&](long long g0, RowEnt (&e)[BL]) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? al[q0 + u] : 0u;
+            for (int u = 0; u < BL; ++u) {
+                const long long g = g0 + u < hi ? g0 + u : (last > lo ? last : lo);     // (clamped: masked below)
+                e[u] = dl[(size_t)g * MAXSUB * size];
+            }
+        };
+        auto settle = [&](long long g0, RowEnt (&e)[BL]) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int x = r.xmin + q0 + u;
-                    if (av[u]) {
-                        if (use_tables) row[x] = lut[((unsigned)amul[av[u]] << 8) | row[x]];
-                        else row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
-                    }
+            for (int u = 0; u < BL; ++u) if (!(g0 + u < hi)) e[u] = none;
+        };
+        RowEnt e0[BL], e1[BL], e2[BL];
+        unsigned av0[BL][8], av1[BL][8];
+        int ql0[BL], qh0[BL], ql1[BL], qh1[BL];
+        if (lo < hi) {
+            entries(lo, e0); entries(lo + BL, e1);
+            settle(lo, e0);
+#pragma unroll
+            for (int u = 0; u < BL; ++u) { seg_range(e0[u], ql0[u], qh0[u]); fetch8(e0[u], ql0[u], qh0[u], av0[u]); }
+        }
+        for (long long g0 = lo; g0 < hi; g0 += BL) {
+            entries(g0 + 2 * BL, e2);
+            settle(g0 + BL, e1);
+#pragma unroll
+            for (int u = 0; u < BL; ++u) { seg_range(e1[u], ql1[u], qh1[u]); fetch8(e1[u], ql1[u], qh1[u], av1[u]); }
+#pragma unroll
+            for (int u = 0; u < BL; ++u) {
+                if (ql0[u] < qh0[u]) {
+                    mask8(ql0[u], qh0[u], av0[u]);
+                    if (tables) { blend8(av0[u], e0[u].xmin + ql0[u], 255u, A.a8, true); rest(e0[u], ql0[u], qh0[u], 255u, A.a8, true); }
+                    else { blend8(av0[u], e0[u].xmin + ql0[u], 255u, A.a8, false); rest(e0[u], ql0[u], qh0[u], 255u, A.a8, false); }
+                }
+                const int more = (e0[u].len >> ROW_MORE_SHIFT) & 7;           // further sub-paths of the line (rare)
+                for (int q = 1; q <= more; ++q) {
+                    const RowEnt f = dl[((size_t)(g0 + u) * MAXSUB + q) * size];
+                    if (tables) whole(f, 255u, A.a8, true); else whole(f, 255u, A.a8, false);
                 }
             }
-        };
-        // The image's lines in order.  A line costs a chain of round trips (polygon count and item: scalar loads; the
-        // row's entry; its alpha bytes), and the blend order forbids working on two lines at once -- but not FETCHING
-        // ahead: the scalars are requested two lines ahead, the row entry one line ahead (it is in flight while the
-        // current line's bytes are fetched and blended).
-        const Item none = {0, 0, 0, -1};
-        auto line_head = [&](long long g, int& np, Item& it) {
-            np = 0; it = none;
-            if (g < hi) { np = A.polys[g * (1 + 2 * MAXSUB)]; if (np > 0) it = A.items[g * MAXSUB]; }   // (wave-uniform)
-        };
-        int n1, n2, n3;
-        Item i1, i2, i3;
-        line_head(lo, n1, i1);
-        line_head(lo + 1, n2, i2);
-        RowRef r1 = fetch_row(i1);
-        for (long long g = lo; g < hi; ++g) {
-            line_head(g + 2, n3, i3);
-            const RowRef r2 = fetch_row(i2);
-            if (tables) apply_row(i1, r1, 255u, A.a8, true); else apply_row(i1, r1, 255u, A.a8, false);
-            for (int q = 1; q < n1; ++q) {                // further sub-paths of the line (NaN breaks: rare)
-                const Item it = A.items[g * MAXSUB + q];
-                const RowRef r = fetch_row(it);
-                if (tables) apply_row(it, r, 255u, A.a8, true); else apply_row(it, r, 255u, A.a8, false);
+#pragma unroll
+            for (int u = 0; u < BL; ++u) {
+                e0[u] = e1[u]; e1[u] = e2[u]; ql0[u] = ql1[u]; qh0[u] = qh1[u];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) av0[u][k] = av1[u][k];
             }
-            i1 = i2; n1 = n2; r1 = r2; i2 = i3; n2 = n3;
         }
-        for (int side = 0; side < 4; ++side) {
-            const Item it = A.items[(A.nlines + side) * MAXSUB];
-            apply_row(it, fetch_row(it), 0u, 255u, false);
-        }
+        for (int side = 0; side < 4; ++side) whole(dl[(size_t)(A.nlines + side) * MAXSUB * size], 0u, 255u, false);
     }
     __syncthreads();
     // coalesced store of the workgroup's rows
@@ -654,15 +714,15 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const int samples = 10000;                            // sphere_mapping.py:40
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
     const long long max_lines = 49152;
-    const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 + MAXSUB * sizeof(Item) +
-                            16384 + (size_t)(size + 8) * sizeof(RowRef) + 8;
+    const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 +
+                            16384 + (size_t)MAXSUB * size * sizeof(RowEnt) + 8;
     long long chunk_lines = 0;
     for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
         b1 = b0 + 1;
         while (b1 < batch && offsets[b1 + 1] - offsets[b0] <= max_lines) ++b1;
         chunk_lines = std::max<long long>(chunk_lines, offsets[b1] - offsets[b0]);
     }
-    const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
+    const size_t ob = vpk::em_align((size_t)(batch + 1) * 8 + (size_t)batch * 4, 256);   // offsets, then the blend's image order
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
     const size_t tb = vpk::em_align((size_t)samples * 4 * 8, 256);
     const size_t nl = (size_t)chunk_lines + 4;
@@ -679,6 +739,17 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     if (!same) {
         VPK_HIP(h, hipStreamSynchronize(h->stream));
         VPK_HIP(h, hipMemcpyAsync(base, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        // the blend's workgroups of an image last as long as the image has lines: within a chunk the images are dealt out
+        // longest first, so that the kernel does not end on a 400-line image that started last
+        std::vector<int> order((size_t)batch);
+        for (int b0 = 0, b1; b0 < batch; b0 = b1) {
+            b1 = b0 + 1;
+            while (b1 < batch && offsets[b1 + 1] - offsets[b0] <= max_lines) ++b1;
+            for (int b = b0; b < b1; ++b) order[b] = b - b0;
+            std::stable_sort(order.begin() + b0, order.begin() + b1, [&](int x, int y) {
+                return offsets[b0 + x + 1] - offsets[b0 + x] > offsets[b0 + y + 1] - offsets[b0 + y]; });
+        }
+        VPK_HIP(h, hipMemcpyAsync(base + (size_t)(batch + 1) * 8, order.data(), (size_t)batch * 4, hipMemcpyHostToDevice, h->stream));
         VPK_HIP(h, hipStreamSynchronize(h->stream));
         h->raster_offsets.assign((const long long*)offsets, (const long long*)offsets + batch + 1);
     }
@@ -688,7 +759,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         h->raster_table_size = size;
     }
     RasterArgs A;
-    A.l = l; A.offsets = (const long long*)base; A.tab = (const double*)(base + ob + fb); A.size = size; A.samples = samples;
+    A.l = l; A.offsets = (const long long*)base; A.order = (const int*)(base + (size_t)(batch + 1) * 8); A.tab = (const double*)(base + ob + fb); A.size = size; A.samples = samples;
     A.a8 = (unsigned)(alpha * 255.0 + 0.5);               // agg::rgba8(rgba): uround
     A.out = out; A.ctr = (int*)(base + ob); A.bump = (unsigned long long*)(base + ob + 64); A.flags = (unsigned*)(base + ob + 256);
     char* p = base + ob + fb + tb;
@@ -698,9 +769,8 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
     A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
-    A.items = (Item*)p; p += vpk::em_align(nl * MAXSUB * sizeof(Item), 256);
     A.alpha = (unsigned char*)p; A.alpha_cap = nl * 16384; p += vpk::em_align(nl * 16384, 256);
-    A.rows = (RowRef*)p; A.rows_cap = nl * (size_t)(size + 8);
+    A.dense = (RowEnt*)p;
     if (!h->raster_ready) {
         VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(blend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        BROWS * 1024 + 256 + (BLEND_LUT_MAX_A8 + 1) * 256));
@@ -734,13 +804,13 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
             VPK_HIP(h, hipEventSynchronize(ev[3]));
             for (int q = 0; q < 3; ++q) VPK_HIP(h, hipEventElapsedTime(&ms[q], ev[q], ev[q + 1]));
             VPK_HIP(h, hipEventElapsedTime(&ms_points, ev[0], ev[4]));
-            unsigned long long bump[2];
-            VPK_HIP(h, hipMemcpy(bump, A.bump, 16, hipMemcpyDeviceToHost));
+            unsigned long long bump[1];
+            VPK_HIP(h, hipMemcpy(bump, A.bump, 8, hipMemcpyDeviceToHost));
             int dbg[16];
             VPK_HIP(h, hipMemcpy(dbg, A.ctr, sizeof(dbg), hipMemcpyDeviceToHost));
             fprintf(stderr, "vpk_sphere_raster: %d images, %lld lines: simplify %.2f + outlines %.2f ms, coverage %.2f ms, blend %.2f ms; %.0f coverage bytes "
-                    "and %.0f rows per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
-                    A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)(bump[0] & ((1ull << BUMP_ROWS_SHIFT) - 1ull)) / nt, (double)(bump[0] >> BUMP_ROWS_SHIFT) / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
+                    "per line; workgroup 0 of the coverage kernel: bounds %.2f, scan %.2f, cells %.2f, sweep %.2f ms\n", A.batch,
+                    A.nlines, ms_points, ms[0] - ms_points, ms[1], ms[2], (double)bump[0] / nt, dbg[8] * 1e-5, dbg[9] * 1e-5, dbg[10] * 1e-5,
                     dbg[11] * 1e-5);
             for (int q = 0; q < 5; ++q) (void)hipEventDestroy(ev[q]);
         }
@@ -754,7 +824,7 @@ int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out) {
     if (!h || !flags_out || batch < 1 || !h->raster_hdr) return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster_flags: bad argument");
     VPK_HIP(h, hipSetDevice(h->device));
     VPK_HIP(h, hipStreamSynchronize(h->stream));
-    const size_t ob = vpk::em_align((size_t)(batch + 1) * 8, 256);
+    const size_t ob = vpk::em_align((size_t)(batch + 1) * 8 + (size_t)batch * 4, 256);   // (the layout of vpk_sphere_raster)
     VPK_HIP(h, hipMemcpy(flags_out, (char*)h->raster_hdr + ob + 256, (size_t)batch * 4, hipMemcpyDeviceToHost));
     return VPK_OK;
 }
