@@ -92,3 +92,18 @@ def test_wave_parallel_simplifier_equals_the_sequential_machine(monkeypatch):
     monkeypatch.delenv("VPK_RASTER_SEQUENTIAL")
     assert np.array_equal(fast, slow), "%d pixels differ" % (fast != slow).sum()
     assert fast.max() > 100                                        # (lines do pile up: the comparison is not of empty canvases)
+
+
+def test_empty_images_in_a_batch_and_extreme_canvas_sizes():
+    """Images without lines between others (the frame alone), a 64-px and a 1000-px canvas (row tables, LDS rows and the
+    blend's column segments are sized from the canvas), against the CPU restatement."""
+    from oracle import agg_raster
+    from vanishing_points_2017_amd import sphere_mapping, synth
+    a = synth.make_scene(77, 40, 3, raster=None)["l"]
+    sets = [a[:0], a, a[:0], a[:3], a[:0]]
+    got = sphere_mapping.raster_batch(sets, size=500, alpha=0.1)
+    for lines, r in zip(sets, got):
+        assert np.array_equal(r, agg_raster.raster(lines))
+    assert np.array_equal(sphere_mapping.raster_batch([a[:5]], size=64, alpha=0.1)[0], agg_raster.raster(a[:5], size=64))
+    assert np.array_equal(sphere_mapping.raster_batch([a[:5]], size=1000, alpha=0.2)[0],
+                          agg_raster.raster(a[:5], size=1000, alpha=0.2))
