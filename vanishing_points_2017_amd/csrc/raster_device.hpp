@@ -312,17 +312,12 @@ struct CellSink {
 };
 // (the sink travels BY VALUE through the noinline walkers below: a pointer to it would be a pointer into the caller's
 //  private memory, and every field access a scratch load)
-template <int MODE> RDEV_INLINE void cell_add(const CellSink& s, int ex, int ey, int c, int a) {
+template <int MODE> RDEV_INLINE void cell_add(const CellSink& s, int ex, int ey, int c, int a, int row_base) {
     if ((c | a) == 0) return;
-    if (ey < 0 || ey >= s.size || ex < -1 || ex > s.size) return;
-    if (MODE == BOUNDS) {
-        RS_ATOMIC_MIN(s.rowmin + ey, ex + 1);
-        RS_ATOMIC_MAX(s.rowmax + ey, ex + 1);
-    } else if (MODE == POOLED) {
-        if (ey < s.blo || ey >= s.bhi) return;
-        const int idx = s.rowoff[ey] - s.boff + (ex + 1 - s.rowmin[ey]);
-        if (c) RS_ATOMIC_ADD(s.pcover + idx, c);
-        if (a) RS_ATOMIC_ADD(s.parea + idx, a);
+    if (ex < -1 || ex > s.size) return;
+    if (MODE == POOLED) {                     // row_base: the row's first pool entry minus its first cell (cell_hline)
+        if (c) RS_ATOMIC_ADD(s.pcover + row_base + ex, c);
+        if (a) RS_ATOMIC_ADD(s.parea + row_base + ex, a);
     } else {
         const size_t idx = (size_t)ey * (s.size + 2) + ex + 1;
         if (c) RS_ATOMIC_ADD_GLOBAL(s.cover + idx, c);
@@ -344,16 +339,22 @@ template <int MODE> RDEV_INLINE void cell_hline(const CellSink& s, int ey, int x
         RS_ATOMIC_MAX(s.rowmax + ey, hi + 1);
         return;
     }
+    if (ey < 0 || ey >= s.size) return;
+    int row_base = 0;
+    if (MODE == POOLED) {                     // the row's entries in the pool: looked up once per row piece, not per cell
+        if (ey < s.blo || ey >= s.bhi) return;
+        row_base = s.rowoff[ey] - s.boff + 1 - s.rowmin[ey];
+    }
     if (ex1 == ex2) {
         const int delta = y2 - y1;
-        cell_add<MODE>(s, ex1, ey, delta, (fx1 + fx2) * delta);
+        cell_add<MODE>(s, ex1, ey, delta, (fx1 + fx2) * delta, row_base);
         return;
     }
     int p = (SUB - fx1) * (y2 - y1), first = SUB, incr = 1, dx = x2 - x1;
     if (dx < 0) { p = fx1 * (y2 - y1); first = 0; incr = -1; dx = -dx; }
     int delta = p / dx, mod = p % dx;
     if (mod < 0) { --delta; mod += dx; }
-    cell_add<MODE>(s, ex1, ey, delta, (fx1 + first) * delta);
+    cell_add<MODE>(s, ex1, ey, delta, (fx1 + first) * delta, row_base);
     ex1 += incr;
     y1 += delta;
     if (ex1 != ex2) {
@@ -365,13 +366,13 @@ template <int MODE> RDEV_INLINE void cell_hline(const CellSink& s, int ey, int x
             delta = lift;
             mod += rem;
             if (mod >= 0) { mod -= dx; ++delta; }
-            cell_add<MODE>(s, ex1, ey, delta, SUB * delta);
+            cell_add<MODE>(s, ex1, ey, delta, SUB * delta, row_base);
             y1 += delta;
             ex1 += incr;
         }
     }
     delta = y2 - y1;
-    cell_add<MODE>(s, ex1, ey, delta, (fx2 + SUB - first) * delta);
+    cell_add<MODE>(s, ex1, ey, delta, (fx2 + SUB - first) * delta, row_base);
 }
 // rasterizer_cells_aa::line for the rows [part * nrows / nparts, (part + 1) * nrows / nparts) of the edge only: a long
 // edge is shared by several threads.  AGG walks the rows with an integer DDA (x advances by lift, plus one whenever
