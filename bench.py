@@ -698,7 +698,10 @@ def run_workload(args, dist, rank, local_rank, world):
             "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": torch.get_num_threads(),
             "ms_per_step": elapsed / args.steps * 1e3, "host_submit_ms_per_step": submit_s / args.steps * 1e3,
             "host_enqueue_ms_per_step": float(np.median(call_s)) * 1e3,
-            "host_note": "host_enqueue = median duration of a step's enqueue call (one vpk_pipeline_step in lanes mode); "
+            "host_enqueue_unblocked_ms": float(np.min(call_s)) * 1e3,
+            "host_note": "host_enqueue = median duration of a step's enqueue call (one vpk_pipeline_step in lanes mode), "
+                         "host_enqueue_unblocked = the shortest one (a call that did not have to wait for a free header "
+                         "buffer: the host's own work per step); "
                          "host_submit = wall time of the whole submit loop / steps, which includes flow control: "
                          "vpk_em_batch keeps four pinned header buffers per handle and waits for the oldest launch's "
                          "header copy once five launches are queued on a handle",
