@@ -162,7 +162,13 @@ int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
 /* ---- sphere rasteriser (sphere_mapping.py:36-72) ----------------------------------------------- */
 /* replaces: get_sphere_image / sphere_line_plot (evaluation.py:12-14).  l: sum(N) x 3 fp64
  * homogeneous lines, offsets [host]: B+1 int64 prefix of line counts; out: B x size x size uint8,
- * image row 0 = beta = +pi/2.  alpha = per-line blend weight (0.1 in the reference). */
+ * image row 0 = beta = +pi/2.  alpha = per-line blend weight (0.1 in the reference).  size 8..1024.
+ * The reference's matplotlib / Agg pipeline stage by stage (10 000 samples per line, PathSimplifier, 1 pt stroke,
+ * anti-aliased scanline coverage, plain 8-bit "over" in line order, black axes spines last): pixel-exact.
+ * Asynchronous on the handle's stream, except that `offsets` (caller-owned host memory) is uploaded and waited for when
+ * it differs from the previous call's on this handle -- a pipeline that rasterises the same batch structure again does
+ * not wait for anything.  Workspace (kept on the handle, grown on demand): ~45 KB + 32 x size bytes per line of the
+ * largest chunk of <= 49 152 lines. */
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
                       double alpha, uint8_t* out);
 /* per-image flags of the LAST vpk_sphere_raster call on this handle (waits for it): bit 0 = a line produced more outline
