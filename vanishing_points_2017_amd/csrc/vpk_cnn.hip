@@ -44,7 +44,8 @@ struct ConvDims {
 //   C[m][n] = sum_k Wp[k][m] * X[k][n],  m = output channel, n = (b, oh, ow), k = (ic, kh, kw)
 // WAVES_M x WAVES_N waves, each owning TM x TN MFMA tiles of 32 x 32.
 // --------------------------------------------------------------------------------------------
-// LDS-DMA implicit GEMM (every conv / dense layer; conv1's input is pre-converted to fp32):
+// LDS-DMA implicit GEMM (every conv / dense layer; for conv1 only the unfused / tapped paths -- its input is then
+// pre-converted to fp32 phase planes by prep_input_kernel; the default conv1 is conv1_direct_kernel below):
 // both operand tiles go HBM -> LDS with global_load_lds (no staging VGPRs, no ds_write), three LDS
 // stages, raw s_barrier + counted s_waitcnt vmcnt(N) so that the DMA of stage t+2 stays in flight
 // across the barrier that publishes stage t+1 (cdna_hip_programming.md T3/T4).  The weights panel is
@@ -432,7 +433,8 @@ __device__ long long c1d_dbg[256 * 8 * 8];
 #else
 #define C1D_T(i)
 #endif
-__global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+__global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const unsigned char* __restrict__ sphere,
+                                                                      const float* __restrict__ mean_pp, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                                       int OHp, int OWp, int opad, int* __restrict__ tile_counter,
                                                                       int total_tiles) {
@@ -476,43 +478,56 @@ __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const floa
     constexpr int PRE_LAST = 16 * C1D_PY * C1D_PX - (PRE - 1) * C1D_THREADS;      // threads that hold a sixth one
     // per-thread constants of the raw-patch copy, element u = (phase p, row, column): offset from the patch origin inside
     // the image's 16 stacked phase planes, LDS index, and (row << 8 | column) for the clamped loads of border patches
-    int poff[PRE], pdst[PRE], pyx[PRE];
+    // The input is read where the caller left it: the uint8 rasters, and the mean blob re-ordered once at load time into the
+    // 16 stride-4 phase planes (P[py][px][Y][X] = mean[4Y + py][4X + px]); evaluation.py:35's float(image) - mean happens
+    // on the way into LDS.  (A pre-pass used to write that difference as fp32 phase planes: 102 MB out and in per batch.)
+    int poff[PRE], pdst[PRE], pyx[PRE], boff[PRE];
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const int e = tid + u * C1D_THREADS;
         const int ph = e / (C1D_PY * C1D_PX), rem = e - ph * (C1D_PY * C1D_PX);
         const int py = rem / C1D_PX, px = rem - py * C1D_PX;
-        poff[u] = (ph * C1_PW + py) * C1_PW + px;
+        poff[u] = (ph * C1_PW + py) * C1_PW + px;                             // in the mean's phase planes
+        boff[u] = (C1_PH * py + ph / C1_PH) * 500 + C1_PH * px + ph % C1_PH;  // in the raster: pixel (4 Y + py', 4 X + px')
         pdst[u] = (ph * C1D_PY + py) * C1D_PXL + px;
         pyx[u] = (ph << 16) | (py << 8) | px;
     }
-    auto patch_load = [&](int tile, float (&v)[PRE]) {
+    auto patch_load = [&](int tile, float (&v)[PRE], unsigned (&v8)[PRE]) {
         const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
         const int y0 = (C1_PR - 1) * pr, x0 = (C1_PC - 1) * pc;
-        const float* img = in + (size_t)b * 16 * C1_PW * C1_PW;
+        const unsigned char* img = sphere + (size_t)b * 500 * 500;
         if (pr < C1_TR - 1 && pc < C1_TC - 1) {        // the patch lies inside the planes: scalar base + per-thread offset
-            const float* base = img + y0 * C1_PW + x0;
+            const float* mbase = mean_pp + y0 * C1_PW + x0;
+            const unsigned char* base = img + (C1_PH * y0) * 500 + C1_PH * x0;
 #pragma unroll
-            for (int u = 0; u < PRE; ++u) v[u] = (u < PRE - 1 || tid < PRE_LAST) ? base[poff[u]] : 0.f;
+            for (int u = 0; u < PRE; ++u) {
+                const bool on = u < PRE - 1 || tid < PRE_LAST;
+                v[u] = on ? mbase[poff[u]] : 0.f;
+                v8[u] = on ? (unsigned)base[boff[u]] : 0u;
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {            // overhang is clamped (those taps only reach conv outputs that no
                 const int y = y0 + ((pyx[u] >> 8) & 255), x = x0 + (pyx[u] & 255);   //  pooling window uses)
-                const int yy = (pyx[u] >> 16) * C1_PW + (y < C1_PW ? y : C1_PW - 1), xx = x < C1_PW ? x : C1_PW - 1;
-                v[u] = (u < PRE - 1 || tid < PRE_LAST) ? img[yy * C1_PW + xx] : 0.f;
+                const int ph = pyx[u] >> 16;
+                const int yc = y < C1_PW ? y : C1_PW - 1, xc = x < C1_PW ? x : C1_PW - 1;
+                const bool on = u < PRE - 1 || tid < PRE_LAST;
+                v[u] = on ? mean_pp[(ph * C1_PW + yc) * C1_PW + xc] : 0.f;
+                v8[u] = on ? (unsigned)img[(C1_PH * yc + ph / C1_PH) * 500 + C1_PH * xc + ph % C1_PH] : 0u;
             }
         }
     };
-    auto patch_store = [&](const float (&v)[PRE]) {
+    auto patch_store = [&](const float (&v)[PRE], const unsigned (&v8)[PRE]) {
 #pragma unroll
         for (int u = 0; u < PRE; ++u)
-            if (u < PRE - 1 || tid < PRE_LAST) Xs[pdst[u]] = v[u];
+            if (u < PRE - 1 || tid < PRE_LAST) Xs[pdst[u]] = (float)v8[u] - v[u];
     };
     // dynamic tile queue (CUs held by other streams' kernels make static shares uneven); the index of the tile after
     // next is fetched one tile ahead, so the atomic's round trip is never waited for
     int tile = blockIdx.x;
     float pre[PRE];
-    if (tile < total_tiles) { patch_load(tile, pre); patch_store(pre); }
+    unsigned pre8[PRE];
+    if (tile < total_tiles) { patch_load(tile, pre, pre8); patch_store(pre, pre8); }
     if (tid == 0) s_next[0] = atomicAdd(tile_counter, 1) + (int)gridDim.x;
     __syncthreads();
     int next = __builtin_amdgcn_readfirstlane(s_next[0]);
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const floa
     for (int it = 0; tile < total_tiles; ++it) {
         int nx = 0;
         if (tid == 0) nx = atomicAdd(tile_counter, 1);            // consumed at the end of the tile: its round trip is never waited for
-        if (next < total_tiles) patch_load(next, pre);              // in flight under the MFMAs below
+        if (next < total_tiles) patch_load(next, pre, pre8);        // in flight under the MFMAs below
         f32x4 acc[6];
         // The operands of K step s + 1 are requested before the MFMAs of step s are issued (the scheduling barriers keep
         // the compiler from sinking the LDS reads back down to their first use, which leaves one LDS round trip exposed
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const floa
         C1D_T(2)
         lds_barrier();                                              // Cs and the raw patch are free
         C1D_T(3)
-        if (next < total_tiles) patch_store(pre);
+        if (next < total_tiles) patch_store(pre, pre8);
         // ---- ReLU -> LDS patch [channel][column] (bias is already in); positions outside the conv blob become 0 ----
         {
             const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR;
@@ -667,7 +682,8 @@ __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const floa
 extern "C" int vpk_dbg_c1d(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c1d_dbg), sizeof(long long) * 256 * 8 * 8); }
 #endif
 
-// conv1 input: float(uint8 raster) - mean (evaluation.py:35), written as the 16 stride-4 phase planes
+// conv1 input for the unfused / tapped paths (the default conv1_direct_kernel converts in its patch loader):
+// float(uint8 raster) - mean (evaluation.py:35), written as the 16 stride-4 phase planes
 //   P[py][px][Y][X] = x[4Y + py][4X + px]   (125 x 125 each)
 // so that conv1 (11 x 11, stride 4) is a stride-1 gather for the DMA kernel: tap (kh, kw) of output (oh, ow)
 // is P[kh % 4][kw % 4][oh + kh / 4][ow + kw / 4], and the 64 lanes of a gather (consecutive ow) read 256
@@ -940,6 +956,7 @@ int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
 struct vpk_cnn_state {
     Layer L[8];              // conv1..5, fc6..8
     float* mean = nullptr;
+    float* mean_pp = nullptr;   // the mean as 16 stride-4 phase planes (conv1_direct_kernel)
     bool loaded = false;
     // activations (grown on demand)
     float* act = nullptr;
@@ -964,6 +981,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.wsplit) (void)hipFree(l.wsplit);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
+    if (h->cnn->mean_pp) (void)hipFree(h->cnn->mean_pp);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
     if (h->cnn->ev_ready)
         for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
@@ -1087,8 +1105,10 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
 
     // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
-    hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
-                       500 * 500);
+    const bool direct = !(tap == 0 || !S->fuse_conv1) && S->fuse_conv1 != 2;   // conv1_direct_kernel reads the rasters itself
+    if (!direct)
+        hipLaunchKernelGGL(prep_input_kernel, dim3((500 * 500 + 255) / 256, batch), dim3(256), 0, st, sphere, S->mean, R[R_IN],
+                           500 * 500);
     if (tap == 0 || !S->fuse_conv1) {
         launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(0), 96, R[R_IN], S->L[0], R[R_CONV1], 1, ctr + 0);   // stride 1 over the phase planes
         mark();
@@ -1108,8 +1128,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
             launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false, true>, df, 96, R[R_IN], S->L[0], R[R_POOL1], 1, ctr + 0);
         } else {
             const int total = batch * C1_TR * C1_TC;
-            hipLaunchKernelGGL(conv1_direct_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1D_THREADS), 0, st, R[R_IN],
-                               S->L[0].wp, S->L[0].bias, R[R_POOL1], 65, 65, 2, ctr + 0, total);
+            hipLaunchKernelGGL(conv1_direct_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1D_THREADS), 0, st, sphere,
+                               S->mean_pp, S->L[0].wp, S->L[0].bias, R[R_POOL1], 65, 65, 2, ctr + 0, total);
         }
         mark();
         mark();
@@ -1261,6 +1281,14 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
     vpk_cnn_state* S = h->cnn;
     VPK_HIP(h, hipMalloc((void**)&S->mean, 500 * 500 * sizeof(float)));
     VPK_HIP(h, hipMemcpy(S->mean, mean, 500 * 500 * sizeof(float), hipMemcpyHostToDevice));
+    {   // the same blob as stride-4 phase planes, P[py][px][Y][X] = mean[4 Y + py][4 X + px] (conv1_direct_kernel's loader)
+        std::vector<float> pp((size_t)16 * C1_PW * C1_PW);
+        for (int y = 0; y < 500; ++y)
+            for (int x = 0; x < 500; ++x)
+                pp[(size_t)((y % C1_PH) * C1_PH + (x % C1_PH)) * (C1_PW * C1_PW) + (y / C1_PH) * C1_PW + x / C1_PH] = mean[y * 500 + x];
+        VPK_HIP(h, hipMalloc((void**)&S->mean_pp, pp.size() * sizeof(float)));
+        VPK_HIP(h, hipMemcpy(S->mean_pp, pp.data(), pp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     for (int li = 0; li < 8; ++li) {
         const Topo& t = TOPO[li];
         Layer& l = S->L[li];
