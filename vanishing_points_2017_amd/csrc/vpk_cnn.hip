@@ -434,7 +434,7 @@ __device__ long long c1d_dbg[256 * 8 * 8];
 #define C1D_T(i)
 #endif
 __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const unsigned char* __restrict__ sphere,
-                                                                      const float* __restrict__ mean_pp, const float* __restrict__ wp,
+                                                                      const float* __restrict__ mean, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                                       int OHp, int OWp, int opad, int* __restrict__ tile_counter,
                                                                       int total_tiles) {
@@ -474,58 +474,63 @@ __global__ __launch_bounds__(C1D_THREADS, 2) void conv1_direct_kernel(const unsi
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bl[i][r] = bias[16 * i + 4 * g + r];
-    constexpr int PRE = (16 * C1D_PY * C1D_PX + C1D_THREADS - 1) / C1D_THREADS;   // raw-patch floats per thread (6)
-    constexpr int PRE_LAST = 16 * C1D_PY * C1D_PX - (PRE - 1) * C1D_THREADS;      // threads that hold a sixth one
-    // per-thread constants of the raw-patch copy, element u = (phase p, row, column): offset from the patch origin inside
-    // the image's 16 stacked phase planes, LDS index, and (row << 8 | column) for the clamped loads of border patches
-    // The input is read where the caller left it: the uint8 rasters, and the mean blob re-ordered once at load time into the
-    // 16 stride-4 phase planes (P[py][px][Y][X] = mean[4Y + py][4X + px]); evaluation.py:35's float(image) - mean happens
-    // on the way into LDS.  (A pre-pass used to write that difference as fp32 phase planes: 102 MB out and in per batch.)
-    int poff[PRE], pdst[PRE], pyx[PRE], boff[PRE];
+    // The input is read where the caller left it: the uint8 rasters and the mean blob (row-major, as loaded);
+    // evaluation.py:35's float(image) - mean happens on the way into LDS.  (A pre-pass used to write that difference as
+    // fp32 phase planes: 102 MB out and in per batch.)  A thread fetches QUADS: the four horizontally adjacent pixels
+    // (4 X .. 4 X + 3) of raster row 4 Y + py' are one 4-byte word of the raster and one 16-byte word of the mean, and
+    // they are the elements (Y, X) of the four phase planes (py', 0..3) -- 684 quads per patch, two per thread.
+    constexpr int QUADS = C1_PH * C1D_PY * C1D_PX;                                 // 684
+    constexpr int PRE = (QUADS + C1D_THREADS - 1) / C1D_THREADS;                   // quads per thread (2)
+    constexpr int PRE_LAST = QUADS - (PRE - 1) * C1D_THREADS;                      // threads that hold a second one
+    int qoff[PRE], pdst[PRE], pyx[PRE];
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const int e = tid + u * C1D_THREADS;
-        const int ph = e / (C1D_PY * C1D_PX), rem = e - ph * (C1D_PY * C1D_PX);
+        const int pq = e / (C1D_PY * C1D_PX), rem = e - pq * (C1D_PY * C1D_PX);    // pq = py' (row phase)
         const int py = rem / C1D_PX, px = rem - py * C1D_PX;
-        poff[u] = (ph * C1_PW + py) * C1_PW + px;                             // in the mean's phase planes
-        boff[u] = (C1_PH * py + ph / C1_PH) * 500 + C1_PH * px + ph % C1_PH;  // in the raster: pixel (4 Y + py', 4 X + px')
-        pdst[u] = (ph * C1D_PY + py) * C1D_PXL + px;
-        pyx[u] = (ph << 16) | (py << 8) | px;
+        qoff[u] = (C1_PH * py + pq) * 500 + C1_PH * px;                            // pixel offset from the patch's first pixel
+        pdst[u] = ((pq * C1_PH) * C1D_PY + py) * C1D_PXL + px;                     // LDS index in phase plane (pq, 0)
+        pyx[u] = (pq << 16) | (py << 8) | px;
     }
-    auto patch_load = [&](int tile, float (&v)[PRE], unsigned (&v8)[PRE]) {
+    auto patch_load = [&](int tile, f32x4 (&v)[PRE], unsigned (&v8)[PRE]) {
         const int pc = tile % C1_TC, pr = (tile / C1_TC) % C1_TR, b = tile / (C1_TC * C1_TR);
         const int y0 = (C1_PR - 1) * pr, x0 = (C1_PC - 1) * pc;
         const unsigned char* img = sphere + (size_t)b * 500 * 500;
         if (pr < C1_TR - 1 && pc < C1_TC - 1) {        // the patch lies inside the planes: scalar base + per-thread offset
-            const float* mbase = mean_pp + y0 * C1_PW + x0;
-            const unsigned char* base = img + (C1_PH * y0) * 500 + C1_PH * x0;
+            const int origin = (C1_PH * y0) * 500 + C1_PH * x0;
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {
                 const bool on = u < PRE - 1 || tid < PRE_LAST;
-                v[u] = on ? mbase[poff[u]] : 0.f;
-                v8[u] = on ? (unsigned)base[boff[u]] : 0u;
+                const int o = on ? origin + qoff[u] : origin;
+                v[u] = *reinterpret_cast<const f32x4*>(mean + o);
+                v8[u] = *reinterpret_cast<const unsigned*>(img + o);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {            // overhang is clamped (those taps only reach conv outputs that no
                 const int y = y0 + ((pyx[u] >> 8) & 255), x = x0 + (pyx[u] & 255);   //  pooling window uses)
-                const int ph = pyx[u] >> 16;
+                const int pq = pyx[u] >> 16;
                 const int yc = y < C1_PW ? y : C1_PW - 1, xc = x < C1_PW ? x : C1_PW - 1;
                 const bool on = u < PRE - 1 || tid < PRE_LAST;
-                v[u] = on ? mean_pp[(ph * C1_PW + yc) * C1_PW + xc] : 0.f;
-                v8[u] = on ? (unsigned)img[(C1_PH * yc + ph / C1_PH) * 500 + C1_PH * xc + ph % C1_PH] : 0u;
+                const int o = on ? (C1_PH * yc + pq) * 500 + C1_PH * xc : 0;
+                v[u] = *reinterpret_cast<const f32x4*>(mean + o);
+                v8[u] = *reinterpret_cast<const unsigned*>(img + o);
             }
         }
     };
-    auto patch_store = [&](const float (&v)[PRE], const unsigned (&v8)[PRE]) {
+    auto patch_store = [&](const f32x4 (&v)[PRE], const unsigned (&v8)[PRE]) {
 #pragma unroll
         for (int u = 0; u < PRE; ++u)
-            if (u < PRE - 1 || tid < PRE_LAST) Xs[pdst[u]] = (float)v8[u] - v[u];
+            if (u < PRE - 1 || tid < PRE_LAST) {
+#pragma unroll
+                for (int q = 0; q < C1_PH; ++q)
+                    Xs[pdst[u] + q * (C1D_PY * C1D_PXL)] = (float)((v8[u] >> (8 * q)) & 255u) - v[u][q];
+            }
     };
     // dynamic tile queue (CUs held by other streams' kernels make static shares uneven); the index of the tile after
     // next is fetched one tile ahead, so the atomic's round trip is never waited for
     int tile = blockIdx.x;
-    float pre[PRE];
+    f32x4 pre[PRE];
     unsigned pre8[PRE];
     if (tile < total_tiles) { patch_load(tile, pre, pre8); patch_store(pre, pre8); }
     if (tid == 0) s_next[0] = atomicAdd(tile_counter, 1) + (int)gridDim.x;
@@ -956,7 +961,6 @@ int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
 struct vpk_cnn_state {
     Layer L[8];              // conv1..5, fc6..8
     float* mean = nullptr;
-    float* mean_pp = nullptr;   // the mean as 16 stride-4 phase planes (conv1_direct_kernel)
     bool loaded = false;
     // activations (grown on demand)
     float* act = nullptr;
@@ -981,7 +985,6 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.wsplit) (void)hipFree(l.wsplit);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
-    if (h->cnn->mean_pp) (void)hipFree(h->cnn->mean_pp);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
     if (h->cnn->ev_ready)
         for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
@@ -1129,7 +1132,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         } else {
             const int total = batch * C1_TR * C1_TC;
             hipLaunchKernelGGL(conv1_direct_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1D_THREADS), 0, st, sphere,
-                               S->mean_pp, S->L[0].wp, S->L[0].bias, R[R_POOL1], 65, 65, 2, ctr + 0, total);
+                               S->mean, S->L[0].wp, S->L[0].bias, R[R_POOL1], 65, 65, 2, ctr + 0, total);
         }
         mark();
         mark();
@@ -1281,14 +1284,6 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
     vpk_cnn_state* S = h->cnn;
     VPK_HIP(h, hipMalloc((void**)&S->mean, 500 * 500 * sizeof(float)));
     VPK_HIP(h, hipMemcpy(S->mean, mean, 500 * 500 * sizeof(float), hipMemcpyHostToDevice));
-    {   // the same blob as stride-4 phase planes, P[py][px][Y][X] = mean[4 Y + py][4 X + px] (conv1_direct_kernel's loader)
-        std::vector<float> pp((size_t)16 * C1_PW * C1_PW);
-        for (int y = 0; y < 500; ++y)
-            for (int x = 0; x < 500; ++x)
-                pp[(size_t)((y % C1_PH) * C1_PH + (x % C1_PH)) * (C1_PW * C1_PW) + (y / C1_PH) * C1_PW + x / C1_PH] = mean[y * 500 + x];
-        VPK_HIP(h, hipMalloc((void**)&S->mean_pp, pp.size() * sizeof(float)));
-        VPK_HIP(h, hipMemcpy(S->mean_pp, pp.data(), pp.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     for (int li = 0; li < 8; ++li) {
         const Topo& t = TOPO[li];
         Layer& l = S->L[li];
