@@ -142,6 +142,9 @@ def test_bench_modes_produce_a_valid_line(mode):
     if mode == "lanes":                                      # ... and the split-precision path is reported beside it
         alt = line["alt_precision"]
         assert alt["value"] > 0 and alt["steps"] == 3 and "bf16" in alt["cnn"]
+        fl = line["from_lines"]                              # ... and the same steps starting from the line sets:
+        assert fl["value"] > 0 and fl["steps"] == 3          # raster (own stream) -> CNN -> EM, pipelined, gives what the
+        assert fl["results_equal_unpipelined_pass"] is True  # three stages give one after the other
 
 
 @pytest.mark.parametrize("ranks", [2, 8])
