@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
     const double thr2 = (1.0 / 9.0) * (1.0 / 9.0);
     double lastx = 0, lasty = 0, origdx = 0, origdy = 0, orig_norm2 = 0, fwd_max = 0, bwd_max = 0, nextx = 0, nexty = 0, nbx = 0,
            nby = 0, startx = 0, starty = 0;
-    bool last_fwd = false, last_bwd = false, clipped = true;
+    bool last_fwd = false, last_bwd = false, clipped = true, started = false;
     int n = 0, overflow = 0;
     auto emit = [&](double x, double y) {
         if (n < MAXS) { if (lane == 0) { out[n].x = x; out[n].y = y; } ++n; } else overflow = 1;
@@ -127,14 +127,19 @@ __global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
         double be = -atan((-la * sa - lc * ca) / lb);                         // sphere_mapping.py:63
         be *= -1;                                                             // :65
         const double y = size - (be - lo_a) / (hi_a - lo_a) * size;
-        if (__ballot(valid && (!(y == y) || isinf(y))) != 0ull) {            // PathNanRemover's business: the sequential machine
+        const unsigned long long bad = __ballot(valid && (!(y == y) || isinf(y)));
+        unsigned long long pending = __ballot(valid);
+        if (bad != 0ull) {
+            // PathNanRemover's business.  A line whose samples are ALL non-finite (the all-zero line: 0 / 0 everywhere)
+            // draws nothing and is settled here; any other mixture goes to the sequential machine.
+            if (bad == pending && !started) continue;
             if (lane == 0) A.seq[g] = 1;
             return;
         }
-        unsigned long long pending = __ballot(valid);
-        if (c0 == 0) {                                                        // move_to
+        if (!started) {                                                       // move_to (the first finite sample)
+            if (c0 != 0) { if (lane == 0) A.seq[g] = 1; return; }             // (finite samples after non-finite ones: a broken path)
             lastx = lane_value(x, 0); lasty = lane_value(y, 0);
-            orig_norm2 = 0.0; bwd_max = 0.0; clipped = true;
+            orig_norm2 = 0.0; bwd_max = 0.0; clipped = true; started = true;
             pending &= ~1ull;
         }
         while (pending != 0ull) {
@@ -213,11 +218,13 @@ __global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
         }
     }
     // path_cmd_stop
-    if (orig_norm2 != 0.0) {
-        emit(nextx, nexty);
-        if (bwd_max > 0.0) emit(nbx, nby);
+    if (started) {
+        if (orig_norm2 != 0.0) {
+            emit(nextx, nexty);
+            if (bwd_max > 0.0) emit(nbx, nby);
+        }
+        emit(lastx, lasty);
     }
-    emit(lastx, lasty);
     if (lane == 0) { A.seq[g] = 0; A.nsimp[g] = n | (overflow ? 0x40000000 : 0); }
 }
 
