@@ -135,7 +135,8 @@ int vpk_em_flush(vpk_handle* h);
  * Copies to HBM (synchronous). */
 int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean);
 /* replaces: caffe_forward (evaluation.py:34-38) for a batch: sphere B x 500 x 500 uint8 ->
- * out B x 20 x 20 fp32 (sigout).  max batch per call is unbounded (internally chunked). */
+ * out B x 20 x 20 fp32 (sigout).  max batch per call is unbounded (internally chunked).  `sphere` must be 4-byte
+ * aligned (device allocations are). */
 int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out);
 /* debugging/parity: run the net and also return an intermediate blob by name index
  * (0=conv1 relu, 1=pool1, 2=conv2, 3=pool2, 4=conv3, 5=conv4, 6=conv5, 7=pool5, 8=fc6, 9=fc7,

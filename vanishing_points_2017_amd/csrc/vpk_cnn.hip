@@ -1363,6 +1363,8 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
 
 int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
     if (!h || !sphere || !out || batch < 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_forward: bad argument");
+    if (((size_t)sphere & 3) != 0)      // conv1's loader reads four horizontally adjacent pixels as one 4-byte word
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_forward: the rasters must be 4-byte aligned");
     if (!h->cnn || !h->cnn->loaded) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_forward before vpk_cnn_load");
     VPK_HIP(h, hipSetDevice(h->device));
     // activations for the whole batch stay in HBM; chunk only if they would exceed a third of it
