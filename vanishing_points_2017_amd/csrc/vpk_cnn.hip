@@ -915,21 +915,31 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_tiled_kernel(const float* __
     }
 }
 
-// MAX pooling 3x3 stride 2, Caffe ceil mode with clipped windows (deploy.prototxt:45-55)
-__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, long long BC, int H, int W,
-                               int PH, int PW, int ksz, int stride) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= BC * PH * PW) return;
-    int pw = (int)(idx % PW);
-    int ph = (int)((idx / PW) % PH);
-    long long bc = idx / ((long long)PW * PH);
-    int h0 = ph * stride, w0 = pw * stride;
-    int h1 = h0 + ksz < H ? h0 + ksz : H, w1 = w0 + ksz < W ? w0 + ksz : W;
-    const float* x = in + (size_t)bc * H * W;
-    float m = -3.402823466e38f;
-    for (int h = h0; h < h1; ++h)
-        for (int w = w0; w < w1; ++w) { float v = x[(size_t)h * W + w]; m = v > m ? v : m; }
-    out[idx] = m;
+// pool5 (deploy.prototxt:181-191): 3 x 3 / 2 max pool of unpadded 30 x 30 planes -> 15 x 15 (ceil mode: the last window is
+// clipped).  A workgroup stages PL whole planes in LDS with 16-byte loads (a plane is 3600 contiguous bytes; the windows
+// of neighbouring outputs overlap, and one thread per output reading its nine values from HBM ran at 2.3 TB/s), then
+// every thread takes pooled outputs out of LDS; stores are contiguous.  Maxima: order-free, same values.
+template <int PL>
+__global__ __launch_bounds__(256) void pool5_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes) {
+    constexpr int H = 30, W = 30, P = 15, HW = H * W, PP = P * P;
+    __shared__ __attribute__((aligned(16))) float s[PL * HW];
+    const long long p0 = (long long)blockIdx.x * PL;
+    const int np = planes - p0 < PL ? (int)(planes - p0) : PL;
+    const f32x4* src = reinterpret_cast<const f32x4*>(in + p0 * HW);
+    for (int q = threadIdx.x; q < np * HW / 4; q += 256) reinterpret_cast<f32x4*>(s)[q] = src[q];
+    __syncthreads();
+    float* dst = out + p0 * PP;
+    for (int e = threadIdx.x; e < np * PP; e += 256) {
+        const int pl = e / PP, o = e - pl * PP;
+        const int py = o / P, px = o - py * P;
+        const float* x = s + pl * HW + (2 * py) * W + 2 * px;
+        const bool by = 2 * py + 2 < H, bx = 2 * px + 2 < W;     // (only the last row / column of windows is clipped)
+        float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[W], x[W + 1]));
+        if (bx) m = fmaxf(m, fmaxf(x[2], x[W + 2]));
+        if (by) m = fmaxf(m, fmaxf(x[2 * W], x[2 * W + 1]));
+        if (bx && by) m = fmaxf(m, x[2 * W + 2]);
+        dst[e] = m;
+    }
 }
 
 // weight re-pack: Caffe [G*OC][K] (K contiguous) -> k-major panels [G][Kp][Mp], zero padded
@@ -1210,8 +1220,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
     if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long long)batch * 256 * 225)), dim3(256), 0, st, R[R_CONV5],
-                       R[R_POOL5], (long long)batch * 256, 30, 30, 15, 15, 3, 2);
+    hipLaunchKernelGGL((pool5_kernel<8>), dim3((unsigned)(((long long)batch * 256 + 7) / 8)), dim3(256), 0, st, R[R_CONV5], R[R_POOL5],
+                       (long long)batch * 256);
     mark();
     if ((rc = tapcopy(7, R[R_POOL5], A_POOL5))) return rc;
     // fc6 / fc7 / fc8: split-K partials + deterministic reduction (+ bias, ReLU / sigmoid)
