@@ -135,3 +135,29 @@ def test_split_path_beyond_4_gib_of_activations():
     assert np.abs(out[:6] - native).max() <= 2e-5
     twins = out.reshape(300, 6, 20, 20)
     assert np.array_equal(twins, np.broadcast_to(twins[:1], twins.shape))
+
+
+def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_pass(net_and_ref):
+    """conv1's loader reads four adjacent raster bytes as one word: a raster pointer that is not 4-byte aligned is an
+    argument error (never a silent wrong read).  And the two ways of forming float(raster) - mean -- in conv1's loader
+    (default) and as the fp32 pre-pass of the unfused path -- give the same response map to rounding."""
+    import torch
+    from vanishing_points_2017_amd._lib import VpkError
+    from vanishing_points_2017_amd import cnn
+    _, sphere, ref, _ = net_and_ref
+    net = cnn.Net(cnn.synthetic_weights(3), cnn.synthetic_mean(3))   # (other tests have loaded other weights on the handle)
+    rt = net.rt
+    with rt.on_stream():                                  # (the net's stream: the copies below are ordered before its kernels)
+        flat = torch.zeros(sphere.size + 8, dtype=torch.uint8, device=rt.tdev)
+        flat[1:1 + sphere.size] = torch.from_numpy(sphere.reshape(-1)).to(rt.tdev)
+        with pytest.raises(VpkError):
+            net.forward_device(flat[1:1 + sphere.size].view(sphere.shape))
+        flat[4:4 + sphere.size] = torch.from_numpy(sphere.reshape(-1)).to(rt.tdev)
+        out = net.forward_device(flat[4:4 + sphere.size].view(sphere.shape))
+    rt.synchronize()
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5
+    net.set_fusion(False)
+    unf = net.forward(sphere)
+    net.set_fusion(True)
+    assert np.abs(got - unf).max() <= 2e-5
