@@ -107,6 +107,7 @@ def load():
     lib.vpk_cnn_set_precision.argtypes = [c_void, ctypes.c_int]
     lib.vpk_cnn_last_layer_ms.argtypes = [c_void, ctypes.POINTER(ctypes.c_float)]
     lib.vpk_sphere_raster.argtypes = [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void]
+    lib.vpk_sphere_raster_flags.argtypes = [c_void, ctypes.c_int, c_void]
     lib.vpk_lsd_detect.argtypes = [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_int)]
     _lib = lib

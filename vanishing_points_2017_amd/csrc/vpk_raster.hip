@@ -407,9 +407,17 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         if (threadIdx.x == 63) {
             S.total[0] = incl; S.total[1] = ymin; S.total[2] = ymax;
             long long ab = -1, rb = 0;
-            if (incl > 0) {                               // space in the call's coverage pool (bump allocation)
-                ab = (long long)atomicAdd(A.bump, (unsigned long long)incl);
-                if ((unsigned long long)ab + incl > A.alpha_cap) ab = -1;
+            if (incl > 0) {
+                // space in the call's coverage pool: bump allocation by compare-and-swap, so that a polygon that does not fit
+                // is refused WITHOUT moving the counter -- it alone is dropped (and its image flagged), not every polygon
+                // that happens to ask after it
+                unsigned long long cur = *(volatile unsigned long long*)A.bump;
+                for (;;) {
+                    if (cur + (unsigned long long)incl > A.alpha_cap) { ab = -1; break; }
+                    const unsigned long long seen = atomicCAS(A.bump, cur, cur + (unsigned long long)incl);
+                    if (seen == cur) { ab = (long long)cur; break; }
+                    cur = seen;
+                }
             }
             S.base[0] = ab; S.base[1] = rb;
         }
@@ -722,7 +730,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
     const long long max_lines = 49152;
     const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 +
-                            16384 + (size_t)MAXSUB * size * sizeof(RowEnt) + 8;
+                            (size_t)MAXSUB * size * sizeof(RowEnt) + 8;
     long long chunk_lines = 0;
     for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
         b1 = b0 + 1;
@@ -733,7 +741,10 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const size_t fb = vpk::em_align(256 + (size_t)batch * 4, 256);
     const size_t tb = vpk::em_align((size_t)samples * 4 * 8, 256);
     const size_t nl = (size_t)chunk_lines + 4;
-    const size_t need = ob + fb + tb + nl * per_line + 8192;
+    // the coverage pool: 16 KB per line on average (measured: ~6 KB) and never less than eight canvases' worth -- the row
+    // ranges of ONE line can span most of the canvas (see polygon_coverage), and a call may consist of one line
+    const size_t alpha_bytes = std::max<size_t>(nl * 16384, (size_t)8 * size * (size + 2));
+    const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;
     const void* had = h->raster_hdr;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
@@ -776,7 +787,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
     A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
-    A.alpha = (unsigned char*)p; A.alpha_cap = nl * 16384; p += vpk::em_align(nl * 16384, 256);
+    A.alpha = (unsigned char*)p; A.alpha_cap = alpha_bytes; p += vpk::em_align(alpha_bytes, 256);
     A.dense = (RowEnt*)p;
     if (!h->raster_ready) {
         VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(blend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

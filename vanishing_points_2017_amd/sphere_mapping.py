@@ -4,6 +4,8 @@ import ctypes
 
 import numpy as np
 
+from ._lib import VpkError
+
 from .runtime import get_runtime
 
 
@@ -33,7 +35,18 @@ def raster_batch(lines_list, size=500, alpha=0.1, device=0):
         d = rt.torch.from_numpy(cat).to(rt.tdev)
     out = raster_batch_device(rt, d, offsets, size, alpha)
     rt.synchronize()
+    flags = raster_flags(rt, len(counts))
+    if flags.any():                                          # never a silently incomplete raster
+        raise VpkError("sphere raster: the kernel's buffers were too small for a line of image(s) %s (vertices per "
+                       "outline or coverage bytes): the raster of those images is incomplete" % np.nonzero(flags)[0].tolist())
     return out.cpu().numpy()
+
+
+def raster_flags(rt, batch):
+    """Per-image flags of the last raster call on rt's handle (waits for it): bit 0 = a line was truncated / dropped."""
+    flags = np.zeros(batch, dtype=np.uint32)
+    rt.check(rt.lib.vpk_sphere_raster_flags(rt.h, int(batch), flags.ctypes.data_as(ctypes.c_void_p)))
+    return flags
 
 
 def sphere_line_plot(lines, size, alpha=0.1, f=1.0, alternative=False, device=0):
