@@ -18,6 +18,7 @@ void draw_polygon(const V2* v, int n, unsigned grey, unsigned a8, int size, std:
     CellSink sink;
     sink.cover = cover.data(); sink.area = area.data(); sink.pcover = nullptr; sink.parea = nullptr;
     sink.rowmin = rowmin.data(); sink.rowmax = rowmax.data(); sink.rowoff = nullptr; sink.size = size;
+    sink.rmin = sink.rmax = sink.lcov = nullptr; sink.xs = 0x7fffffff;      // one range per row here
     sink.blo = 0; sink.bhi = size; sink.boff = 0;
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = sink;
@@ -109,6 +110,7 @@ extern "C" int sim_edge_shares(double x1, double y1, double x2, double y2, int s
     std::vector<int> c1((size_t)size * (size + 2), 0), a1(c1), c2(c1), a2(c1), rmin(size, 0x7fffffff), rmax(size, -1);
     CellSink s;
     s.pcover = s.parea = nullptr; s.rowmin = rmin.data(); s.rowmax = rmax.data(); s.rowoff = nullptr; s.size = size;
+    s.rmin = s.rmax = s.lcov = nullptr; s.xs = 0x7fffffff;
     s.blo = 0; s.bhi = size; s.boff = 0;
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size;
@@ -152,6 +154,7 @@ extern "C" int sim_polygon_balance(const double* l3, int size, double* out) {
     std::vector<int> cover((size_t)size * (size + 2), 0), area(cover), rmin(size, 0x7fffffff), rmax(size, -1);
     CellSink s;
     s.pcover = s.parea = nullptr; s.rowmin = rmin.data(); s.rowmax = rmax.data(); s.rowoff = nullptr; s.size = size;
+    s.rmin = s.rmax = s.lcov = nullptr; s.xs = 0x7fffffff;
     s.blo = 0; s.bhi = size; s.boff = 0; s.cover = cover.data(); s.area = area.data();
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = s; ec.nparts = K;

@@ -303,13 +303,24 @@ constexpr int POOL = 7040;              // cells (cover, area) of one polygon in
 enum SinkMode { BOUNDS = 0, POOLED = 1, GLOBAL = 2 };
 
 typedef RS_LDS int* lds_int_ptr;
+// A row's cells come in up to TWO ranges.  The curve is the graph of a function with at most one interior extremum, so a row
+// beside the apex is crossed twice, far apart, with nothing of the polygon in between: one range from the first to the last
+// cell would consist mostly of that gap (measured: 6 100 entries per line, 1 600 of them cells).  The polygon's cells are
+// therefore split at the apex column `xs`: cells left of it form the row's L range (rowmin / rowmax), the others its R range
+// (rmin / rmax).  A row piece that straddles xs makes the two adjacent; and a gap may only be dropped if nothing is to be
+// drawn in it, i.e. if the running cover across it -- the covers of the L cells, `lcov` -- is zero (the flat span at the
+// apex itself has cells at its two ends only and IS drawn in between).  After the row scan `lcov` holds, per row, the
+// number of L entries, or -1 if the row is one joined range [rowmin, rmax].
 struct CellSink {
     int* cover; int* area;              // GLOBAL: [size][size + 2], x shifted by one (cells at x = -1 and x = size exist)
     lds_int_ptr pcover, parea;          // POOLED: LDS pool
-    lds_int_ptr rowmin, rowmax, rowoff; // LDS, per row
+    lds_int_ptr rowmin, rowmax, rowoff; // LDS, per row: L range (cell index + 1), first pool entry
+    lds_int_ptr rmin, rmax, lcov;       // LDS, per row: R range; cover of the L pieces, then the split (see above)
+    int xs;                             // first cell column of the R side (host build: INT_MAX -- one range per row)
     int size;
     int blo, bhi, boff;                 // POOLED: the band of rows [blo, bhi) the pool holds now; pool index = rowoff - boff
 };
+RDEV_INLINE int row_len(int lo, int hi) { return hi >= lo ? hi - lo + 1 : 0; }
 // (the sink travels BY VALUE through the noinline walkers below: a pointer to it would be a pointer into the caller's
 //  private memory, and every field access a scratch load)
 template <int MODE> RDEV_INLINE void cell_add(const CellSink& s, int ex, int ey, int c, int a, int row_base) {
@@ -335,15 +346,29 @@ template <int MODE> RDEV_INLINE void cell_hline(const CellSink& s, int ey, int x
         int lo = ex1 < ex2 ? ex1 : ex2, hi = ex1 < ex2 ? ex2 : ex1;
         if (hi < -1 || lo > s.size) return;
         lo = lo < -1 ? -1 : lo; hi = hi > s.size ? s.size : hi;
-        RS_ATOMIC_MIN(s.rowmin + ey, lo + 1);
-        RS_ATOMIC_MAX(s.rowmax + ey, hi + 1);
+        if (hi < s.xs) {                      // a piece of the L side: its cells' covers add up to y2 - y1
+            RS_ATOMIC_MIN(s.rowmin + ey, lo + 1);
+            RS_ATOMIC_MAX(s.rowmax + ey, hi + 1);
+            if (s.lcov) RS_ATOMIC_ADD(s.lcov + ey, y2 - y1);
+        } else if (lo >= s.xs) {              // of the R side
+            RS_ATOMIC_MIN(s.rmin + ey, lo + 1);
+            RS_ATOMIC_MAX(s.rmax + ey, hi + 1);
+        } else {                              // across the split: the two ranges touch
+            RS_ATOMIC_MIN(s.rowmin + ey, lo + 1);
+            RS_ATOMIC_MAX(s.rowmax + ey, s.xs);
+            RS_ATOMIC_MIN(s.rmin + ey, s.xs + 1);
+            RS_ATOMIC_MAX(s.rmax + ey, hi + 1);
+        }
         return;
     }
     if (ey < 0 || ey >= s.size) return;
     int row_base = 0;
     if (MODE == POOLED) {                     // the row's entries in the pool: looked up once per row piece, not per cell
         if (ey < s.blo || ey >= s.bhi) return;
+        const int split = s.lcov[ey];         // entries of the L range, or -1: one joined range
+        const int lo = ex1 < ex2 ? ex1 : ex2;
         row_base = s.rowoff[ey] - s.boff + 1 - s.rowmin[ey];
+        if (split >= 0 && lo >= s.xs) row_base = s.rowoff[ey] - s.boff + split + 1 - s.rmin[ey];
     }
     if (ex1 == ex2) {
         const int delta = y2 - y1;

@@ -43,19 +43,22 @@ using namespace vpk_raster;
 //   blend_kernel     16 image rows x 8 column segments per workgroup, the rows' pixels in LDS: the image's lines IN
 //                    INPUT ORDER (the 8-bit blend does not commute), then the four spines; one coalesced store
 // ---------------------------------------------------------------------------------------------------------------
-// One polygon's coverage of one image row: alpha bytes [off, off + (len & ROW_LEN)) of the call's pool, first pixel xmin
-// (len & ROW_LEN == 0: the row is not touched).  The table is DENSE -- [line][sub-path][row] -- so that the blend can fetch
-// the entries of several lines at once without first reading anything about the lines; bits 12.. of `len` in sub-path 0 =
-// the line's further sub-paths (a NaN sample breaks the path: rare).
-struct RowEnt { unsigned off; short xmin; short len; };
+// One polygon's coverage of one image row: up to two ranges of pixels (raster_device.hpp: CellSink) whose alpha bytes lie back
+// to back in the call's pool -- L: pixels [xminL, xminL + lenL) at `off`, R: [xminR, xminR + lenR) at off + lenL (a length
+// of 0: no such range; both 0: the row is not touched).  The table is DENSE -- [line][sub-path][row] -- so that the blend can
+// fetch the entries of several lines at once without first reading anything about the lines; bits 12.. of `lenL` in
+// sub-path 0 = the line's further sub-paths (a NaN sample breaks the path: rare).
+struct RowEnt { unsigned off; short xminL, lenL, xminR, lenR; int pad; };
 constexpr int ROW_LEN = 0xfff, ROW_MORE_SHIFT = 12;
+constexpr int POLY_INTS = 1 + 3 * MAXSUB;                // per line: sub-paths, then (first vertex, vertices, split column) each
 
 struct RasterArgs {
     const double* l; const long long* offsets; const int* order; const double* tab;
     int batch; int size; int samples; unsigned a8; long long nlines; long long line0;   // this chunk: lines [line0, line0 + nlines)
     unsigned char* out; int* ctr; unsigned* flags;       // ctr[0]: line queue, [1]: unused; 64-bit bump counters follow
     unsigned long long* bump;                            // [0]: alpha bytes used, [1]: row refs used
-    V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, 1 + 2 * MAXSUB
+    V2* simp; V2* verts; int* polys;                     // per line: MAXS, MAXV, POLY_INTS
+    int pool, rowcap;                                    // coverage_kernel: pool entries and row-array length in (dynamic) LDS
     int probe;                                           // VPK_RASTER_TIMES: workgroup 0 of coverage_kernel times its phases
     int* seq; int* nsimp; int force_seq;                 // per line: 1 = left to the sequential machine; points kept by simplify_kernel
     unsigned char* alpha; unsigned long long alpha_cap;
@@ -236,8 +239,19 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
     unsigned dummy = 0;
     unsigned* fl = &dummy;
     o.v = A.verts + (size_t)g * MAXV; o.n = 0; o.cap = MAXV; o.flags = fl;
-    int* pt = A.polys + g * (1 + 2 * MAXSUB);
+    int* pt = A.polys + g * POLY_INTS;
     const int size = A.size;
+    // the column at which coverage_kernel splits the rows' cells in two ranges: the curve's interior extremum (a row beside
+    // it is crossed twice, far apart); any column is correct, this one saves the most.  From the kept points of the path.
+    auto split_column = [&](const V2* p, int n) {
+        int imin = 0, imax = 0;
+        for (int k = 1; k < n; ++k) { if (p[k].y < p[imin].y) imin = k; if (p[k].y > p[imax].y) imax = k; }
+        const double xa = p[imin].x, xb = p[imax].x;
+        const double da = xa < size - xa ? xa : size - xa, db = xb < size - xb ? xb : size - xb;   // distance from the canvas's sides
+        const double x = da >= db ? xa : xb;
+        const int c = (int)floor(x);
+        return c < 0 ? 0 : (c > size ? size : c);
+    };
     if (g >= A.nlines) {
         // the axes' spines: left, right, bottom, top (matplotlib's drawing order): two-vertex rectilinear paths, snapped to
         // pixel centres (PathSnapper: floor(v + 0.5) + 0.5 for a stroke whose width rounds to an odd number of pixels)
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         sp[0].x = floor(x0 + 0.5) + 0.5; sp[0].y = floor(y0 + 0.5) + 0.5;
         sp[1].x = floor(x1 + 0.5) + 0.5; sp[1].y = floor(y1 + 0.5) + 0.5;
         stroke_outline(sp, 2, w_spine, o);
-        pt[0] = 1; pt[1] = 0; pt[2] = o.n;
+        pt[0] = 1; pt[1] = 0; pt[2] = o.n; pt[3] = size + 2;        // (a spine: one range per row)
         return;
     }
     const double width_px = 100.0 / 72.0;                 // 1 pt at 100 dpi (matplotlib 1.5.1's default line width)
@@ -261,9 +275,10 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         sm.end();
         if (sm.n >= 2) {
             const int first = o.n;
+            const int xsp = split_column(sp, sm.n);
             stroke_outline(sp, sm.n, width_px, o);
             if (o.n - first >= 3) {
-                if (npoly < MAXSUB) { pt[1 + 2 * npoly] = first; pt[2 + 2 * npoly] = o.n - first; ++npoly; }
+                if (npoly < MAXSUB) { pt[1 + 3 * npoly] = first; pt[2 + 3 * npoly] = o.n - first; pt[3 + 3 * npoly] = xsp; ++npoly; }
                 else dummy |= FLAG_OVERFLOW;
             }
         }
@@ -295,8 +310,9 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
         if (k & 0x40000000) dummy |= FLAG_OVERFLOW;
         sm.have = false;
         if (sm.n >= 2) {
+            const int xsp = split_column(sp, sm.n);
             stroke_outline(sp, sm.n, width_px, o);
-            if (o.n >= 3) { pt[1] = 0; pt[2] = o.n; npoly = 1; }
+            if (o.n >= 3) { pt[1] = 0; pt[2] = o.n; pt[3] = xsp; npoly = 1; }
         }
         sm.n = 0;
     }
@@ -318,14 +334,16 @@ constexpr int LVERT = 256;                               // vertices of a polygo
 struct CovShared {
     int* total; long long* base; unsigned short* eoff; V2* vert; int* tail;
 };
-__device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int size, const CovShared& S, const RasterArgs& A,
+__device__ bool polygon_coverage(const V2* v, int n, int xsplit, const CellSink& sink, int size, const CovShared& S, const RasterArgs& A,
                                  RowEnt* ent, int more) {
     const bool probe = A.probe && threadIdx.x == 0 && blockIdx.x == 0;
     long long tp = probe ? wall_clock64() : 0;
     auto lap = [&](int slot) { if (probe) { const long long now = wall_clock64(); atomicAdd(A.ctr + 8 + slot, (int)(now - tp)); tp = now; } };
     unsigned short* s_eoff = S.eoff;
+    const int POOL = A.pool;
     EdgeClip ec;
     ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = sink;
+    ec.c.xs = xsplit;
     // Work items = (edge, share of its rows).  An outline has ~120 edges of which most cross one to three rows and a few
     // thirty or more; an item costs the clipper's and the walker's set-up (divisions in double and in int) before its first
     // cell, so an edge gets one share per ROWS_PER_ITEM rows it crosses -- not a fixed number of shares (with 4 RT / n
@@ -372,20 +390,29 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
     };
     Work mine = {};                                       // this thread's first item: the same in both passes
     if ((int)threadIdx.x < items) mine = work_item(threadIdx.x);
-    for (int it = threadIdx.x; it < items; it += RT) {    // pass 1: the rows' cell ranges
+    for (int it = threadIdx.x; it < items; it += RT) {    // pass 1: the rows' cell ranges (L and R of the split column)
         const Work w = it == (int)threadIdx.x ? mine : work_item(it);
         ec.part = w.part; ec.nparts = w.nparts;
         ec.edge<BOUNDS>(w.a.x, w.a.y, w.b.x, w.b.y);
     }
     __syncthreads();
     lap(0);
-    // exclusive prefix sum of the ranges' lengths over the rows (one wave), first / last touched row
+    // A row's pool entries: its L range then its R range, or -- if they touch, or if something is to be drawn between them
+    // (lcov != 0) -- ONE range from the first L cell to the last R cell.  lcov becomes the number of L entries (-1: joined).
+    auto row_entries = [&](int y) {
+        const int sp = sink.lcov[y];
+        return sp < 0 ? sink.rmax[y] - sink.rowmin[y] + 1 : sp + row_len(sink.rmin[y], sink.rmax[y]);
+    };
+    // exclusive prefix sum of the rows' entries (one wave), first / last touched row
     if (threadIdx.x < 64) {
         const int per = (size + 63) / 64;
         const int y0 = threadIdx.x * per;
         int sum = 0, ymin = 0x7fffffff, ymax = -1;
         for (int y = y0; y < y0 + per && y < size; ++y) {
-            const int len = sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
+            const int ll = row_len(sink.rowmin[y], sink.rowmax[y]), rl = row_len(sink.rmin[y], sink.rmax[y]);
+            const bool joined = ll > 0 && rl > 0 && (sink.rowmax[y] + 1 >= sink.rmin[y] || sink.lcov[y] != 0);
+            sink.lcov[y] = joined ? -1 : ll;
+            const int len = joined ? sink.rmax[y] - sink.rowmin[y] + 1 : ll + rl;
             if (len) { ymin = ymin < y ? ymin : y; ymax = y; }
             sum += len;
         }
@@ -397,7 +424,7 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         int off = incl - sum;
         for (int y = y0; y < y0 + per && y < size; ++y) {
             sink.rowoff[y] = off;
-            off += sink.rowmax[y] >= sink.rowmin[y] ? sink.rowmax[y] - sink.rowmin[y] + 1 : 0;
+            off += row_entries(y);
         }
         for (int o = 32; o > 0; o >>= 1) {
             const int a = __shfl_xor(ymin, o), b = __shfl_xor(ymax, o);
@@ -406,37 +433,32 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         }
         if (threadIdx.x == 63) {
             S.total[0] = incl; S.total[1] = ymin; S.total[2] = ymax;
-            long long ab = -1, rb = 0;
+            long long ab = -1;
             if (incl > 0) {
-                // space in the call's coverage pool: bump allocation by compare-and-swap, so that a polygon that does not fit
-                // is refused WITHOUT moving the counter -- it alone is dropped (and its image flagged), not every polygon
-                // that happens to ask after it
-                unsigned long long cur = *(volatile unsigned long long*)A.bump;
-                for (;;) {
-                    if (cur + (unsigned long long)incl > A.alpha_cap) { ab = -1; break; }
-                    const unsigned long long seen = atomicCAS(A.bump, cur, cur + (unsigned long long)incl);
-                    if (seen == cur) { ab = (long long)cur; break; }
-                    cur = seen;
-                }
+                // space in the call's coverage pool: one atomic add; a polygon that does not fit gives its bytes back, so that
+                // it alone is dropped (and its image flagged), not every polygon that asks after it.  (A compare-and-swap loop
+                // on the one counter, 512 workgroups contending, cost 100 ms per call.)
+                const unsigned long long old = atomicAdd(A.bump, (unsigned long long)incl);
+                if (old + (unsigned long long)incl > A.alpha_cap) atomicAdd(A.bump, 0ull - (unsigned long long)incl);
+                else ab = (long long)old;
             }
-            S.base[0] = ab; S.base[1] = rb;
+            S.base[0] = ab;
         }
     }
     __syncthreads();
     lap(1);
     const int total = S.total[0], ymin = S.total[1], ymax = S.total[2];
     const long long ab = S.base[0];
-    const bool ok = ab >= 0;                              // (a polygon past the call's HBM pools is dropped and flagged)
-    // The pool holds the cell ranges of a BAND of rows at a time: all touched rows when they fit (the usual case), else as
-    // many consecutive rows as fit -- a curve with an interior extremum crosses the rows beside it twice, far apart, and a
-    // row's range spans both crossings.
+    const bool ok = ab >= 0;                              // (a polygon past the call's HBM pool is dropped and flagged)
+    // The LDS pool holds the entries of a BAND of rows at a time: all touched rows when they fit (the usual case), else as
+    // many consecutive rows as fit.
     int ys = ok ? ymin : size;
     while (ys <= ymax && ys < size) {
         int ye = ys + 1;                                  // (uniform: every thread walks the same prefix sums)
         const int boff = sink.rowoff[ys];
         if (total <= POOL) ye = ymax + 1;                  // everything fits: one band
-        else while (ye <= ymax && sink.rowoff[ye] + (sink.rowmax[ye] >= sink.rowmin[ye] ? sink.rowmax[ye] - sink.rowmin[ye] + 1 : 0) - boff <= POOL) ++ye;
-        CellSink band = sink;
+        else while (ye <= ymax && sink.rowoff[ye] + row_entries(ye) - boff <= POOL) ++ye;
+        CellSink band = ec.c;
         band.blo = ys; band.bhi = ye; band.boff = boff;
         ec.c = band;
         for (int it = threadIdx.x; it < items; it += RT) {    // pass 2: the cells of the band's rows
@@ -447,17 +469,15 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         __syncthreads();
         lap(2);
         // The sweep (the per-pixel form of sweep_scanline, see blend_kernel) over the band's pool entries, which are the
-        // rows' cell ranges back to back: every thread takes an equal run of consecutive entries -- not a row: rows are 1
-        // to 500 entries long --, the running cover at the start of its run being the covers of its row before it.
+        // rows' entries back to back: every thread takes an equal run of consecutive entries -- not a row: rows are 1
+        // to 500 entries long --, the running cover at the start of its run being the covers of its row before it.  (The
+        // running cover simply continues from a row's L entries into its R entries: it is 0 across a dropped gap.)
         const int last = ye - 1;
-        const int bend = sink.rowoff[last] + (sink.rowmax[last] >= sink.rowmin[last] ? sink.rowmax[last] - sink.rowmin[last] + 1 : 0);
+        const int bend = sink.rowoff[last] + row_entries(last);
         const int E = bend - boff, C = (E + RT - 1) / RT;
         const int q0 = threadIdx.x * C, q1 = q0 + C < E ? q0 + C : E;
         int y = ys, row_lo = 0, row_hi = 0;               // the row of entry q0: pool entries [row_lo, row_hi)
-        auto row_span = [&](int yy) {
-            const int len = sink.rowmax[yy] >= sink.rowmin[yy] ? sink.rowmax[yy] - sink.rowmin[yy] + 1 : 0;
-            row_lo = sink.rowoff[yy] - boff; row_hi = row_lo + len;
-        };
+        auto row_span = [&](int yy) { row_lo = sink.rowoff[yy] - boff; row_hi = row_lo + row_entries(yy); };
         if (q0 < q1) {
             int lo = ys, hi = ye;                         // last row whose offset is <= q0 (an empty row shares its successor's)
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sink.rowoff[mid] - boff <= q0) lo = mid; else hi = mid; }
@@ -466,7 +486,7 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
             int tail = 0, started = 0, yy = y, rhi = row_hi;
             for (int q = q0; q < q1; ++q) {
                 if (q == rhi) {                           // the next non-empty row starts at this entry
-                    do { ++yy; rhi = sink.rowoff[yy] - boff + (sink.rowmax[yy] >= sink.rowmin[yy] ? sink.rowmax[yy] - sink.rowmin[yy] + 1 : 0); } while (q == rhi);
+                    do { ++yy; rhi = sink.rowoff[yy] - boff + row_entries(yy); } while (q == rhi);
                     tail = 0; started = 1;
                 }
                 tail += sink.pcover[q];
@@ -491,10 +511,13 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
             }
         }
         for (int yy = ys + threadIdx.x; yy < ye; yy += RT) {
-            const int lo = sink.rowmin[yy], hi = sink.rowmax[yy];
+            const int sp = sink.lcov[yy];
+            const int ll = sp < 0 ? sink.rmax[yy] - sink.rowmin[yy] + 1 : sp, rl = sp < 0 ? 0 : row_len(sink.rmin[yy], sink.rmax[yy]);
             RowEnt r;
-            r.off = (unsigned)(ab + sink.rowoff[yy]); r.xmin = (short)(lo - 1); r.len = (short)((hi >= lo ? hi - lo + 1 : 0) | more);
-            if (hi < lo) { r.off = 0; r.xmin = 0; }
+            r.off = (unsigned)(ab + sink.rowoff[yy]);
+            r.xminL = (short)(ll ? sink.rowmin[yy] - 1 : 0); r.lenL = (short)(ll | more);
+            r.xminR = (short)(rl ? sink.rmin[yy] - 1 : 0); r.lenR = (short)rl;
+            r.pad = 0;
             ent[yy] = r;
         }
         __syncthreads();
@@ -507,31 +530,40 @@ __device__ bool polygon_coverage(const V2* v, int n, const CellSink& sink, int s
         ys = ye;
     }
     for (int y = threadIdx.x; y < size; y += RT) {
-        if (!ok || y < ymin || y > ymax) { RowEnt r; r.off = 0; r.xmin = 0; r.len = (short)more; ent[y] = r; }   // rows the polygon leaves alone
-        sink.rowmin[y] = 0x7fffffff; sink.rowmax[y] = -1;
+        if (!ok || y < ymin || y > ymax) {                // rows the polygon leaves alone
+            RowEnt r;
+            r.off = 0; r.xminL = 0; r.lenL = (short)more; r.xminR = 0; r.lenR = 0; r.pad = 0;
+            ent[y] = r;
+        }
+        sink.rowmin[y] = 0x7fffffff; sink.rowmax[y] = -1; sink.rmin[y] = 0x7fffffff; sink.rmax[y] = -1; sink.lcov[y] = 0;
     }
     __syncthreads();
     return ok || total == 0;
 }
 
 __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 waves per SIMD: two workgroups per CU
-    __shared__ int s_rowmin[1024], s_rowmax[1024], s_rowoff[1024];
-    __shared__ int s_pcover[POOL], s_parea[POOL];
+    extern __shared__ int s_dyn[];                       // six row arrays of A.rowcap ints, then the pool (cover, area)
     __shared__ int s_next, s_total[4];
     __shared__ unsigned short s_eoff[MAXV + 2];          // first work item of every edge of the polygon at hand
     __shared__ V2 s_vert[LVERT + 1];                     // its vertices (closed: [n] = [0])
     __shared__ long long s_base[2];
-    const int size = A.size;
+    __shared__ int s_tail[2 * RT];                       // the sweep's per-thread partial sums
+    const int size = A.size, rc = A.rowcap;
+    int* s_rowmin = s_dyn; int* s_rowmax = s_dyn + rc; int* s_rowoff = s_dyn + 2 * rc;
+    int* s_rmin = s_dyn + 3 * rc; int* s_rmax = s_dyn + 4 * rc; int* s_lcov = s_dyn + 5 * rc;
+    int* s_pcover = s_dyn + 6 * rc; int* s_parea = s_pcover + A.pool;
     CellSink sink;
     sink.cover = nullptr; sink.area = nullptr;
     sink.rowmin = (lds_int_ptr)s_rowmin; sink.rowmax = (lds_int_ptr)s_rowmax; sink.rowoff = (lds_int_ptr)s_rowoff; sink.size = size;
+    sink.rmin = (lds_int_ptr)s_rmin; sink.rmax = (lds_int_ptr)s_rmax; sink.lcov = (lds_int_ptr)s_lcov; sink.xs = 0;
     sink.pcover = (lds_int_ptr)s_pcover; sink.parea = (lds_int_ptr)s_parea;
+    sink.blo = 0; sink.bhi = 0; sink.boff = 0;
     CovShared S;
-    S.total = s_total; S.base = s_base; S.eoff = s_eoff; S.vert = s_vert;
-    __shared__ int s_tail[2 * RT];                       // the sweep's per-thread partial sums
-    S.tail = s_tail;
-    for (int y = threadIdx.x; y < 1024; y += RT) { s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; }
-    for (int q = threadIdx.x; q < POOL; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
+    S.total = s_total; S.base = s_base; S.eoff = s_eoff; S.vert = s_vert; S.tail = s_tail;
+    for (int y = threadIdx.x; y < rc; y += RT) {
+        s_rowmin[y] = 0x7fffffff; s_rowmax[y] = -1; s_rowoff[y] = 0; s_rmin[y] = 0x7fffffff; s_rmax[y] = -1; s_lcov[y] = 0;
+    }
+    for (int q = threadIdx.x; q < A.pool; q += RT) { s_pcover[q] = 0; s_parea[q] = 0; }   // the sweeps leave the pool zero again
     if (threadIdx.x == 0) s_next = atomicAdd(A.ctr, 1);
     __syncthreads();
     for (;;) {
@@ -540,14 +572,14 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
         if (g >= A.nlines + 4) break;
         int nx = 0;
         if (threadIdx.x == 0) nx = atomicAdd(A.ctr, 1);  // the line after this one: the round trip runs beside the work below
-        const int* pt = A.polys + g * (1 + 2 * MAXSUB);
+        const int* pt = A.polys + g * POLY_INTS;
         const int npoly = pt[0];
         const int more = (npoly > 1 ? npoly - 1 : 0) << ROW_MORE_SHIFT;
         for (int q = 0; q < (npoly > 0 ? npoly : 1); ++q) {
             RowEnt* ent = A.dense + ((size_t)g * MAXSUB + q) * size;
             if (q < npoly) {
-                const bool ok = polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 2 * q], pt[2 + 2 * q], sink, size, S, A, ent,
-                                                 q == 0 ? more : 0);
+                const bool ok = polygon_coverage(A.verts + (size_t)g * MAXV + pt[1 + 3 * q], pt[2 + 3 * q], pt[3 + 3 * q], sink, size, S,
+                                                 A, ent, q == 0 ? more : 0);
                 if (!ok && threadIdx.x == 0 && g < A.nlines) {                      // dropped: tell the line's image
                     int lo = 0, hi = A.batch;
                     const long long gl = A.line0 + g;
@@ -555,7 +587,11 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
                     atomicOr(A.flags + A.first_image + lo, FLAG_OVERFLOW);
                 }
             } else {                                      // a line that left no polygon: an empty sub-path 0
-                for (int y = threadIdx.x; y < size; y += RT) { RowEnt r; r.off = 0; r.xmin = 0; r.len = 0; ent[y] = r; }
+                for (int y = threadIdx.x; y < size; y += RT) {
+                    RowEnt r;
+                    r.off = 0; r.xminL = 0; r.lenL = 0; r.xminR = 0; r.lenR = 0; r.pad = 0;
+                    ent[y] = r;
+                }
             }
         }
         if (threadIdx.x == 0) s_next = nx;
@@ -596,7 +632,7 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     __syncthreads();
     if (y < size) {
         const RowEnt* dl = A.dense + y;                   // this row's entries: dl[(line * MAXSUB + sub-path) * size]
-        const RowEnt none = {0u, 0, 0};
+        struct Range { unsigned off; int xmin, len; };    // one range of an entry: pixels [xmin, xmin + len), bytes at off
         // eight consecutive pixels.  Through the tables every step is eight independent LDS reads (old pixels, colour alphas,
         // new pixels: alpha 0 maps a pixel to itself), then the writes -- of the pixels with coverage only: a thread must not
         // touch its neighbours' columns, not even to write back what it read.  (Eight `if (cover) pixel = ...` in a row
@@ -619,47 +655,47 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
                 if (av[u]) row[x] = (unsigned char)blend(row[x], grey, a8, av[u]);
             }
         };
-        auto seg_range = [&](const RowEnt& e, int& qlo, int& qhi) {   // the entry's bytes that fall into this thread's columns
-            const int len = e.len & ROW_LEN;
-            qlo = x0 - e.xmin > 0 ? x0 - e.xmin : 0;
-            qhi = x1 - e.xmin < len ? x1 - e.xmin : len;
+        auto seg_range = [&](const Range& r, int& qlo, int& qhi) {    // the range's bytes that fall into this thread's columns
+            qlo = x0 - r.xmin > 0 ? x0 - r.xmin : 0;
+            qhi = x1 - r.xmin < r.len ? x1 - r.xmin : r.len;
         };
         // (loads are issued unconditionally -- a slot outside the range reads the pool's first byte and is masked afterwards --
         //  so that the compiler can COUNT the loads in flight: a skipped load makes every later wait a wait for everything)
-        auto fetch8 = [&](const RowEnt& e, int q0, int qhi, unsigned (&av)[8]) {
-            const unsigned char* al = A.alpha + e.off;
+        auto fetch8 = [&](const Range& r, int q0, int qhi, unsigned (&av)[8]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = A.alpha[q0 + u < qhi ? (size_t)e.off + q0 + u : 0];
-            (void)al;
+            for (int u = 0; u < 8; ++u) av[u] = A.alpha[q0 + u < qhi ? (size_t)r.off + q0 + u : 0];
         };
         auto mask8 = [&](int q0, int qhi, unsigned (&av)[8]) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? av[u] : 0u;
         };
-        auto rest = [&](const RowEnt& e, int qlo, int qhi, unsigned grey, unsigned a8, bool use_tables) {   // bytes past the first eight
+        auto rest = [&](const Range& r, int qlo, int qhi, unsigned grey, unsigned a8, bool use_tables) {   // bytes past the first eight
             for (int q0 = qlo + 8; q0 < qhi; q0 += 8) {
                 unsigned av[8];
-                fetch8(e, q0, qhi, av);
+                fetch8(r, q0, qhi, av);
                 mask8(q0, qhi, av);
-                blend8(av, e.xmin + q0, grey, a8, use_tables);
+                blend8(av, r.xmin + q0, grey, a8, use_tables);
             }
         };
-        auto whole = [&](const RowEnt& e, unsigned grey, unsigned a8, bool use_tables) {
+        auto whole = [&](const Range& r, unsigned grey, unsigned a8, bool use_tables) {
             int qlo, qhi;
-            seg_range(e, qlo, qhi);
+            seg_range(r, qlo, qhi);
             if (qlo < qhi) {
                 unsigned av[8];
-                fetch8(e, qlo, qhi, av);
+                fetch8(r, qlo, qhi, av);
                 mask8(qlo, qhi, av);
-                blend8(av, e.xmin + qlo, grey, a8, use_tables);
-                rest(e, qlo, qhi, grey, a8, use_tables);
+                blend8(av, r.xmin + qlo, grey, a8, use_tables);
+                rest(r, qlo, qhi, grey, a8, use_tables);
             }
         };
+        auto range_l = [&](const RowEnt& e) { Range r; r.off = e.off; r.xmin = e.xminL; r.len = e.lenL & ROW_LEN; return r; };
+        auto range_r = [&](const RowEnt& e) { Range r; r.off = e.off + (unsigned)(e.lenL & ROW_LEN); r.xmin = e.xminR; r.len = e.lenR; return r; };
         // The image's lines in order -- the blend does not commute -- but FETCHED ahead: the dense table needs no knowledge
-        // about a line to address its entry, so while group k (BL lines) is blended (LDS), the first eight alpha bytes of
-        // group k + 1 and the entries of group k + 2 are in flight.
-        constexpr int BL = 2;
+        // about a line to address its entry, so while group k (BL lines, two ranges each) is blended (LDS), the first eight
+        // alpha bytes of group k + 1's ranges and the entries of group k + 2 are in flight.
+        constexpr int BL = 2, NR = 2 * BL;
         const long long last = hi - 1;
+        const RowEnt none = {0u, 0, 0, 0, 0, 0};
         auto entries = [&](long long g0, RowEnt (&e)[BL]) {
 #pragma unroll
             for (int u = 0; u < BL; ++u) {
@@ -671,41 +707,57 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
 #pragma unroll
             for (int u = 0; u < BL; ++u) if (!(g0 + u < hi)) e[u] = none;
         };
+        auto ranges_of = [&](const RowEnt (&e)[BL], Range (&r)[NR]) {
+#pragma unroll
+            for (int u = 0; u < BL; ++u) { r[2 * u] = range_l(e[u]); r[2 * u + 1] = range_r(e[u]); }
+        };
         RowEnt e0[BL], e1[BL], e2[BL];
-        unsigned av0[BL][8], av1[BL][8];
-        int ql0[BL], qh0[BL], ql1[BL], qh1[BL];
+        Range r0[NR], r1[NR];
+        unsigned av0[NR][8], av1[NR][8];
+        int ql0[NR], qh0[NR], ql1[NR], qh1[NR];
         if (lo < hi) {
             entries(lo, e0); entries(lo + BL, e1);
             settle(lo, e0);
+            ranges_of(e0, r0);
 #pragma unroll
-            for (int u = 0; u < BL; ++u) { seg_range(e0[u], ql0[u], qh0[u]); fetch8(e0[u], ql0[u], qh0[u], av0[u]); }
+            for (int u = 0; u < NR; ++u) { seg_range(r0[u], ql0[u], qh0[u]); fetch8(r0[u], ql0[u], qh0[u], av0[u]); }
         }
         for (long long g0 = lo; g0 < hi; g0 += BL) {
             entries(g0 + 2 * BL, e2);
             settle(g0 + BL, e1);
+            ranges_of(e1, r1);
 #pragma unroll
-            for (int u = 0; u < BL; ++u) { seg_range(e1[u], ql1[u], qh1[u]); fetch8(e1[u], ql1[u], qh1[u], av1[u]); }
+            for (int u = 0; u < NR; ++u) { seg_range(r1[u], ql1[u], qh1[u]); fetch8(r1[u], ql1[u], qh1[u], av1[u]); }
 #pragma unroll
-            for (int u = 0; u < BL; ++u) {
+            for (int u = 0; u < NR; ++u) {
                 if (ql0[u] < qh0[u]) {
                     mask8(ql0[u], qh0[u], av0[u]);
-                    if (tables) { blend8(av0[u], e0[u].xmin + ql0[u], 255u, A.a8, true); rest(e0[u], ql0[u], qh0[u], 255u, A.a8, true); }
-                    else { blend8(av0[u], e0[u].xmin + ql0[u], 255u, A.a8, false); rest(e0[u], ql0[u], qh0[u], 255u, A.a8, false); }
+                    if (tables) { blend8(av0[u], r0[u].xmin + ql0[u], 255u, A.a8, true); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, true); }
+                    else { blend8(av0[u], r0[u].xmin + ql0[u], 255u, A.a8, false); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, false); }
                 }
-                const int more = (e0[u].len >> ROW_MORE_SHIFT) & 7;           // further sub-paths of the line (rare)
-                for (int q = 1; q <= more; ++q) {
-                    const RowEnt f = dl[((size_t)(g0 + u) * MAXSUB + q) * size];
-                    if (tables) whole(f, 255u, A.a8, true); else whole(f, 255u, A.a8, false);
+                if (u & 1) {                              // after a line's second range: its further sub-paths (rare)
+                    const int more = (e0[u >> 1].lenL >> ROW_MORE_SHIFT) & 7;
+                    for (int q = 1; q <= more; ++q) {
+                        const RowEnt f = dl[((size_t)(g0 + (u >> 1)) * MAXSUB + q) * size];
+                        if (tables) { whole(range_l(f), 255u, A.a8, true); whole(range_r(f), 255u, A.a8, true); }
+                        else { whole(range_l(f), 255u, A.a8, false); whole(range_r(f), 255u, A.a8, false); }
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < BL; ++u) {
-                e0[u] = e1[u]; e1[u] = e2[u]; ql0[u] = ql1[u]; qh0[u] = qh1[u];
+            for (int u = 0; u < BL; ++u) { e0[u] = e1[u]; e1[u] = e2[u]; }
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                r0[u] = r1[u]; ql0[u] = ql1[u]; qh0[u] = qh1[u];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) av0[u][k] = av1[u][k];
             }
         }
-        for (int side = 0; side < 4; ++side) whole(dl[(size_t)(A.nlines + side) * MAXSUB * size], 0u, 255u, false);
+        for (int side = 0; side < 4; ++side) {
+            const RowEnt f = dl[(size_t)(A.nlines + side) * MAXSUB * size];
+            whole(range_l(f), 0u, 255u, false);
+            whole(range_r(f), 0u, 255u, false);
+        }
     }
     __syncthreads();
     // coalesced store of the workgroup's rows
@@ -729,7 +781,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const int samples = 10000;                            // sphere_mapping.py:40
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
     const long long max_lines = 49152;
-    const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + (1 + 2 * MAXSUB) * 4 +
+    const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + POLY_INTS * 4 +
                             (size_t)MAXSUB * size * sizeof(RowEnt) + 8;
     long long chunk_lines = 0;
     for (int b0 = 0, b1; b0 < batch; b0 = b1) {           // the largest chunk decides the workspace
@@ -786,12 +838,19 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.force_seq = getenv("VPK_RASTER_SEQUENTIAL") != nullptr;   // development / tests: every line through the sequential machine
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
-    A.polys = (int*)p; p += vpk::em_align(nl * (1 + 2 * MAXSUB) * 4, 256);
+    A.polys = (int*)p; p += vpk::em_align(nl * POLY_INTS * 4, 256);
     A.alpha = (unsigned char*)p; A.alpha_cap = alpha_bytes; p += vpk::em_align(alpha_bytes, 256);
     A.dense = (RowEnt*)p;
+    // coverage_kernel's LDS: two workgroups per CU (80 KB each); what the static arrays and the six row arrays leave is the pool
+    constexpr int COV_LDS = 80 * 1024, COV_STATIC = 11 * 1024;
+    A.rowcap = (size + 63) & ~63;
+    A.pool = ((COV_LDS - COV_STATIC - 6 * A.rowcap * 4) / 8) & ~63;
+    const size_t cov_dyn = (size_t)(6 * A.rowcap + 2 * A.pool) * 4;
     if (!h->raster_ready) {
         VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(blend_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        BROWS * 1024 + 256 + (BLEND_LUT_MAX_A8 + 1) * 256));
+        VPK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(coverage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       COV_LDS - COV_STATIC));
         h->raster_ready = true;
     }
     const int ldp = (size + 3) & ~3;
@@ -811,7 +870,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
         const int wgs = (int)std::min<long long>(nt, 2ll * h->num_cu);      // two workgroups fit a CU (LDS: 76 KB each)
-        hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), 0, h->stream, A);
+        hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), cov_dyn, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[2], h->stream));
         hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS * BSEG),
                            (size_t)BROWS * ldp + 256 + (A.a8 <= BLEND_LUT_MAX_A8 ? (size_t)(A.a8 + 1) * 256 : 0), h->stream, A);
