@@ -659,21 +659,22 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
             qlo = x0 - r.xmin > 0 ? x0 - r.xmin : 0;
             qhi = x1 - r.xmin < r.len ? x1 - r.xmin : r.len;
         };
-        // (loads are issued unconditionally -- a slot outside the range reads the pool's first byte and is masked afterwards --
-        //  so that the compiler can COUNT the loads in flight: a skipped load makes every later wait a wait for everything)
-        auto fetch8 = [&](const Range& r, int q0, int qhi, unsigned (&av)[8]) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = A.alpha[q0 + u < qhi ? (size_t)r.off + q0 + u : 0];
+        // Eight alpha bytes are ONE unaligned 8-byte load (the hardware takes unaligned global addresses; up to seven bytes
+        // past the range's end are read and masked away: the pool has slack behind it).  Loads are issued unconditionally
+        // -- an empty range reads the pool's first bytes -- so that the compiler can COUNT the loads in flight: a skipped
+        // load makes every later wait a wait for everything.
+        typedef unsigned long long __attribute__((aligned(1))) u64u;
+        auto fetch8 = [&](const Range& r, int q0, int qhi) {
+            return *reinterpret_cast<const u64u*>(A.alpha + (q0 < qhi ? (size_t)r.off + q0 : 0));
         };
-        auto mask8 = [&](int q0, int qhi, unsigned (&av)[8]) {
+        auto unpack8 = [&](unsigned long long w, int q0, int qhi, unsigned (&av)[8]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? av[u] : 0u;
+            for (int u = 0; u < 8; ++u) av[u] = q0 + u < qhi ? (unsigned)(w >> (8 * u)) & 255u : 0u;
         };
         auto rest = [&](const Range& r, int qlo, int qhi, unsigned grey, unsigned a8, bool use_tables) {   // bytes past the first eight
             for (int q0 = qlo + 8; q0 < qhi; q0 += 8) {
                 unsigned av[8];
-                fetch8(r, q0, qhi, av);
-                mask8(q0, qhi, av);
+                unpack8(fetch8(r, q0, qhi), q0, qhi, av);
                 blend8(av, r.xmin + q0, grey, a8, use_tables);
             }
         };
@@ -682,8 +683,7 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
             seg_range(r, qlo, qhi);
             if (qlo < qhi) {
                 unsigned av[8];
-                fetch8(r, qlo, qhi, av);
-                mask8(qlo, qhi, av);
+                unpack8(fetch8(r, qlo, qhi), qlo, qhi, av);
                 blend8(av, r.xmin + qlo, grey, a8, use_tables);
                 rest(r, qlo, qhi, grey, a8, use_tables);
             }
@@ -713,27 +713,28 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
         };
         RowEnt e0[BL], e1[BL], e2[BL];
         Range r0[NR], r1[NR];
-        unsigned av0[NR][8], av1[NR][8];
+        unsigned long long w0[NR], w1[NR];
         int ql0[NR], qh0[NR], ql1[NR], qh1[NR];
         if (lo < hi) {
             entries(lo, e0); entries(lo + BL, e1);
             settle(lo, e0);
             ranges_of(e0, r0);
 #pragma unroll
-            for (int u = 0; u < NR; ++u) { seg_range(r0[u], ql0[u], qh0[u]); fetch8(r0[u], ql0[u], qh0[u], av0[u]); }
+            for (int u = 0; u < NR; ++u) { seg_range(r0[u], ql0[u], qh0[u]); w0[u] = fetch8(r0[u], ql0[u], qh0[u]); }
         }
         for (long long g0 = lo; g0 < hi; g0 += BL) {
             entries(g0 + 2 * BL, e2);
             settle(g0 + BL, e1);
             ranges_of(e1, r1);
 #pragma unroll
-            for (int u = 0; u < NR; ++u) { seg_range(r1[u], ql1[u], qh1[u]); fetch8(r1[u], ql1[u], qh1[u], av1[u]); }
+            for (int u = 0; u < NR; ++u) { seg_range(r1[u], ql1[u], qh1[u]); w1[u] = fetch8(r1[u], ql1[u], qh1[u]); }
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
                 if (ql0[u] < qh0[u]) {
-                    mask8(ql0[u], qh0[u], av0[u]);
-                    if (tables) { blend8(av0[u], r0[u].xmin + ql0[u], 255u, A.a8, true); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, true); }
-                    else { blend8(av0[u], r0[u].xmin + ql0[u], 255u, A.a8, false); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, false); }
+                    unsigned av[8];
+                    unpack8(w0[u], ql0[u], qh0[u], av);
+                    if (tables) { blend8(av, r0[u].xmin + ql0[u], 255u, A.a8, true); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, true); }
+                    else { blend8(av, r0[u].xmin + ql0[u], 255u, A.a8, false); rest(r0[u], ql0[u], qh0[u], 255u, A.a8, false); }
                 }
                 if (u & 1) {                              // after a line's second range: its further sub-paths (rare)
                     const int more = (e0[u >> 1].lenL >> ROW_MORE_SHIFT) & 7;
@@ -748,9 +749,7 @@ __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
             for (int u = 0; u < BL; ++u) { e0[u] = e1[u]; e1[u] = e2[u]; }
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
-                r0[u] = r1[u]; ql0[u] = ql1[u]; qh0[u] = qh1[u];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) av0[u][k] = av1[u][k];
+                r0[u] = r1[u]; ql0[u] = ql1[u]; qh0[u] = qh1[u]; w0[u] = w1[u];
             }
         }
         for (int side = 0; side < 4; ++side) {
@@ -796,7 +795,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // the coverage pool: 16 KB per line on average (measured: ~6 KB) and never less than eight canvases' worth -- the row
     // ranges of ONE line can span most of the canvas (see polygon_coverage), and a call may consist of one line
     const size_t alpha_bytes = std::max<size_t>(nl * 16384, (size_t)8 * size * (size + 2));
-    const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;
+    const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;   // (the slack also covers the blend's 8-byte reads at the pool's end)
     const void* had = h->raster_hdr;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
