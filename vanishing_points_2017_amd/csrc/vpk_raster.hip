@@ -40,7 +40,7 @@ using namespace vpk_raster;
 //   coverage_kernel  one WORKGROUP per line at a time (persistent workgroups over a queue of ALL lines: the lines of an
 //                    image need no order here): cells in the LDS pool, sweep -> the line's coverage as one byte per
 //                    pixel of every touched row's cell range (the pool's packing) + the dense row table, in HBM
-//   blend_kernel     16 image rows x 8 column segments per workgroup, the rows' pixels in LDS: the image's lines IN
+//   blend_kernel     32 image rows x 8 column segments per workgroup, the rows' pixels in LDS: the image's lines IN
 //                    INPUT ORDER (the 8-bit blend does not commute), then the four spines; one coalesced store
 // ---------------------------------------------------------------------------------------------------------------
 // One polygon's coverage of one image row: up to two ranges of pixels (raster_device.hpp: CellSink) whose alpha bytes lie back
@@ -603,8 +603,9 @@ __global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 
 // calculate_alpha((R << 9) - area), one without (no cell, or a cell of a vertical edge on the pixel boundary) lies in the
 // span that runs to the next cell and got calculate_alpha(R << 9) -- 0 after the row's last cell --, R = running cover;
 // coverage_kernel stored those alphas.  Here: fixed_blender_rgba_plain, item after item.
-constexpr int BROWS = 16, BSEG = 8;                       // image rows per workgroup x column segments per row: 128 threads
-                                                         // (measured: 64 x 8 1.12 ms, 32 x 8 0.98, 16 x 8 0.92, 16 x 16 1.01)
+constexpr int BROWS = 32, BSEG = 8;                       // image rows per workgroup x column segments per row: 256 threads
+                                                         // (measured, 102 / 95 images: 8 x 8 0.66 / 1.59 ms, 16 x 8 0.77 / 1.47,
+                                                         //  32 x 8 0.74 / 1.37)
 constexpr unsigned BLEND_LUT_MAX_A8 = 63;                // colour alphas up to this blend through a table (17 KB of LDS at most)
 __global__ __launch_bounds__(BROWS * BSEG) void blend_kernel(RasterArgs A) {
     extern __shared__ unsigned char s_px[];              // [BROWS][size rounded to 4], then the tables
