@@ -107,3 +107,27 @@ def test_empty_images_in_a_batch_and_extreme_canvas_sizes():
     assert np.array_equal(sphere_mapping.raster_batch([a[:5]], size=64, alpha=0.1)[0], agg_raster.raster(a[:5], size=64))
     assert np.array_equal(sphere_mapping.raster_batch([a[:5]], size=1000, alpha=0.2)[0],
                           agg_raster.raster(a[:5], size=1000, alpha=0.2))
+
+
+def test_lines_far_from_the_principal_point_need_no_more_room_than_others():
+    """|c| >> |a|, |b|: the curve is an arch whose rows are crossed twice, hundreds of pixels apart.  With one range of cells
+    per row such a polygon asked for 100 000 pool entries (mostly the gap), a hundred of them overran the call's coverage pool
+    and -- with the shared bump counter -- took lines of OTHER images with them.  Rows now hold two ranges split at the apex
+    (gap dropped where nothing is drawn in it).  Against the CPU restatement, in a batch and alone; and the wrapper raises
+    rather than return an incomplete raster (checked by making sure no flag is up)."""
+    from oracle import agg_raster
+    from vanishing_points_2017_amd import sphere_mapping, synth
+    from vanishing_points_2017_amd.runtime import get_runtime
+    rng = np.random.default_rng(99)
+    wide = rng.normal(size=(60, 3))
+    wide[:, 2] *= 50
+    steep = rng.normal(size=(60, 3))
+    steep[:, 1] *= 0.01
+    ordinary = synth.make_scene(503, 60, 3, raster=None)["l"]
+    sets = [ordinary, wide, steep, wide[:1]]
+    got = sphere_mapping.raster_batch(sets, size=500, alpha=0.1)
+    for lines, r in zip(sets, got):
+        assert np.array_equal(r, agg_raster.raster(lines))
+    assert not sphere_mapping.raster_flags(get_runtime(0), len(sets)).any()
+    one = np.array([[-0.26247709, -1.59752339, -74.31417043]])       # (alone: eight canvases of pool, several LDS bands)
+    assert np.array_equal(sphere_mapping.raster_batch([one], size=500, alpha=0.1)[0], agg_raster.raster(one))

@@ -33,7 +33,7 @@
 
 namespace vpk_raster {
 
-constexpr int RT = 512;                 // threads per workgroup
+constexpr int RT = 256;                 // threads per workgroup of coverage_kernel (one polygon at a time: ~250 work items)
 constexpr int MAXS = 384;               // simplified points kept per line (typical: 30-100)
 constexpr int MAXV = 1024;              // outline vertices per line (typical: 60-200)
 constexpr int MAXSUB = 4;               // sub-paths per line (a NaN sample breaks the path)

@@ -541,7 +541,7 @@ __device__ bool polygon_coverage(const V2* v, int n, int xsplit, const CellSink&
     return ok || total == 0;
 }
 
-__global__ __launch_bounds__(RT, 4) void coverage_kernel(RasterArgs A) {   // 4 waves per SIMD: two workgroups per CU
+__global__ __launch_bounds__(RT, 3) void coverage_kernel(RasterArgs A) {   // three workgroups (of four waves) per CU
     extern __shared__ int s_dyn[];                       // six row arrays of A.rowcap ints, then the pool (cover, area)
     __shared__ int s_next, s_total[4];
     __shared__ unsigned short s_eoff[MAXV + 2];          // first work item of every edge of the polygon at hand
@@ -841,8 +841,10 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.polys = (int*)p; p += vpk::em_align(nl * POLY_INTS * 4, 256);
     A.alpha = (unsigned char*)p; A.alpha_cap = alpha_bytes; p += vpk::em_align(alpha_bytes, 256);
     A.dense = (RowEnt*)p;
-    // coverage_kernel's LDS: two workgroups per CU (80 KB each); what the static arrays and the six row arrays leave is the pool
-    constexpr int COV_LDS = 80 * 1024, COV_STATIC = 11 * 1024;
+    // coverage_kernel's LDS: three workgroups per CU (53 KB each); what the static arrays and the six row arrays leave is the
+    // pool.  (Measured with the two-range rows, 102 / 95 images: 512 threads x 2 per CU 1.36 / 2.60 ms, 256 x 4 1.32 / 2.23,
+    // 256 x 3 1.06 / 1.98.)
+    constexpr int COV_LDS = 53 * 1024, COV_STATIC = 11 * 1024;
     A.rowcap = (size + 63) & ~63;
     A.pool = ((COV_LDS - COV_STATIC - 6 * A.rowcap * 4) / 8) & ~63;
     const size_t cov_dyn = (size_t)(6 * A.rowcap + 2 * A.pool) * 4;
@@ -869,7 +871,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         if (times) VPK_HIP(h, hipEventRecord(ev[4], h->stream));
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
-        const int wgs = (int)std::min<long long>(nt, 2ll * h->num_cu);      // two workgroups fit a CU (LDS: 76 KB each)
+        const int wgs = (int)std::min<long long>(nt, 3ll * h->num_cu);      // three workgroups fit a CU (LDS, registers)
         hipLaunchKernelGGL(coverage_kernel, dim3(wgs), dim3(RT), cov_dyn, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[2], h->stream));
         hipLaunchKernelGGL(blend_kernel, dim3((size + BROWS - 1) / BROWS, A.batch), dim3(BROWS * BSEG),
