@@ -168,7 +168,7 @@ int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
  * anti-aliased scanline coverage, plain 8-bit "over" in line order, black axes spines last): pixel-exact.
  * Asynchronous on the handle's stream, except that `offsets` (caller-owned host memory) is uploaded and waited for when
  * it differs from the previous call's on this handle -- a pipeline that rasterises the same batch structure again does
- * not wait for anything.  Workspace (kept on the handle, grown on demand): ~45 KB + 32 x size bytes per line of the
+ * not wait for anything.  Workspace (kept on the handle, grown on demand): ~38 KB + 64 x size bytes per line of the
  * largest chunk of <= 49 152 lines. */
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
                       double alpha, uint8_t* out);
