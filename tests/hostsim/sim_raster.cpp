@@ -126,73 +126,3 @@ extern "C" int sim_edge_shares(double x1, double y1, double x2, double y2, int s
     for (size_t i = 0; i < c1.size(); ++i) bad += (c1[i] != c2[i]) || (a1[i] != a2[i]);
     return bad;
 }
-
-// development statistics (scripts/raster_balance.py): how the coverage kernel's (edge, share) items of one line's polygon load
-// its 512 threads.  out[0] = vertices, [1] = K, [2] = cells in all, [3] = sum over the 8 waves' max ... see the script.
-extern "C" int sim_polygon_balance(const double* l3, int size, double* out) {
-    const int ns = 10000;
-    const double lo_a = -PI_D / 2, hi_a = PI_D / 2, step = (hi_a - lo_a) / (ns - 1);
-    std::vector<V2> simp(MAXS), verts(MAXV);
-    unsigned flags = 0;
-    Simplifier sm;
-    sm.init(simp.data(), MAXS);
-    for (int i = 0; i < ns; ++i) {
-        const double al = (i == ns - 1) ? hi_a : lo_a + i * step;
-        double be = -atan((-l3[0] * sin(al) - l3[2] * cos(al)) / l3[1]);
-        be *= -1;
-        const double x = (al - lo_a) / (hi_a - lo_a) * size, y = size - (be - lo_a) / (hi_a - lo_a) * size;
-        if (!(y == y)) return -1;
-        if (!sm.have) sm.begin(x, y); else sm.feed(x, y);
-    }
-    sm.end();
-    Outline o;
-    o.v = verts.data(); o.n = 0; o.cap = MAXV; o.flags = &flags;
-    stroke_outline(simp.data(), sm.n, 100.0 / 72.0, o);
-    const int n = o.n;
-    int K = (4 * RT) / (n > 0 ? n : 1);
-    K = K < 1 ? 1 : (K > 32 ? 32 : K);
-    std::vector<int> cover((size_t)size * (size + 2), 0), area(cover), rmin(size, 0x7fffffff), rmax(size, -1);
-    CellSink s;
-    s.pcover = s.parea = nullptr; s.rowmin = rmin.data(); s.rowmax = rmax.data(); s.rowoff = nullptr; s.size = size;
-    s.rmin = s.rmax = s.lcov = nullptr; s.xs = 0x7fffffff;
-    s.blo = 0; s.bhi = size; s.boff = 0; s.cover = cover.data(); s.area = area.data();
-    EdgeClip ec;
-    ec.bx1 = 0.0; ec.by1 = 0.0; ec.bx2 = (double)size; ec.by2 = (double)size; ec.c = s; ec.nparts = K;
-    const int items = n * K;
-    std::vector<long long> per_item(items, 0);
-    long long total = 0;
-    for (int it = 0; it < items; ++it) {
-        const int k = it / K;
-        ec.part = it - k * K;
-        // count the cells of this item: number of accumulator entries it changes (fresh accumulators)
-        ec.edge<GLOBAL>(verts[k].x, verts[k].y, verts[k + 1 < n ? k + 1 : 0].x, verts[k + 1 < n ? k + 1 : 0].y);
-        long long cnt = 0;
-        // the item's cells lie in the rows of its edge: scan a bounding box of the edge
-        const double ya = verts[k].y, yb = verts[k + 1 < n ? k + 1 : 0].y;
-        int y0 = (int)floor(ya < yb ? ya : yb) - 1, y1 = (int)floor(ya < yb ? yb : ya) + 1;
-        y0 = y0 < 0 ? 0 : y0; y1 = y1 >= size ? size - 1 : y1;
-        for (int y = y0; y <= y1; ++y)
-            for (int x = 0; x < size + 2; ++x) {
-                int& c = cover[(size_t)y * (size + 2) + x]; int& a = area[(size_t)y * (size + 2) + x];
-                if (c | a) { ++cnt; c = 0; a = 0; }
-            }
-        per_item[it] = cnt; total += cnt;
-    }
-    // waves: thread t takes items t, t + 512, ...; a wave's time ~ sum over rounds of (setup + max cells over its lanes)
-    double wave_max = 0, wave_sum = 0;
-    long long max_item = 0;
-    for (int w = 0; w < 8; ++w) {
-        double tw = 0;
-        for (int base = 0; base < items; base += RT) {
-            long long m = -1;
-            for (int lane = 0; lane < 64; ++lane) {
-                const int it = base + w * 64 + lane;
-                if (it < items) { m = per_item[it] > m ? per_item[it] : m; max_item = per_item[it] > max_item ? per_item[it] : max_item; }
-            }
-            if (m >= 0) tw += 8.0 + (double)m;          // setup counted as eight cells' worth
-        }
-        wave_max = tw > wave_max ? tw : wave_max; wave_sum += tw;
-    }
-    out[0] = n; out[1] = K; out[2] = (double)total; out[3] = wave_max; out[4] = wave_sum / 8; out[5] = (double)max_item; out[6] = sm.n;
-    return 0;
-}
