@@ -22,8 +22,14 @@ HBM-roofline workload (configs[4] stress: 512 images x 1000 lines x 8 VPs x 50 i
 2 018-image HLW-shape set (configs[3]: EM + horizon selection, AUC, parity of the stored subsample with the reference).
 
 What is timed: CNN forward -> EM on inputs resident in HBM.  LSD, the rasteriser and the horizon / AUC
-stage are not in the timed region; the "parity" object compares the EM kernel's results on the same
-scenes with stored results of the reference itself (tests/golden/full_c2.npz), outside the timed region.
+stage are not in the timed region.  The workload generator yields LINES only; the resident rasters are made from them
+by vpk_sphere_raster before the clock starts, as the reference makes a datum's raster from its lines
+(evaluation.py:175) -- and they are the reference's own, pixel for pixel: the "parity" object checks every raster's
+hash against the hash of the reference's sphere_line_plot output stored in tests/golden/full_c2.npz, and compares the
+EM's results on these rasters (with the generator's response maps, which is what the reference was given) with the
+reference's stored results, outside the timed region.  "value" feeds the EM the random-weight CNN's own response maps
+(the reference's data flow); "value_fixture_prior" repeats the same K steps -- CNN executed all the same -- with the EM
+fed the response maps the parity object uses, i.e. the workload whose parity the line quotes.
 """
 import argparse
 import json
@@ -147,6 +153,8 @@ def make_workload(kind, rank, count):
             s = synth.make_scene(5000 + 16 * rank + i, 1000, 8)
             s["init_vp"] = synth.stress_init_vps(5000 + 16 * rank + i)
             base.append(s)
+        from vanishing_points_2017_amd import sphere_mapping
+        sphere_mapping.attach_rasters(base)               # (once per distinct scene, not per copy)
         scenes = [base[i % distinct] for i in range(count)]
         kw = dict(num_iter=50, do_split=False, do_merge=False, final_convergence=-1)
     return scenes, kw
@@ -190,7 +198,8 @@ def reference_parity(rt, gem, scenes, d, l_pristine, params, max_vp, first_index
     rt.synchronize()
     host = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
     offs = d["offsets"]
-    comps, err_gpu, err_ref, skipped = {}, [], [], 0
+    comps, err_gpu, err_ref, skipped, raster_ok, raster_n = {}, [], [], 0, 0, 0
+    sphere_host = d["sphere"].cpu().numpy()             # the resident rasters of the timed run (vpk_sphere_raster)
     for b, sc in enumerate(scenes):
         idx = first_index + b
         if not ref.has(idx):
@@ -199,6 +208,9 @@ def reference_parity(rt, gem, scenes, d, l_pristine, params, max_vp, first_index
         if parity.input_sha(sc) != r["input_sha"]:      # the generator produced other inputs on this host
             skipped += 1
             continue
+        if r["raster_sha"] is not None:                 # the reference's own sphere_line_plot output for these lines
+            raster_n += 1
+            raster_ok += int(parity.raster_sha(sphere_host[b]) == r["raster_sha"])
         m = int(host["num_vp"][b])
         res = {"status": int(host["status"][b]), "iterations": int(host["iterations"][b]),
                "vp_assoc": host["vp_assoc"][offs[b]:offs[b + 1]], "vp": host["vp"][b, :m], "counts": host["counts"][b, :m]}
@@ -211,12 +223,16 @@ def reference_parity(rt, gem, scenes, d, l_pristine, params, max_vp, first_index
         return {"images": 0, "inputs_differ": skipped}
     out = parity.summarise(comps)
     out["inputs_differ"] = skipped
+    out["rasters_equal_reference"] = "%d/%d" % (raster_ok, raster_n)
+    out["path"] = ("lines -> vpk_sphere_raster -> vpk_em_batch with the generator's response maps (the inputs the reference "
+                   "was given); the same resident rasters feed the timed steps")
     if err_gpu:
         out["horizon_auc"] = float(auc_mod.calc_auc(np.array(err_gpu), cutoff=0.25)[0])
         out["horizon_auc_reference"] = float(auc_mod.calc_auc(np.array(err_ref), cutoff=0.25)[0])
         out["horizon_auc_images"] = len(err_gpu)
     out["reference_seconds_per_image"] = float(np.mean(ref.g["ref_seconds"]))
-    out["source"] = "tests/golden/full_c2.npz: the reference's own EM + calc_horizon on the same %d scenes" % len(ref)
+    out["source"] = ("tests/golden/full_c2.npz: the reference's own sphere_line_plot + EM + calc_horizon on the same %d "
+                     "line sets" % len(ref))
     return out
 
 
@@ -264,37 +280,54 @@ def main():
 
 
 def hlw_pass(local_rank):
-    """BASELINE configs[3] on this GPU: the 2 018 HLW-shape images (100..1000 lines) through ONE vpk_em_batch launch and
-    the batched horizon selection, inputs (lines, response maps, GPU rasters) resident in HBM before the clock starts;
-    then the 64 images the reference's own results are stored for (tests/golden/full_c4.npz; the generator's raster
-    for those) as a second small batch, compared with them.  Returns the "workloads.hlw" object."""
-    from vanishing_points_2017_amd import auc as auc_mod, calc_horizon as ch, em as gem, parity, sphere_mapping, synth
+    """BASELINE configs[3] on this GPU: the 2 018 HLW-shape line sets (100..1000 lines) through the whole path --
+    vpk_sphere_raster -> vpk_cnn_forward (all 2 018 rasters) -> ONE vpk_em_batch launch -> vpk_horizon_batch -- with the
+    line sets and the response maps resident in HBM before the clock starts.  The EM's prior is the generator's
+    response map of each image (the random-weight CNN's output is computed and discarded: the AUC is meant to be the
+    fixture workload's).  Then the 64 images the reference's own results are stored for (tests/golden/full_c4.npz) as a
+    second small batch from their lines alone, compared with them.  Returns the "workloads.hlw" object."""
+    import torch
+    from vanishing_points_2017_amd import _lib, auc as auc_mod, calc_horizon as ch, em as gem, parity, sphere_mapping, synth
     from vanishing_points_2017_amd.runtime import get_runtime
     rt = get_runtime(local_rank, "em0")
+    rt_cnn = get_runtime(local_rank, "cnn")
+    net = get_net(local_rank, rt_cnn)[0]
+    net.set_precision(0)
     rt.handle.em_set_workgroups(0)
     t0 = time.time()
-    scenes = list(synth.config_scenes(4, raster=None))
-    rasters = sphere_mapping.raster_batch([s["l"] for s in scenes], size=500, alpha=0.1, device=local_rank)
-    for s, r in zip(scenes, rasters):
-        s["sphere_image"] = r
-    setup_s = time.time() - t0
+    scenes = list(synth.config_scenes(4))
     params = gem._params({})
-    d = gem.upload_batch(rt, scenes)
+    d = gem.upload_batch(rt, scenes)                      # (also makes the rasters once, outside the timing: compared below)
+    setup_s = time.time() - t0
     l_in = d["l"].clone()                                 # (the EM normalises l in place)
+    offs = _lib.host_i64(d["offsets"])
+    with rt.on_stream():
+        sphere_t = torch.empty_like(d["sphere"])
     rt.synchronize()
-    # one untimed launch first: the handle's workspace and pinned header buffers grow to this batch's size on first use
-    # (hipFree / hipMalloc of several GB inside a launch took 130 ... 390 ms from run to run), then the timed launch
-    t1 = time.perf_counter()
-    gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, params, max_vp=64)
-    rt.synchronize()
-    first_s = time.perf_counter() - t1
-    d["l"].copy_(l_in)
-    rt.synchronize()
-    t1 = time.perf_counter()
-    out = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], d["sphere"], None, params, max_vp=64)
-    rt.synchronize()
-    em_s = time.perf_counter() - t1
+
+    def one_pass():
+        """raster -> CNN -> EM -> (host) horizon; every stage waited for (host clock), nothing overlapped"""
+        t = [time.perf_counter()]
+        sphere_mapping.raster_batch_device(rt, l_in, offs, 500, 0.1, out=sphere_t)
+        rt.synchronize()
+        t.append(time.perf_counter())
+        resp = net.forward_device(sphere_t)
+        rt_cnn.synchronize()
+        t.append(time.perf_counter())
+        d["l"].copy_(l_in)
+        o = gem.em_batch_device(rt, d["offsets"], d["l"], d["lp"], d["cnn"], sphere_t, None, params, max_vp=64)
+        rt.synchronize()
+        t.append(time.perf_counter())
+        return o, resp, np.diff(t)
+
+    # one untimed pass first: the handles' workspaces (raster pools, CNN arena for 2 018 images, EM slots, pinned header
+    # buffers) grow to this batch's size on first use (hipFree / hipMalloc of several GB inside a launch took
+    # 130 ... 390 ms from run to run), then the timed pass
+    _, _, first = one_pass()
+    out, resp, (raster_s, cnn_s, em_s) = one_pass()
+    rasters_same = bool(torch.equal(sphere_t, d["sphere"]))
     host = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+    assert not (host["status"] == 3).any()
     results = []
     for b in range(len(scenes)):
         m = int(host["num_vp"][b]) if host["status"][b] == 0 else 0
@@ -307,22 +340,35 @@ def hlw_pass(local_rank):
     iters = host["iterations"]
     evals = iters + 5
     b_em = float(np.sum(8.0 * n_lines ** 2 * (evals + 1) + evals * (64.0 * n_lines + 16.0 * np.maximum(host["num_vp"], 1) * n_lines)))
-    res = {"config": "configs[3] HLW-shape: 2018 images, N~U{100..1000} lines, EM + horizon selection on one GPU (the 8-GPU "
-                     "sharded form is benchmark.py --hlw --synthetic --gpus 8)",
-           "images": len(scenes), "images_per_s": len(scenes) / (em_s + hor_s), "em_ms": em_s * 1e3, "em_first_launch_ms": first_s * 1e3, "horizon_ms": hor_s * 1e3,
-           "em_images_per_s": len(scenes) / em_s, "ok_images": int((host["status"] == 0).sum()),
+    total_s = raster_s + cnn_s + em_s + hor_s
+    res = {"config": "configs[3] HLW-shape: 2018 images, N~U{100..1000} lines: sphere raster -> CNN -> EM -> horizon selection on one "
+                     "GPU (the 8-GPU sharded form is benchmark.py --hlw --synthetic --gpus 8)",
+           "images": len(scenes), "images_per_s": len(scenes) / total_s,
+           "raster_ms": raster_s * 1e3, "cnn_ms": cnn_s * 1e3, "em_ms": em_s * 1e3, "horizon_ms": hor_s * 1e3,
+           "first_pass_ms": {"raster": first[0] * 1e3, "cnn": first[1] * 1e3, "em": first[2] * 1e3},
+           "em_images_per_s": len(scenes) / em_s, "cnn_images_per_s": len(scenes) / cnn_s, "raster_images_per_s": len(scenes) / raster_s,
+           "ok_images": int((host["status"] == 0).sum()),
            "iterations_mean": float(iters.mean()), "lines_mean": float(n_lines.mean()),
            "em_roofline": {"bound": "hbm", "achieved": b_em / em_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": b_em / em_s / 1e9 / HBM_PEAK_GBS,
                            "note": "B_EM (SURVEY 8d) of the 2018 images / the launch's wall time (host clock around a synchronised launch)"},
+           "cnn_roofline": {"bound": "mfma", "achieved": sum(net.LAYER_FLOP.values()) * len(scenes) / cnn_s / 1e12,
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": sum(net.LAYER_FLOP.values()) * len(scenes) / cnn_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                            "note": "whole net (6.73 GFLOP per image) x 2018 images / the forward's wall time, nothing beside it"},
            "horizon_auc": float(auc_mod.calc_auc(errs.copy(), cutoff=0.25)[0]),
+           "rasters_equal_untimed_pass": rasters_same,
            "setup_s_outside_timing": setup_s,
-           "note": "timed: one vpk_em_batch launch over all images + vpk_horizon_batch; not timed: generator, GPU raster, upload"}
+           "note": "timed (host clock, stage after stage, nothing overlapped): vpk_sphere_raster of the 2018 line sets, "
+                   "vpk_cnn_forward of the 2018 rasters (random-init weights; its output is discarded), one vpk_em_batch launch with "
+                   "the generator's response maps as priors, vpk_horizon_batch; not timed: generator, upload of lines / priors"}
     if os.path.isfile(parity.golden_path(4)):
         ref = parity.ReferenceResults(4)
         stored = [next(synth.config_scenes(4, count=1, start=int(i))) for i in ref.index]
         same = [parity.input_sha(sc) == ref.get(i)["input_sha"] for sc, i in zip(stored, ref.index)]
-        got = gem.em_batch(stored, device=local_rank)
+        got = gem.em_batch(stored, device=local_rank)   # from the lines alone: the rasters are made on the way
+        ras_ok = sum(int(ref.get(i)["raster_sha"] is not None and parity.raster_sha(sc["sphere_image"]) == ref.get(i)["raster_sha"])
+                     for sc, i in zip(stored, ref.index))
         comps, e_gpu, e_ref = {}, [], []
         for sc, i, r, ok in zip(stored, ref.index, got, same):
             if not ok:
@@ -335,10 +381,11 @@ def hlw_pass(local_rank):
                 e_ref.append(ch.horizon_error(g["hP1"], g["hP2"], sc["true_horizon"], sc["image_shape"]))
         par = parity.summarise(comps)
         par["inputs_differ"] = int(len(same) - sum(same))
+        par["rasters_equal_reference"] = "%d/%d" % (ras_ok, len(stored))
         if e_gpu:
             par["horizon_auc"] = float(auc_mod.calc_auc(np.array(e_gpu), cutoff=0.25)[0])
             par["horizon_auc_reference"] = float(auc_mod.calc_auc(np.array(e_ref), cutoff=0.25)[0])
-        par["source"] = "tests/golden/full_c4.npz: the reference's own EM + calc_horizon on %d of the 2018 scenes" % len(ref)
+        par["source"] = "tests/golden/full_c4.npz: the reference's own sphere_line_plot + EM + calc_horizon on %d of the 2018 line sets" % len(ref)
         res["parity"] = par
     return res
 
@@ -457,9 +504,10 @@ def run_workload(args, dist, rank, local_rank, world):
         ring = [pipeline.Step(rt_cnn, lanes[j % n_lanes], d, params, l_in=l_pristine, max_vp=max_vp,
                               records=dist is not None, image_ids=image_ids, timing=False) for j in range(2 * n_lanes)]
     quads = {}
+    active = {"ring": ring}                              # which ring of buffer sets step_lanes enqueues (see the fixture-prior leg)
 
     def step_lanes(k):
-        st = ring[k % len(ring)]
+        st = active["ring"][k % len(ring)]
         if k not in quads:                               # (steps outside the timed loop; the timed ones are made ahead)
             quads[k] = pipeline.event_quad(rt_cnn, st.rt_em)
         e, handles = quads[k]
@@ -496,6 +544,7 @@ def run_workload(args, dist, rank, local_rank, world):
         for k in range(args.steps):
             quads[args.warmup + k] = pipeline.event_quad(rt_cnn, ring[(args.warmup + k) % len(ring)].rt_em)
         sync_all()
+    net.set_profiling(True)                              # (restarts the per-layer averages: the timed passes only)
     t0 = time.perf_counter()
     evs = []
     call_s = []
@@ -507,15 +556,42 @@ def run_workload(args, dist, rank, local_rank, world):
     submit_s = time.perf_counter() - t0
     sync_all()
     elapsed = time.perf_counter() - t0
-    layer_ms = net.last_layer_ms()
+    layer_ms, layer_passes = net.mean_layer_ms()         # averaged over the timed steps' passes (HIP events on the CNN stream)
     out = {q: (v.clone() if torch.is_tensor(v) else v) for q, v in out.items()}   # the ring's buffers are reused by the legs below
+    rank_elapsed = [elapsed]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rt.tdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tall = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=rt.tdev)
+        dist.all_gather_into_tensor(tall, torch.tensor([elapsed], dtype=torch.float64, device=rt.tdev))
+        rank_elapsed = [float(x) for x in tall.cpu()]
+        elapsed = max(rank_elapsed)                      # the job's time is its slowest rank's
 
     cnn_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     em_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    # The same K steps once more with the EM fed the FIXTURE response maps (the generator's: what the reference was given and
+    # what the parity object runs) instead of the random-weight CNN's output.  The CNN is executed all the same (its output is
+    # written and left unused): the work of a deployment whose net produces the priors the fixtures stand for.
+    fixture = None
+    if args.workload == "yud" and not sliced and not args.no_alt:
+        ring_fix = [pipeline.Step(rt_cnn, lanes[j % n_lanes], d, params, l_in=l_pristine, max_vp=max_vp, records=dist is not None,
+                                  image_ids=image_ids, timing=False, em_prior=d["cnn"]) for j in range(2 * n_lanes)]
+        active["ring"] = ring_fix
+        for k in range(max(args.warmup, n_lanes)):
+            step(k)
+        sync_all()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            e_fix, out_fix = step(args.warmup + k)
+        sync_all()
+        fix_elapsed = time.perf_counter() - t1
+        if dist is not None:
+            tmax = torch.tensor([fix_elapsed], dtype=torch.float64, device=rt.tdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            fix_elapsed = float(tmax.item())
+        it_fix = out_fix["iterations"].cpu().numpy()
+        assert not (out_fix["status"] == 3).any().item()
+        fixture = {"value": count * world * args.steps / fix_elapsed, "ms_per_step": fix_elapsed / args.steps * 1e3,
+                   "iterations_mean": float(it_fix.mean()), "iterations_max": int(it_fix.max())}
+        active["ring"] = ring
     # The same K steps once more with conv2..5 on the bf16 matrix cores (vpk_cnn_set_precision(1): three bf16 pieces per f32
     # operand, six products per f32 product -- f32-class accuracy, tests/test_gpu_cnn.py).  Reported beside the headline
     # number, never as it: `value` is the native-f32 run above.
@@ -615,9 +691,11 @@ def run_workload(args, dist, rank, local_rank, world):
                       "value": count * world * args.steps / fl_elapsed, "unit": "images/s",
                       "ms_per_step": fl_elapsed / args.steps * 1e3, "steps": args.steps,
                       "raster_alone_ms": raster_alone_ms, "raster_alone_images_per_s": count / raster_alone_ms * 1e3,
-                      "note": "the headline run's resident rasters are the workload generator's (synth.raster_numpy), these are the "
-                              "library's own (the reference's Agg pipeline, pixel-exact): the two runs' results are not comparable line by line",
-                      "results_equal_unpipelined_pass": bool(all(torch.equal(o_lines[q], plain[q]) for q in plain))}
+                      "note": "same inputs as the headline run: there the rasters of these line sets were made by the same "
+                              "vpk_sphere_raster before the clock started, here every step makes them again",
+                      "results_equal_unpipelined_pass": bool(all(torch.equal(o_lines[q], plain[q]) for q in plain)),
+                      "results_equal_headline_run": bool(all(torch.equal(o_lines[q], out[q]) for q in plain))}
+    assert not (out["status"] == 3).any().item(), "an image found no working-set slot (VPK_EM_NO_SLOT): results incomplete"
     iters = out["iterations"].cpu().numpy()
     status = out["status"].cpu().numpy()
     nvp = out["num_vp"].cpu().numpy()
@@ -651,7 +729,10 @@ def run_workload(args, dist, rank, local_rank, world):
         roof_em = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None, "traffic_source": traffic_src,
-                   "note": "achieved = modelled algorithmic bytes (SURVEY 8d B_EM) / kernel time measured on overlapped streams; "
+                   "evaluations_I": float(evals.mean()),
+                   "note": "achieved = modelled algorithmic bytes (SURVEY 8d B_EM with I = E-step evaluations per image = loop "
+                           "iterations + 1 initial + 4 in the finalisation; evaluations_I = its mean; SURVEY's figure for the stress "
+                           "unit takes I = 50, this run's is 54) / mean kernel time of the timed steps, measured on overlapped streams; "
                            "traffic = HBM bytes per launch from the PMC passes"}
         name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])   # the layer with the most arithmetic (conv2)
         flop = cnn.Net.LAYER_FLOP[name] * count
@@ -659,7 +740,9 @@ def run_workload(args, dist, rank, local_rank, world):
                     "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
                     "traffic": (tc["hbm_read_bytes"] + tc["hbm_write_bytes"]) if tc else None,
-                    "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel"}
+                    "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel",
+                    "note": "achieved = the layer's flops / its mean duration over the timed steps (HIP events on the CNN stream, "
+                            "%d passes), i.e. with whatever ran beside it" % layer_passes}
         if args.cnn_precision == 1:     # conv2 on the bf16 matrix cores: six bf16 MFMA products per f32 product
             roof_cnn.update({"kernel": "conv_gemm_split_kernel(%s)" % name, "achieved": 6.0 * roof_cnn["achieved"],
                              "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None,
@@ -705,6 +788,9 @@ def run_workload(args, dist, rank, local_rank, world):
             "metric_note": "BASELINE.json's metric name; the timed region is CNN forward -> EM refinement with inputs resident "
                            "in HBM (no LSD, no rasteriser); horizon-AUC parity is the 'parity' object, outside the timed region",
             "value": value, "unit": "images/s", "n_gpus": world, "ranks_seen": world if dist is None else dist.get_world_size(),
+            "rank_elapsed_ms": {"min": min(rank_elapsed) * 1e3, "max": max(rank_elapsed) * 1e3,
+                                "note": "wall time of the K timed steps per rank (barrier + synchronize on both sides); "
+                                        "value uses the max"},
             "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": torch.get_num_threads(),
             "ms_per_step": elapsed / args.steps * 1e3, "host_submit_ms_per_step": submit_s / args.steps * 1e3,
             "host_enqueue_ms_per_step": float(np.median(call_s)) * 1e3,
@@ -719,10 +805,12 @@ def run_workload(args, dist, rank, local_rank, world):
             "vs_baseline": None,
             "dtype": "f32 (CNN, MFMA) + f64 (EM)" if args.cnn_precision == 0 else
                      "f32 as 3 bf16 pieces x 6 bf16-MFMA products, f32 accumulate (conv2-5) + f32 MFMA (conv1, fc6-8) + f64 (EM)",
-            "data": "synthetic (seeded YUD-shape line sets and rasters; random-init AlexNet-500 weights)",
+            "data": "synthetic (seeded line sets of the config's shape; their rasters made by vpk_sphere_raster = the reference's "
+                    "own, hash-checked in 'parity'; random-init AlexNet-500 weights)",
             "config": {"workload": "configs[1] YUD-shape: %d images/GPU, N~U{100..400} lines, 3 VPs, CNN+EM"
                                    % count if args.workload == "yud" else
-                                   "configs[4] stress: %d images/GPU x 1000 lines x 8 VP candidates x 50 EM iterations" % count,
+                                   "configs[4] stress: %d of 10 000 images per launch and GPU (%d distinct scenes) x 1000 lines x 8 VP "
+                                   "candidates x 50 EM iterations" % (count, min(count, 16)),
                        "images_per_gpu": count, "parallelism": "image-sharded x%d" % world},
             "stage_ms": ({"cnn": cnn_ms, "em_slice": em_ms, "em_mode": args.em_mode, "em_slice_budget_ms": slice_ms,
                           "em_workgroups": em_wgs,
@@ -733,11 +821,18 @@ def run_workload(args, dist, rank, local_rank, world):
                          {"cnn": cnn_ms, "em": em_ms, "em_mode": "lanes", "em_lanes": n_lanes, "em_workgroups": em_wgs,
                           "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"}),
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
+            "cnn_layer_ms_note": "mean over the %d timed steps' passes (HIP events between the layers on the CNN stream)" % layer_passes,
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
                          "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},
             "roofline": roof,
             "roofline_secondary": roof_cnn if roof is roof_em else roof_em,
         }
+        if fixture:
+            line["value_fixture_prior"] = fixture["value"]
+            line["fixture_prior"] = dict(fixture, unit="images/s", steps=args.steps,
+                                         note="the same K steps with the CNN executed and the EM fed the generator's response maps "
+                                              "(the priors the 'parity' object and the reference's stored results use) instead of "
+                                              "the random-weight CNN's output, which 'value' uses (em_stats: its iteration counts)")
         if alt:
             line["alt_precision"] = alt
         if from_lines is not None:

@@ -159,6 +159,9 @@ int vpk_cnn_set_precision(vpk_handle* h, int mode);
  * vpk_cnn_last_layer_ms waits for the pass to finish. */
 int vpk_cnn_set_profiling(vpk_handle* h, int on);
 int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
+/* the same, averaged over the profiled passes since the last vpk_cnn_set_profiling call (at most the last 64); *passes
+ * (may be NULL) = how many.  Waits for them to finish. */
+int vpk_cnn_mean_layer_ms(vpk_handle* h, float ms[13], int* passes);
 
 /* ---- sphere rasteriser (sphere_mapping.py:36-72) ----------------------------------------------- */
 /* replaces: get_sphere_image / sphere_line_plot (evaluation.py:12-14).  l: sum(N) x 3 fp64
@@ -168,13 +171,20 @@ int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]);
  * anti-aliased scanline coverage, plain 8-bit "over" in line order, black axes spines last): pixel-exact.
  * Asynchronous on the handle's stream, except that `offsets` (caller-owned host memory) is uploaded and waited for when
  * it differs from the previous call's on this handle -- a pipeline that rasterises the same batch structure again does
- * not wait for anything.  Workspace (kept on the handle, grown on demand): ~38 KB + 64 x size bytes per line of the
- * largest chunk of <= 49 152 lines. */
+ * not wait for anything.  An image without lines gets the frame-only canvas, like the reference's; when the whole
+ * batch has no line, l may be NULL.  Workspace (kept on the handle, grown on demand), per line of the largest chunk of
+ * <= 49 152 lines: ~38 KB of outline scratch + 64 x size bytes of row table + 16 KB of coverage pool (~86 KB per line at
+ * size 500: 4.2 GB for a full chunk; the pool is never smaller than 8 x size x (size + 2) bytes and must stay below
+ * 4 GiB -- an image of more than ~262 000 lines is refused with VPK_ERR_LIMIT). */
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size,
                       double alpha, uint8_t* out);
+/* replaces: the `alternative` keyword of sphere_line_plot (sphere_mapping.py:58-59; no caller in the reference passes it):
+ * on != 0 makes the following vpk_sphere_raster calls on this handle draw beta = atan(-c / (a cos alpha + b sin alpha))
+ * instead of atan((-a sin alpha - c cos alpha) / b). */
+int vpk_sphere_raster_set_alternative(vpk_handle* h, int on);
 /* per-image flags of the LAST vpk_sphere_raster call on this handle (waits for it): bit 0 = a line produced more outline
  * vertices / coverage than the kernel's buffers hold and was truncated or dropped (never seen on real line sets: a
- * simplified curve keeps 30-100 of its 10 000 samples). */
+ * simplified curve keeps 30-100 of its 10 000 samples).  `batch` must be that call's batch (VPK_ERR_ARG otherwise). */
 int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out);
 
 /* ---- front end: line segment detection (HOST code, host pointers) -------------------------------------------- */
@@ -257,6 +267,10 @@ typedef struct vpk_step_args {
     void* reuse_event;              /* NULL or a hipEvent_t of the caller that guards these buffers: the CNN stream waits
                                        for it before it overwrites cnn_out, and it is recorded behind this step's EM --
                                        so a ring of vpk_step_args can be re-enqueued without host synchronisation */
+    const float* em_prior;          /* NULL: the EM's prior is this step's cnn_out (the reference's flow, run_cnn then run_em);
+                                       else B x 400 response maps to use instead -- the CNN still runs and still writes
+                                       cnn_out (a pipeline whose priors were computed earlier, evaluation.py:285 stores them
+                                       in the datum; bench.py's value_fixture_prior) */
 } vpk_step_args;
 int vpk_pipeline_step(vpk_handle* cnn, vpk_handle* em, const vpk_step_args* a);
 /* Fixed-size result records, one row of vpk_record_width() doubles per image: [image id, status, m, (x, y, z) x 20,
@@ -292,6 +306,12 @@ int vpk_line_counts(vpk_handle* h, int n, int m, const double* lp, const double*
 /* the clustering inside split_best_vp (:568-578): ldist n x n -> labels n (0/1), flags 1. */
 int vpk_cluster2(vpk_handle* h, int n, const double* ldist, int32_t* labels_out,
                  uint32_t* flags_out);
+
+/* diagnostics: y[i] = f(x[i]) for the device's double-precision exp / acos / asin / atan / sqrt / sin / cos / log (fn =
+ * 0..7) as the EM kernels call them (same translation unit, same flags).  replaces: nothing -- it measures the premise
+ * of the parity bar: the reference's probability_functions.py:99-176 evaluates these through NumPy / libm, and results
+ * can only agree to the last bit where these functions do (tests/test_gpu_math.py reports max ulp and mismatch rate). */
+int vpk_math_probe(vpk_handle* h, int fn, long long n, const double* x, double* y);
 
 /* ---- horizon from the best orthogonal VP triplet, batched ------------------------------------------ */
 /* replaces: calc_horizon.calculate_horizon_and_ortho_vp -- calc_horizon.py:19-225 -- called per image from the

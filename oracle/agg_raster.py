@@ -41,11 +41,14 @@ def iround(v):
 # -----------------------------------------------------------------------------------------------------------------
 # the curve in pixel coordinates
 # -----------------------------------------------------------------------------------------------------------------
-def curve_pixels(line, size=500, samples=10000):
-    """sphere_mapping.py:40,61-63 + the axes' data -> display transform + RendererAgg's y flip."""
+def curve_pixels(line, size=500, samples=10000, alternative=False):
+    """sphere_mapping.py:40,58-63 + the axes' data -> display transform + RendererAgg's y flip."""
     a = np.linspace(-np.pi / 2, np.pi / 2, num=samples)
     with np.errstate(divide="ignore", invalid="ignore"):
-        b = -np.arctan((-line[0] * np.sin(a) - line[2] * np.cos(a)) / line[1])
+        if alternative:
+            b = -np.arctan(-line[2] / (np.cos(a) * line[0] + np.sin(a) * line[1]))    # :59
+        else:
+            b = -np.arctan((-line[0] * np.sin(a) - line[2] * np.cos(a)) / line[1])    # :61
     b = b * -1
     lo, hi = -np.pi / 2, np.pi / 2
     # matplotlib composes transScale + transLimits + transAxes into one affine; the products below agree with it to a few
@@ -582,11 +585,11 @@ def blend_white(p, cover, color_a=COLOR_A):
     return (((255 << 8) - r) * alpha + (r << 8)) // a
 
 
-def line_coverage(line, size=500, samples=10000, width_px=100.0 / 72.0):
+def line_coverage(line, size=500, samples=10000, width_px=100.0 / 72.0, alternative=False):
     """{(y, x): cover} of one line's stroke.  A non-finite sample breaks the path (PathNanRemover: the next finite sample
     is a move_to); the sub-paths are stroked one by one and their covers blended one after the other by the caller --
     returned here merged, which is the same thing wherever the strokes do not overlap (they are separated by a gap)."""
-    x, y = curve_pixels(line, size, samples)
+    x, y = curve_pixels(line, size, samples, alternative)
     ok = np.isfinite(x) & np.isfinite(y)
     out = {}
     idx = np.nonzero(ok)[0]
@@ -641,12 +644,12 @@ def spine_coverage(size=500, linewidth_pt=0.8, dpi=100.0):
 _SPINES = {}
 
 
-def raster(lines, size=500, samples=10000, alpha=0.1):
-    """sphere_line_plot(lines, size, alpha) -> uint8 (size, size)."""
+def raster(lines, size=500, samples=10000, alpha=0.1, alternative=False):
+    """sphere_line_plot(lines, size, alpha, alternative=...) -> uint8 (size, size)."""
     img = np.zeros((size, size), dtype=np.int64)
     color_a = int(alpha * 255 + 0.5)                   # agg::rgba8(rgba): uround
     for line in np.asarray(lines, dtype=np.float64).reshape(-1, 3):
-        for (y, x), c in line_coverage(line, size, samples).items():
+        for (y, x), c in line_coverage(line, size, samples, alternative=alternative).items():
             img[y, x] = blend_white(int(img[y, x]), c, color_a)
     if size not in _SPINES:
         _SPINES[size] = spine_coverage(size)

@@ -1,10 +1,14 @@
-"""Run the REFERENCE's own EM over whole BASELINE.json configs and store its results as fixtures.
+"""Run the REFERENCE's own raster + EM over whole BASELINE.json configs and store the results as fixtures.
 
 TEST INFRASTRUCTURE, build container only (needs /root/reference; see ref_shim.py).  For every
 seeded scene of a config (``vanishing_points_2017_amd.synth.config_scenes`` -- the generator behind
-bench.py and the parity tests) this runs the reference's ``vp_localisation.expectation_maximisation``
-(vp_localisation.py:168-450) and ``calc_horizon.calculate_horizon_and_ortho_vp``
-(calc_horizon.py:19-225) and writes ONE compact file per config:
+bench.py and the parity tests; it yields LINES and a response map, no raster) this does what the
+reference does with a datum (evaluation.py:175, :332-350): ``sphere_image =
+sphere_mapping.sphere_line_plot(lines, 500, alpha=0.1)`` (sphere_mapping.py:36-72, under the installed
+matplotlib with the pinned version's default line width, see make_golden.reference_raster), then
+``vp_localisation.expectation_maximisation`` (vp_localisation.py:168-450) on that raster and
+``calc_horizon.calculate_horizon_and_ortho_vp`` (calc_horizon.py:19-225), and writes ONE compact
+file per config:
 
     tests/golden/full_c<config>.npz
         index      image indices inside the config (seed = 1000 * config + index)
@@ -14,8 +18,11 @@ bench.py and the parity tests) this runs the reference's ``vp_localisation.expec
         vp / sigma / counts / counts_w   concatenated per-VP rows (offsets = cumsum(num_vp))
         hP1, hP2, combo                  horizon end points and best_combo (calc_horizon.py)
         ev_split / ev_merge / ev_abort / ev_final_merge    control-flow events seen in the reference
-        input_sha  first 8 bytes of sha1(l | lp | cnn_response | sphere_image): the tests refuse to
-                   compare when the regenerated inputs differ from the ones the reference saw
+        input_sha  first 8 bytes of sha1(l | lp | cnn_response): the tests refuse to compare when the
+                   regenerated inputs differ from the ones the reference saw
+        raster_sha first 8 bytes of sha1(sphere_image) of the REFERENCE's raster: vpk_sphere_raster has to
+                   reproduce it from the lines (the raster itself, 250 KB per image, is not stored)
+        raster_sum sum of the raster's pixels (a second, human-readable check)
 
 Only data is written -- no reference source text travels.  The event counters come from wrapping the
 reference's merge_vps / split_best_vp in memory (nothing is written into the reference tree).
@@ -36,7 +43,8 @@ sys.path.insert(0, HERE)
 
 from ref_shim import load_reference  # noqa: E402
 from vanishing_points_2017_amd import synth  # noqa: E402
-from vanishing_points_2017_amd.parity import input_sha  # noqa: E402
+from vanishing_points_2017_amd.parity import input_sha, raster_sha  # noqa: E402
+from make_golden import reference_raster  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -85,10 +93,11 @@ def run_config(cfg, indices, out_path, mods):
     instrument(mods, ev)
     rec = {k: [] for k in ("index", "n_lines", "status", "iterations", "num_vp", "ref_seconds", "assoc", "vp", "sigma",
                            "counts", "counts_w", "hP1", "hP2", "combo", "ev_split", "ev_merge", "ev_abort",
-                           "ev_final_merge", "input_sha")}
+                           "ev_final_merge", "input_sha", "raster_sha", "raster_sum")}
     with joblib.parallel_backend("multiprocessing"):
         for idx in indices:
             sc = next(synth.config_scenes(cfg, count=1, start=idx))
+            sc["sphere_image"] = reference_raster(mods["sphere_mapping"], sc["l"])
             for k in ev:
                 ev[k] = 0
             n = sc["lp"].shape[0]
@@ -104,6 +113,7 @@ def run_config(cfg, indices, out_path, mods):
             dt = time.time() - t0
             rec["index"].append(idx); rec["n_lines"].append(n); rec["status"].append(status)
             rec["ref_seconds"].append(dt); rec["input_sha"].append(input_sha(sc))
+            rec["raster_sha"].append(raster_sha(sc["sphere_image"])); rec["raster_sum"].append(int(sc["sphere_image"].sum()))
             for k in ev:
                 rec["ev_" + k].append(ev[k])
             if status == 0:
@@ -127,7 +137,8 @@ def save(rec, path):
     def cat(k, shape, dtype):
         return np.concatenate(rec[k]) if rec[k] else np.zeros(shape, dtype)
     out = {k: np.asarray(rec[k]) for k in ("index", "n_lines", "status", "iterations", "num_vp", "ref_seconds",
-                                           "ev_split", "ev_merge", "ev_abort", "ev_final_merge", "input_sha")}
+                                           "ev_split", "ev_merge", "ev_abort", "ev_final_merge", "input_sha", "raster_sha",
+                                           "raster_sum")}
     out["assoc"] = cat("assoc", (0,), np.int16)
     out["vp"] = cat("vp", (0, 3), np.float64)
     for k in ("sigma", "counts", "counts_w"):

@@ -2,7 +2,9 @@
 
     python scripts/full_parity.py <config> [--trace IMAGE]
 
-Prints every image that misses the parity bar with its deltas and writes gpurun_out/full_parity_c<cfg>.json.
+From the lines alone (the rasters are made by vpk_sphere_raster and hash-compared with the reference's).  Prints every image
+that misses the parity bar with its deltas, writes gpurun_out/full_parity_c<cfg>.json and adds the config's failing images
+to gpurun_out/parity_failures.json -- the input of oracle/make_instability_certificates.py (build container).
 --trace IMAGE also prints the per-iteration (M, max VP change) trajectory of that image on the GPU next to
 the CPU oracle's, to locate the iteration where the two runs part."""
 import json
@@ -23,6 +25,8 @@ def main(argv):
     differ = [int(i) for i, s in zip(ref.index, scenes) if parity.input_sha(s) != ref.get(i)["input_sha"]]
     print("config %d: %d stored images, %d with different regenerated inputs %s" % (cfg, len(ref), len(differ), differ[:10]))
     res = gem.em_batch(scenes, want_trace=trace_img is not None)
+    ras = [int(i) for i, s in zip(ref.index, scenes) if parity.raster_sha(s["sphere_image"]) != ref.get(i)["raster_sha"]]
+    print("rasters equal to the reference's: %d of %d %s" % (len(ref) - len(ras), len(ref), ras[:10]))
     comps = {}
     for i, r in zip(ref.index, res):
         if int(i) in differ:
@@ -41,6 +45,12 @@ def main(argv):
     with open("gpurun_out/full_parity_c%d.json" % cfg, "w") as fh:
         json.dump({"summary": summ, "images": {str(k): {a: (b if not isinstance(b, (np.bool_,)) else bool(b)) for a, b in v.items()}
                                                 for k, v in comps.items()}}, fh, default=float)
+    fails = {}
+    if os.path.isfile("gpurun_out/parity_failures.json"):
+        fails = json.load(open("gpurun_out/parity_failures.json"))
+    fails[str(cfg)] = summ["failing_images"]
+    with open("gpurun_out/parity_failures.json", "w") as fh:
+        json.dump(fails, fh)
     if trace_img is not None:
         from oracle import em_numpy
         k = list(ref.index).index(trace_img)

@@ -53,7 +53,7 @@ void draw_polygon(const V2* v, int n, unsigned grey, unsigned a8, int size, std:
 
 }  // namespace
 
-extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, unsigned char* out) {
+extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, int alt, unsigned char* out) {
     const int ns = 10000;
     const double lo_a = -PI_D / 2, hi_a = PI_D / 2, step = (hi_a - lo_a) / (ns - 1);
     std::vector<V2> simp(MAXS), verts(MAXV);
@@ -81,7 +81,8 @@ extern "C" int sim_raster(const double* l, int nlines, int size, double alpha, u
             for (int u = 0; u < OG; ++u) {
                 const int i = i0 + u < ns ? i0 + u : ns - 1;
                 const double al = (i == ns - 1) ? hi_a : lo_a + i * step;
-                double be = -atan((-la * sin(al) - lc * cos(al)) / lb);
+                double be = alt ? -atan(-lc / (cos(al) * la + sin(al) * lb))      // sphere_mapping.py:59
+                                : -atan((-la * sin(al) - lc * cos(al)) / lb);     // :61
                 be *= -1;
                 xs[u] = (al - lo_a) / (hi_a - lo_a) * size;
                 ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;

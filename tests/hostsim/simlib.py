@@ -164,16 +164,17 @@ def raster_lib():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", RASTER_SRC[0], "-o", RASTER_SO])
     _raster_lib = ctypes.CDLL(RASTER_SO)
     _raster_lib.sim_raster.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                       ctypes.POINTER(ctypes.c_uint8)]
+                                       ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]
     _raster_lib.sim_edge_shares.argtypes = [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_int]
     return _raster_lib
 
 
-def sim_raster(lines, size=250, alpha=0.1):
+def sim_raster(lines, size=250, alpha=0.1, alternative=False):
     """The product's stroke / cell / blend arithmetic run serially on the host: uint8 [size, size] and the overflow flags."""
     l = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
     out = np.zeros((size, size), dtype=np.uint8)
-    flags = raster_lib().sim_raster(_p(l, ctypes.c_double), l.shape[0], size, float(alpha), _p(out, ctypes.c_uint8))
+    flags = raster_lib().sim_raster(_p(l, ctypes.c_double), l.shape[0], size, float(alpha), int(bool(alternative)),
+                                    _p(out, ctypes.c_uint8))
     return out, flags
 
 

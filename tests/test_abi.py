@@ -31,11 +31,14 @@ def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    from vanishing_points_2017_amd import _lib, synth, vp_localisation
+    from vanishing_points_2017_amd import _lib, evaluation, synth, vp_localisation
+    import numpy as np
     sc = synth.make_scene(1, 20, 3)
     with pytest.raises(_lib.VpkError):
         vp_localisation.expectation_maximisation(sc["l"], sc["lp"], sc["cnn_response"],
-                                                 sphere_image=sc["sphere_image"])
+                                                 sphere_image=np.zeros((500, 500), np.uint8))
+    with pytest.raises(_lib.VpkError):                   # nor is a raster made on the host
+        evaluation.get_sphere_image(sc["l"], size=500)
 
 
 def test_product_never_imports_oracle():

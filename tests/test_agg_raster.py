@@ -35,3 +35,13 @@ def test_simplifier_keeps_the_curve_within_a_ninth_of_a_pixel():
     t = np.clip(((x - p0[:, 0]) * d[:, 0] + (y - p0[:, 1]) * d[:, 1]) / np.maximum((d * d).sum(1), 1e-30), 0, 1)
     dist = np.hypot(x - (p0[:, 0] + t * d[:, 0]), y - (p0[:, 1] + t * d[:, 1]))
     assert dist.max() <= 1.0 / 9.0 + 1e-9
+
+
+def test_alternative_curve_against_the_references_rasters():
+    """sphere_line_plot(..., alternative=True) (sphere_mapping.py:58-59): the reference's own rasters of three line sets
+    (tests/golden/rasteralt.npz, made by oracle/make_raster_alt_golden.py), pixel for pixel."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rasteralt.npz"))
+    for k in "ac":
+        assert np.array_equal(agg_raster.raster(g["l_" + k], alternative=True), g["raster_" + k]), k

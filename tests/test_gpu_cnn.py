@@ -14,8 +14,8 @@ def net_and_ref():
     from vanishing_points_2017_amd import cnn, synth
     w = cnn.synthetic_weights(3)
     mean = cnn.synthetic_mean(3)
-    scenes = [synth.make_scene(7000 + i, 150 + 40 * i, 3) for i in range(3)]
-    sphere = np.stack([s["sphere_image"] for s in scenes])
+    from vanishing_points_2017_amd import sphere_mapping
+    sphere = sphere_mapping.raster_batch([synth.make_scene(7000 + i, 150 + 40 * i, 3)["l"] for i in range(3)])
     ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
     net = cnn.Net(w, mean)
     return net, sphere, ref, taps
@@ -53,7 +53,8 @@ def test_bench_batch_against_the_oracle(batch):
     from vanishing_points_2017_amd import cnn, synth
     w = cnn.synthetic_weights(0)
     mean = cnn.synthetic_mean(0)
-    sphere = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=batch)])
+    from vanishing_points_2017_amd import sphere_mapping
+    sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=batch)])
     ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
     net = cnn.Net(w, mean)
     try:
@@ -93,7 +94,8 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
     from vanishing_points_2017_amd import cnn, synth
     w = cnn.synthetic_weights(0)
     mean = cnn.synthetic_mean(0)
-    sphere = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=3)])
+    from vanishing_points_2017_amd import sphere_mapping
+    sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=3)])
     ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
     net = cnn.Net(w, mean)
     try:
@@ -122,7 +124,8 @@ def test_split_path_beyond_4_gib_of_activations():
     from vanishing_points_2017_amd import cnn, synth
     w = cnn.synthetic_weights(0)
     mean = cnn.synthetic_mean(0)
-    six = np.stack([s["sphere_image"] for s in synth.config_scenes(2, count=6)])
+    from vanishing_points_2017_amd import sphere_mapping
+    six = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=6)])
     net = cnn.Net(w, mean)
     native = net.forward(six)
     sphere = np.concatenate([six] * 300)

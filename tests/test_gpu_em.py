@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases
-from golden_util import abserr, check_em_result, em_kwargs, load, relerr
+from golden_util import abserr, check_em_result, em_kwargs, gpu_rasters, load, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -174,7 +174,7 @@ def test_against_oracle_on_fresh_scenes():
     """YUD-shape scenes not in the golden set: GPU vs CPU oracle, same seeded inputs."""
     from oracle import em_numpy as em
     from vanishing_points_2017_amd import em as gem, synth
-    scenes = list(synth.config_scenes(2, count=12, start=30))
+    scenes = gpu_rasters(synth.config_scenes(2, count=12, start=30))
     res = gem.em_batch(scenes)
     for sc, r in zip(scenes, res):
         ref = em.expectation_maximisation(sc["l"].copy(), sc["lp"].copy(), sc["cnn_response"].copy(),
@@ -192,7 +192,7 @@ def test_edge_cases_in_one_ragged_batch():
     and more hypotheses than the 32 accumulators).  Checked against the CPU oracle."""
     from oracle import em_numpy as em
     from vanishing_points_2017_amd import em as gem, synth
-    base = list(synth.config_scenes(2, count=3, start=50))
+    base = gpu_rasters(synth.config_scenes(2, count=3, start=50))
     empty = dict(base[0], l=np.zeros((0, 3)), lp=np.zeros((0, 4)))
     two = dict(base[1], l=base[1]["l"][:2].copy(), lp=base[1]["lp"][:2].copy())
     blank = dict(base[2], cnn_response=np.zeros((20, 20), dtype=np.float32))
@@ -314,12 +314,13 @@ def test_row_sliced_smoother_gives_the_bits_of_the_round2_kernels():
     bench's batch: every N from 100 to 400, up to 34 hypotheses), small and odd line counts (slices that are short or
     empty), and ECD-shape images that do not fit the row-sliced panel and fall back."""
     from vanishing_points_2017_amd import em as gem, synth
-    scenes = list(synth.config_scenes(2, count=102))
+    scenes = gpu_rasters(synth.config_scenes(2, count=102))
     for n in (3, 7, 8, 9, 15, 17, 33, 57, 63, 64, 65, 66, 127, 129):
         sc = synth.make_scene(900 + n, max(n, 40), 3)
         scenes.append(dict(sc, l=sc["l"][:n].copy(), lp=sc["lp"][:n].copy()))
     scenes += list(synth.config_scenes(3, count=6))          # ECD-shape: 300..1200 lines, partly in passes
     scenes += [synth.make_scene(8300 + n, n, 5) for n in (1300, 1600)]
+    scenes = gpu_rasters(scenes)
     new = _with_smoother(0, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
     old = _with_smoother(1, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
     ok = 0

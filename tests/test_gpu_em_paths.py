@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases
-from golden_util import abserr, check_em_result, em_kwargs, load, relerr
+from golden_util import abserr, check_em_result, em_kwargs, gpu_rasters, load, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +67,7 @@ def test_images_past_every_lds_panel_against_the_oracle(seed, n):
     runs against the CPU oracle, the bar of every other parity test."""
     from oracle import em_numpy
     from vanishing_points_2017_amd import em as gem, synth
-    sc = synth.make_scene(seed, n, 3)
+    sc = gpu_rasters([synth.make_scene(seed, n, 3)])[0]
     ref = em_numpy.expectation_maximisation(sc["l"].copy(), sc["lp"].copy(), sc["cnn_response"].copy(),
                                             sphere_image=sc["sphere_image"])
     res = gem.em_batch([sc])[0]
@@ -89,6 +89,7 @@ def test_stress_launch_of_512_images_equals_one_image_launches():
         s = synth.make_scene(5000 + i, 1000, 8)
         s["init_vp"] = synth.stress_init_vps(5000 + i)
         base.append(s)
+    base = gpu_rasters(base)
     single = [gem.em_batch([dict(s, l=s["l"].copy())], **kw)[0] for s in base]
     res = gem.em_batch([dict(base[i % 16], l=base[i % 16]["l"].copy()) for i in range(512)], **kw)
     for i, r in enumerate(res):
@@ -104,21 +105,18 @@ def test_all_2018_hlw_shape_images_in_one_launch():
     results are stored for (tests/golden/full_c4.npz) must meet the parity bar inside that launch exactly as they do in
     their own small batch; every image must come back with a regular status."""
     import os
-    from vanishing_points_2017_amd import em as gem, parity, sphere_mapping, synth
+    from vanishing_points_2017_amd import em as gem, parity, synth
     if not os.path.isfile(parity.golden_path(4)):
         pytest.skip("no stored reference results for config 4")
     ref = parity.ReferenceResults(4)
-    scenes = list(synth.config_scenes(4, raster=None))
+    scenes = list(synth.config_scenes(4))
     assert len(scenes) == 2018
     stored = {int(i) for i in ref.index}
-    rasters = sphere_mapping.raster_batch([s["l"] for s in scenes], size=500, alpha=0.1)
-    for k, s in enumerate(scenes):
-        if k in stored:       # the reference saw the generator's own raster for these
-            scenes[k] = next(synth.config_scenes(4, count=1, start=k))
-            assert parity.input_sha(scenes[k]) == ref.get(k)["input_sha"]
-        else:
-            s["sphere_image"] = rasters[k]
-    res = gem.em_batch(scenes)
+    for k in stored:
+        assert parity.input_sha(scenes[k]) == ref.get(k)["input_sha"]
+    res = gem.em_batch(scenes)                            # from the lines alone: the rasters are made on the way (evaluation.py:175)
+    for k in stored:                                      # ... and are the reference's
+        assert parity.raster_sha(scenes[k]["sphere_image"]) == ref.get(k)["raster_sha"], k
     assert len(res) == 2018 and all(r["status"] in (0, 1, 2) for r in res)
     assert sum(r["status"] == 0 for r in res) >= 2000
     bad = [(k, parity.compare_one(res[k], ref.get(k))) for k in sorted(stored) if not parity.passes(parity.compare_one(res[k], ref.get(k)))]

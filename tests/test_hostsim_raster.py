@@ -54,3 +54,13 @@ def test_an_edge_walked_in_shares_gives_the_cells_of_the_edge_walked_whole():
             assert simlib.sim_edge_shares(x1, y1, x2, y2, size, k) == 0, (x1, y1, x2, y2, k)
             n += 1
     assert n == 1200
+
+
+def test_product_arithmetic_on_the_alternative_curve():
+    """The `alternative` parametrisation (sphere_mapping.py:58-59) through the product's simplifier / stroker / cells: the
+    reference's own rasters (tests/golden/rasteralt.npz), pixel for pixel."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rasteralt.npz"))
+    for k in "abc":
+        got, flags = simlib.sim_raster(g["l_" + k], 500, 0.1, alternative=True)
+        assert flags == 0 and np.array_equal(got, g["raster_" + k]), k

@@ -8,12 +8,13 @@ An implementation whose exp/acos/asin differ from glibc's in the last bit (ocml 
 perturbation.  The control scene converges in a few iterations and does not move at all."""
 import numpy as np
 
+from golden_util import cpu_rasters
 from oracle import em_numpy as em
 from vanishing_points_2017_amd import synth
 
 
 def _spread(idx, trials):
-    sc = next(synth.config_scenes(2, count=1, start=idx))
+    sc = cpu_rasters(synth.config_scenes(2, count=1, start=idx))[0]
 
     def run(lp):
         return em.expectation_maximisation(sc["l"].copy(), lp.copy(), sc["cnn_response"].copy(),
@@ -53,7 +54,7 @@ def test_a_collapsed_vp_makes_a_converging_scene_unstable_too():
     in the reference itself (tests/golden/unstable_c4_2062.npz, oracle/make_unstable_golden.py); one ulp elsewhere moves
     nothing.  The HIP path lands on the perturbed member of this family (tests/test_gpu_full_configs.py)."""
     import os
-    sc = next(synth.config_scenes(4, count=1, start=2062))
+    sc = cpu_rasters(synth.config_scenes(4, count=1, start=2062))[0]
 
     def run(lp):
         return em.expectation_maximisation(sc["l"].copy(), lp.copy(), sc["cnn_response"].copy(),

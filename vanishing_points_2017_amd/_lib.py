@@ -41,16 +41,16 @@ class StepArgs(ctypes.Structure):
                 ("counts_w_out", ctypes.c_void_p), ("num_vp_out", ctypes.c_void_p), ("assoc_out", ctypes.c_void_p),
                 ("iterations_out", ctypes.c_void_p), ("status_out", ctypes.c_void_p), ("flags_out", ctypes.c_void_p),
                 ("records", ctypes.c_void_p), ("image_ids", ctypes.c_void_p), ("events", ctypes.c_void_p),
-                ("reuse_event", ctypes.c_void_p)]
+                ("reuse_event", ctypes.c_void_p), ("em_prior", ctypes.c_void_p)]
 
 
 EXPORTS = [
     "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_smoother", "vpk_em_set_lds_panel", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_em_set_distribution_out", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
-    "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_set_precision", "vpk_cnn_last_layer_ms",
-    "vpk_sphere_raster", "vpk_sphere_raster_flags", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
+    "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_set_precision", "vpk_cnn_last_layer_ms", "vpk_cnn_mean_layer_ms",
+    "vpk_sphere_raster", "vpk_sphere_raster_flags", "vpk_sphere_raster_set_alternative", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
     "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_line_counts", "vpk_cluster2", "vpk_horizon_batch", "vpk_lsd_detect",
-    "vpk_pipeline_step", "vpk_build_records", "vpk_record_width",
+    "vpk_pipeline_step", "vpk_build_records", "vpk_record_width", "vpk_math_probe",
 ]
 
 _lib = None
@@ -106,8 +106,11 @@ def load():
     lib.vpk_cnn_set_fusion.argtypes = [c_void, ctypes.c_int]
     lib.vpk_cnn_set_precision.argtypes = [c_void, ctypes.c_int]
     lib.vpk_cnn_last_layer_ms.argtypes = [c_void, ctypes.POINTER(ctypes.c_float)]
+    lib.vpk_cnn_mean_layer_ms.argtypes = [c_void, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.vpk_sphere_raster.argtypes = [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void]
     lib.vpk_sphere_raster_flags.argtypes = [c_void, ctypes.c_int, c_void]
+    lib.vpk_sphere_raster_set_alternative.argtypes = [c_void, ctypes.c_int]
+    lib.vpk_math_probe.argtypes = [c_void, ctypes.c_int, ctypes.c_longlong, c_void, c_void]
     lib.vpk_lsd_detect.argtypes = [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_int)]
     _lib = lib

@@ -96,6 +96,13 @@ class Net(object):
         self.rt.check(self.rt.lib.vpk_cnn_last_layer_ms(self.rt.h, ms))
         return dict(zip(self.LAYER_NAMES, [float(x) for x in ms]))
 
+    def mean_layer_ms(self):
+        """({layer: ms averaged over the profiled passes since set_profiling(True)}, number of passes)."""
+        ms = (ctypes.c_float * 13)()
+        n = ctypes.c_int(0)
+        self.rt.check(self.rt.lib.vpk_cnn_mean_layer_ms(self.rt.h, ms, ctypes.byref(n)))
+        return dict(zip(self.LAYER_NAMES, [float(x) for x in ms])), int(n.value)
+
     def forward_batch(self, sphere_u8, mean_arr=None):
         return self.forward(sphere_u8)
 

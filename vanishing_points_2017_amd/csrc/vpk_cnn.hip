@@ -981,7 +981,9 @@ struct vpk_cnn_state {
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
     int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
     bool profiling = false;
-    hipEvent_t ev[14] = {};
+    static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
+    hipEvent_t ev[EV_RING][14] = {};
+    long long ev_pass = 0;   // profiled passes recorded since profiling was switched on
     bool ev_ready = false;
     bool ev_valid = false;
 };
@@ -997,7 +999,8 @@ void vpk_cnn_free(vpk_handle* h) {
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
     if (h->cnn->ev_ready)
-        for (auto& e : h->cnn->ev) (void)hipEventDestroy(e);
+        for (auto& set : h->cnn->ev)
+            for (auto& e : set) (void)hipEventDestroy(e);
     delete h->cnn;
     h->cnn = nullptr;
 }
@@ -1111,8 +1114,9 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         return d;
     };
     int evi = 0;
+    hipEvent_t* evs = S->ev[S->ev_pass % vpk_cnn_state::EV_RING];
     auto mark = [&]() {
-        if (S->profiling && evi < 14) (void)hipEventRecord(S->ev[evi++], st);
+        if (S->profiling && evi < 14) (void)hipEventRecord(evs[evi++], st);
     };
     int rc;
     mark();
@@ -1241,7 +1245,10 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         fc_in = fc_out;
         fc_out = (li == 5) ? R[R_FCB] : R[R_FCA];
     }
-    if (S->profiling) S->ev_valid = (evi == 14);
+    if (S->profiling) {
+        S->ev_valid = (evi == 14);
+        if (S->ev_valid) ++S->ev_pass;
+    }
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
@@ -1254,11 +1261,13 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_profiling before vpk_cnn_load");
     VPK_HIP(h, hipSetDevice(h->device));
     if (on && !h->cnn->ev_ready) {
-        for (auto& e : h->cnn->ev) VPK_HIP(h, hipEventCreate(&e));
+        for (auto& set : h->cnn->ev)
+            for (auto& e : set) VPK_HIP(h, hipEventCreate(&e));
         h->cnn->ev_ready = true;
     }
     h->cnn->profiling = on != 0;
     h->cnn->ev_valid = false;
+    h->cnn->ev_pass = 0;
     return VPK_OK;
 }
 
@@ -1279,8 +1288,29 @@ int vpk_cnn_set_precision(vpk_handle* h, int mode) {
 int vpk_cnn_last_layer_ms(vpk_handle* h, float ms[13]) {
     if (!h || !ms || !h->cnn) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_last_layer_ms: bad argument");
     if (!h->cnn->ev_valid) return vpk_fail(h, VPK_ERR_STATE, "no profiled forward pass recorded");
-    VPK_HIP(h, hipEventSynchronize(h->cnn->ev[13]));
-    for (int i = 0; i < 13; ++i) VPK_HIP(h, hipEventElapsedTime(&ms[i], h->cnn->ev[i], h->cnn->ev[i + 1]));
+    hipEvent_t* evs = h->cnn->ev[(h->cnn->ev_pass - 1) % vpk_cnn_state::EV_RING];
+    VPK_HIP(h, hipEventSynchronize(evs[13]));
+    for (int i = 0; i < 13; ++i) VPK_HIP(h, hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
+    return VPK_OK;
+}
+
+int vpk_cnn_mean_layer_ms(vpk_handle* h, float ms[13], int* passes) {
+    if (!h || !ms || !h->cnn) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_mean_layer_ms: bad argument");
+    vpk_cnn_state* S = h->cnn;
+    if (!S->ev_valid || S->ev_pass < 1) return vpk_fail(h, VPK_ERR_STATE, "no profiled forward pass recorded");
+    const long long n = S->ev_pass < vpk_cnn_state::EV_RING ? S->ev_pass : vpk_cnn_state::EV_RING;
+    double sum[13] = {};
+    for (long long q = S->ev_pass - n; q < S->ev_pass; ++q) {
+        hipEvent_t* evs = S->ev[q % vpk_cnn_state::EV_RING];
+        VPK_HIP(h, hipEventSynchronize(evs[13]));
+        for (int i = 0; i < 13; ++i) {
+            float t = 0.f;
+            VPK_HIP(h, hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            sum[i] += t;
+        }
+    }
+    for (int i = 0; i < 13; ++i) ms[i] = (float)(sum[i] / (double)n);
+    if (passes) *passes = (int)n;
     return VPK_OK;
 }
 

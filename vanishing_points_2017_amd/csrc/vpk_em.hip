@@ -562,7 +562,37 @@ EmLayout small_layout(int n, int m) {
 
 }  // namespace
 
+namespace {
+// vpk_math_probe: the elementary functions exactly as this translation unit's kernels get them (same compiler flags, same
+// ocml entry points as em_device.hpp's calls), one argument per thread.
+__global__ void math_probe_kernel(int fn, long long n, const double* __restrict__ x, double* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double r;
+    switch (fn) {
+        case 0: r = exp(v); break;
+        case 1: r = acos(v); break;
+        case 2: r = asin(v); break;
+        case 3: r = atan(v); break;
+        case 4: r = sqrt(v); break;
+        case 5: r = sin(v); break;
+        case 6: r = cos(v); break;
+        default: r = log(v); break;
+    }
+    y[i] = r;
+}
+}  // namespace
+
 extern "C" {
+
+int vpk_math_probe(vpk_handle* h, int fn, long long n, const double* x, double* y) {
+    if (!h || fn < 0 || fn > 7 || n < 1 || !x || !y) return vpk_fail(h, VPK_ERR_ARG, "vpk_math_probe: bad argument");
+    VPK_HIP(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, fn, n, x, y);
+    VPK_HIP(h, hipGetLastError());
+    return VPK_OK;
+}
 
 int vpk_em_set_smoother(vpk_handle* h, int mode) {
     if (!h || mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_smoother: mode must be 0 or 1");

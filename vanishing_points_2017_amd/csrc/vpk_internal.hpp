@@ -49,6 +49,8 @@ struct vpk_handle {
     size_t raster_hdr_bytes = 0;
     std::vector<long long> raster_offsets;   // the offsets the device copy in raster_hdr holds (same batch again: no upload, no wait)
     int raster_table_size = 0;               // canvas size the sample table in raster_hdr was made for
+    int raster_last_batch = 0;               // batch of the last vpk_sphere_raster call (vpk_sphere_raster_flags' layout)
+    int raster_alternative = 0;              // vpk_sphere_raster_set_alternative
     bool em_ready = false;    // dynamic-LDS attribute set on the EM kernels
     // time-sliced EM launches (vpk_em_set_time_slice): images not finished within a launch's budget are parked
     // in device-side lists and resumed by the next launch; their slots outlive the launch

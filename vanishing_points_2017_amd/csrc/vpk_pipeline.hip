@@ -88,7 +88,7 @@ int vpk_pipeline_step(vpk_handle* cnn, vpk_handle* em, const vpk_step_args* a) {
         VPK_HIP(em, hipMemcpyAsync(a->l_work, a->l_in, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToDevice, em->stream));
     if (ev && ev[2]) VPK_HIP(em, hipEventRecord(ev[2], em->stream));
     // 4. the EM of this batch, its prior = the CNN's response maps
-    rc = vpk_em_batch(em, a->batch, a->offsets, a->l_work, a->lp, a->cnn_out, a->sphere, a->sphere_size, a->init_vp,
+    rc = vpk_em_batch(em, a->batch, a->offsets, a->l_work, a->lp, a->em_prior ? a->em_prior : a->cnn_out, a->sphere, a->sphere_size, a->init_vp,
                       a->n_init, a->params, a->max_vp, a->vp_out, a->sigma_out, a->counts_out, a->counts_w_out,
                       a->num_vp_out, a->assoc_out, a->iterations_out, a->status_out, a->flags_out, nullptr, nullptr);
     if (rc) return rc;

@@ -64,7 +64,17 @@ struct RasterArgs {
     unsigned char* alpha; unsigned long long alpha_cap;
     RowEnt* dense;                                       // [nlines + 4 spines][MAXSUB][size]
     int first_image;                                     // images [first_image, first_image + batch) of the caller's batch
+    int alt;                                             // 1: the reference's `alternative` curve (sphere_mapping.py:58-59)
 };
+
+// beta(alpha) of one sample, operation by operation as NumPy evaluates the reference's expression (sphere_mapping.py:59 /
+// :61, then `b *= -1`, :63) -- the unit is built with -ffp-contract=off
+__device__ __forceinline__ double curve_beta(double la, double lb, double lc, double sa, double ca, int alt) {
+    double be = alt ? -atan(-lc / (ca * la + sa * lb))                     // :59
+                    : -atan((-la * sa - lc * ca) / lb);                   // :61
+    be *= -1;                                                             // :63
+    return be;
+}
 
 // per sample, the same for every line: sin / cos of alpha (sphere_mapping.py:61-63) and the pixel x of the sample
 __global__ void raster_table_kernel(int ns, int size, double* tab) {
@@ -127,8 +137,7 @@ __global__ __launch_bounds__(64) void simplify_kernel(RasterArgs A) {
         const bool valid = i < ns;
         const int ic = valid ? i : ns - 1;
         const double sa = A.tab[4 * ic + 1], ca = A.tab[4 * ic + 2], x = A.tab[4 * ic];
-        double be = -atan((-la * sa - lc * ca) / lb);                         // sphere_mapping.py:63
-        be *= -1;                                                             // :65
+        const double be = curve_beta(la, lb, lc, sa, ca, A.alt);
         const double y = size - (be - lo_a) / (hi_a - lo_a) * size;
         const unsigned long long bad = __ballot(valid && (!(y == y) || isinf(y)));
         unsigned long long pending = __ballot(valid);
@@ -296,8 +305,7 @@ __global__ __launch_bounds__(64) void outline_kernel(RasterArgs A) {
             for (int u = 0; u < OG; ++u) {
                 const int i = i0 + u < ns ? i0 + u : ns - 1;
                 const double sa = A.tab[4 * i + 1], ca = A.tab[4 * i + 2];
-                double be = -atan((-la * sa - lc * ca) / lb);                     // sphere_mapping.py:63
-                be *= -1;                                                         // :65
+                const double be = curve_beta(la, lb, lc, sa, ca, A.alt);
                 xs[u] = A.tab[4 * i];
                 ys[u] = size - (be - lo_a) / (hi_a - lo_a) * size;
             }
@@ -773,7 +781,8 @@ extern "C" {
 
 int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, int batch, int size, double alpha,
                       uint8_t* out) {
-    if (!h || !l || !offsets || !out || batch < 1 || size < 8 || size > 1024 || !(alpha >= 0.0 && alpha <= 1.0))
+    if (!h || !offsets || !out || batch < 1 || size < 8 || size > 1024 || !(alpha >= 0.0 && alpha <= 1.0) ||
+        (!l && offsets[batch] != offsets[0]))             // (no lines at all: the frame-only canvas, l may be NULL)
         return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster: bad argument (size must be 8..1024, alpha 0..1)");
     VPK_HIP(h, hipSetDevice(h->device));
     for (int b = 0; b < batch; ++b)
@@ -796,15 +805,22 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // the coverage pool: 16 KB per line on average (measured: ~6 KB) and never less than eight canvases' worth -- the row
     // ranges of ONE line can span most of the canvas (see polygon_coverage), and a call may consist of one line
     const size_t alpha_bytes = std::max<size_t>(nl * 16384, (size_t)8 * size * (size + 2));
+    if (alpha_bytes >= (1ull << 32))                      // RowEnt::off is 32 bits (a chunk of 49 152 lines needs 0.8 GB)
+        return vpk_fail(h, VPK_ERR_LIMIT, "vpk_sphere_raster: one image has more than 262 000 lines");
     const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;   // (the slack also covers the blend's 8-byte reads at the pool's end)
-    const void* had = h->raster_hdr;
+    const size_t had_bytes = h->raster_hdr_bytes;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
     if (rc) return rc;
+    if (h->raster_hdr_bytes != had_bytes) {               // a fresh allocation (possibly at the old address): nothing cached in it
+        h->raster_offsets.clear();
+        h->raster_table_size = 0;
+    }
+    h->raster_last_batch = batch;
     char* base = (char*)h->raster_hdr;
     // offsets [host] -> device.  Caller-owned pageable memory, so the copy is waited for -- but a pipeline rasterises the
     // same batch structure again and again: when the device copy already holds these offsets nothing is uploaded and the
     // call does not wait for anything (the sample table is kept the same way).
-    const bool same = had == h->raster_hdr && h->raster_offsets.size() == (size_t)batch + 1 &&
+    const bool same = h->raster_offsets.size() == (size_t)batch + 1 &&
                       memcmp(h->raster_offsets.data(), offsets, (size_t)(batch + 1) * 8) == 0;
     if (!same) {
         VPK_HIP(h, hipStreamSynchronize(h->stream));
@@ -836,6 +852,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     A.seq = (int*)p; p += vpk::em_align(nl * 4, 256);
     A.nsimp = (int*)p; p += vpk::em_align(nl * 4, 256);
     A.force_seq = getenv("VPK_RASTER_SEQUENTIAL") != nullptr;   // development / tests: every line through the sequential machine
+    A.alt = h->raster_alternative;
     A.simp = (V2*)p; p += nl * MAXS * sizeof(V2);
     A.verts = (V2*)p; p += nl * MAXV * sizeof(V2);
     A.polys = (int*)p; p += vpk::em_align(nl * POLY_INTS * 4, 256);
@@ -867,7 +884,8 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         hipEvent_t ev[5] = {};
         if (times) for (int q = 0; q < 5; ++q) VPK_HIP(h, hipEventCreate(&ev[q]));
         if (times) VPK_HIP(h, hipEventRecord(ev[0], h->stream));
-        hipLaunchKernelGGL(simplify_kernel, dim3((unsigned)A.nlines), dim3(64), 0, h->stream, A);
+        if (A.nlines > 0)                                 // (a chunk of empty images: only the frame is drawn)
+            hipLaunchKernelGGL(simplify_kernel, dim3((unsigned)A.nlines), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[4], h->stream));
         hipLaunchKernelGGL(outline_kernel, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, A);
         if (times) VPK_HIP(h, hipEventRecord(ev[1], h->stream));
@@ -901,10 +919,18 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
  * kernel's buffers and was truncated / dropped); waits for the call to finish */
 int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out) {
     if (!h || !flags_out || batch < 1 || !h->raster_hdr) return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster_flags: bad argument");
+    if (batch != h->raster_last_batch)                    // the flags' place in the workspace depends on the call's batch
+        return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster_flags: batch differs from the last vpk_sphere_raster call's");
     VPK_HIP(h, hipSetDevice(h->device));
     VPK_HIP(h, hipStreamSynchronize(h->stream));
     const size_t ob = vpk::em_align((size_t)(batch + 1) * 8 + (size_t)batch * 4, 256);   // (the layout of vpk_sphere_raster)
     VPK_HIP(h, hipMemcpy(flags_out, (char*)h->raster_hdr + ob + 256, (size_t)batch * 4, hipMemcpyDeviceToHost));
+    return VPK_OK;
+}
+
+int vpk_sphere_raster_set_alternative(vpk_handle* h, int on) {
+    if (!h) return VPK_ERR_ARG;
+    h->raster_alternative = on ? 1 : 0;
     return VPK_OK;
 }
 

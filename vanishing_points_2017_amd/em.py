@@ -67,8 +67,13 @@ def em_batch_device(rt, offsets, l, lp, cnn, sphere, init_vp=None, params=None, 
 
 def upload_batch(rt, scenes):
     """Concatenate per-image host arrays and copy them to HBM.  scenes: list of dicts with
-    l (N x 3), lp (N x 4), cnn_response (20 x 20 f32), sphere_image (S x S u8)[, init_vp]."""
+    l (N x 3), lp (N x 4), cnn_response (20 x 20 f32), sphere_image (S x S u8)[, init_vp].  A scene whose
+    sphere_image is None gets it from its lines first, as the reference's datum does (evaluation.py:175):
+    sphere_mapping.attach_rasters -> vpk_sphere_raster."""
     torch = rt.torch
+    if any(s.get("sphere_image") is None for s in scenes):
+        from .sphere_mapping import attach_rasters
+        attach_rasters(scenes, runtime=rt)
     counts = [int(s["lp"].shape[0]) for s in scenes]
     offsets = np.zeros(len(scenes) + 1, dtype=np.int64)
     offsets[1:] = np.cumsum(counts)

@@ -121,3 +121,18 @@ def cluster2(ldist, device=0):
         rt.check(rt.lib.vpk_cluster2(rt.h, n, rt.ptr(d), rt.ptr(labels), rt.ptr(flags)))
     rt.synchronize()
     return labels.cpu().numpy(), int(flags.cpu()[0])
+
+
+MATH_FUNCTIONS = ("exp", "acos", "asin", "atan", "sqrt", "sin", "cos", "log")
+
+
+def math_probe(name, x, device=0):
+    """The device's double-precision elementary function ``name`` (as the EM kernels call it) on every element of x."""
+    rt = get_runtime(device)
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    dx = _up(rt, x, np.float64)
+    with rt.on_stream():
+        dy = rt.torch.empty_like(dx)
+        rt.check(rt.lib.vpk_math_probe(rt.h, MATH_FUNCTIONS.index(name), int(x.shape[0]), rt.ptr(dx), rt.ptr(dy)))
+    rt.synchronize()
+    return dy.cpu().numpy()

@@ -20,11 +20,37 @@ def golden_path(config_id):
 
 
 def input_sha(scene):
-    """First 8 bytes of sha1(l | lp | cnn_response | sphere_image) -- ties a stored result to its inputs."""
+    """First 8 bytes of sha1(l | lp | cnn_response) -- ties a stored result to the inputs the reference was given.  The
+    raster is not an input: the reference makes it from the lines (evaluation.py:175), see raster_sha."""
     h = hashlib.sha1()
-    for k in ("l", "lp", "cnn_response", "sphere_image"):
+    for k in ("l", "lp", "cnn_response"):
         h.update(np.ascontiguousarray(scene[k]).tobytes())
     return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def raster_sha(sphere_image):
+    """First 8 bytes of sha1 of a 500 x 500 uint8 raster: the stored value is that of the reference's own
+    sphere_line_plot (sphere_mapping.py:36-72) on the scene's lines."""
+    h = hashlib.sha1(np.ascontiguousarray(sphere_image, dtype=np.uint8).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def instability_certificates(path=None):
+    """{(config, image): certificate} from tests/golden/instability.npz (written in the build container by the test
+    infrastructure from runs of the REFERENCE itself): for an image the HIP path once failed the bar on, how far the
+    reference's own result moves when one input coordinate moves by one ulp.  'unstable' = the reference's own VPs moved
+    by more than the 1e-4 bar, or assignments flipped, or its iteration / VP count changed."""
+    path = path or os.path.join(ROOT, "tests", "golden", "instability.npz")
+    if not os.path.isfile(path):
+        return {}
+    g = np.load(path, allow_pickle=False)
+    out = {}
+    for k in range(len(g["config"])):
+        out[(int(g["config"][k]), int(g["index"][k]))] = {
+            "trials": int(g["trials"][k]), "max_vp_move": float(g["max_vp_move"][k]),
+            "max_assoc_flips": int(g["max_assoc_flips"][k]), "iterations_stable": bool(g["iterations_stable"][k]),
+            "num_vp_stable": bool(g["num_vp_stable"][k]), "unstable": bool(g["unstable"][k])}
+    return out
 
 
 class ReferenceResults(object):
@@ -53,7 +79,8 @@ class ReferenceResults(object):
                 "vp_assoc": g["assoc"][lo:hi].astype(np.int64), "vp": g["vp"][vo:vh], "sigma": g["sigma"][vo:vh],
                 "counts": g["counts"][vo:vh], "counts_weighted": g["counts_w"][vo:vh],
                 "hP1": g["hP1"][k], "hP2": g["hP2"][k], "combo": g["combo"][k],
-                "input_sha": g["input_sha"][k], "ref_seconds": float(g["ref_seconds"][k]),
+                "input_sha": g["input_sha"][k], "raster_sha": g["raster_sha"][k] if "raster_sha" in g else None,
+                "ref_seconds": float(g["ref_seconds"][k]),
                 "events": {e: int(g["ev_" + e][k]) for e in ("split", "merge", "abort", "final_merge")}}
 
 

@@ -16,9 +16,11 @@ MAX_VP = 64
 
 class Step(object):
     """Buffers of one batch in flight on (rt_cnn, rt_em).  ``d``: em.upload_batch() of the batch (resident inputs);
-    ``l_in``: the pristine lines (device, sum N x 3).  ``records=True`` also builds sharding-layout records."""
+    ``l_in``: the pristine lines (device, sum N x 3).  ``records=True`` also builds sharding-layout records.
+    ``em_prior``: B x 400 response maps (device) the EM uses instead of this step's CNN output (the CNN still runs)."""
 
-    def __init__(self, rt_cnn, rt_em, d, params, l_in=None, max_vp=MAX_VP, records=False, image_ids=None, timing=True):
+    def __init__(self, rt_cnn, rt_em, d, params, l_in=None, max_vp=MAX_VP, records=False, image_ids=None, timing=True,
+                 em_prior=None):
         torch = rt_em.torch
         self.rt_cnn, self.rt_em = rt_cnn, rt_em
         self.offsets = _lib.host_i64(d["offsets"])
@@ -68,8 +70,9 @@ class Step(object):
             status_out=ptr(o["status"]).value, flags_out=ptr(o["flags"]).value,
             records=None if self.records is None else ptr(self.records).value,
             image_ids=None if self.records is None else ptr(self.image_ids).value,
-            events=None if self._ev is None else ctypes.addressof(self._ev), reuse_event=self.guard.cuda_event)
-        self._keep = (d, init)
+            events=None if self._ev is None else ctypes.addressof(self._ev), reuse_event=self.guard.cuda_event,
+            em_prior=None if em_prior is None else ptr(em_prior).value)
+        self._keep = (d, init, em_prior)
 
     def enqueue(self, events=None):
         """CNN(batch) on rt_cnn's stream, EM(batch) on rt_em's stream behind it.  Asynchronous.  ``events``: a

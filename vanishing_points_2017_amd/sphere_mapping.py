@@ -24,16 +24,21 @@ def raster_batch_device(rt, l, offsets, size=500, alpha=0.1, out=None):
     return out
 
 
-def raster_batch(lines_list, size=500, alpha=0.1, device=0):
-    """Host convenience: list of (N_i x 3) arrays -> (B, size, size) uint8."""
-    rt = get_runtime(device)
-    counts = [int(a.shape[0]) for a in lines_list]
+def raster_batch(lines_list, size=500, alpha=0.1, device=0, alternative=False, runtime=None):
+    """Host convenience: list of (N_i x 3) arrays -> (B, size, size) uint8.  An image without lines gets the frame-only
+    canvas (what the reference's figure shows when the loop at sphere_mapping.py:54 runs zero times)."""
+    rt = runtime if runtime is not None else get_runtime(device)
+    counts = [int(np.asarray(a).reshape(-1, 3).shape[0]) for a in lines_list]
     offsets = np.zeros(len(counts) + 1, dtype=np.int64)
     offsets[1:] = np.cumsum(counts)
     cat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, 3) for a in lines_list], 0))
     with rt.on_stream():
-        d = rt.torch.from_numpy(cat).to(rt.tdev)
-    out = raster_batch_device(rt, d, offsets, size, alpha)
+        d = rt.torch.from_numpy(cat).to(rt.tdev) if cat.shape[0] else None
+    rt.check(rt.lib.vpk_sphere_raster_set_alternative(rt.h, 1 if alternative else 0))
+    try:
+        out = raster_batch_device(rt, d, offsets, size, alpha)
+    finally:
+        rt.check(rt.lib.vpk_sphere_raster_set_alternative(rt.h, 0))
     rt.synchronize()
     flags = raster_flags(rt, len(counts))
     if flags.any():                                          # never a silently incomplete raster
@@ -49,10 +54,18 @@ def raster_flags(rt, batch):
     return flags
 
 
+def attach_rasters(scenes, size=500, alpha=0.1, device=0, runtime=None):
+    """What the reference does when it makes a datum (evaluation.py:175): every scene whose 'sphere_image' is None gets
+    the raster of its lines (one vpk_sphere_raster call for all of them).  Returns ``scenes``."""
+    todo = [s for s in scenes if s.get("sphere_image") is None]
+    if todo:
+        for s, r in zip(todo, raster_batch([s["l"] for s in todo], size=size, alpha=alpha, device=device, runtime=runtime)):
+            s["sphere_image"] = r
+    return scenes
+
+
 def sphere_line_plot(lines, size, alpha=0.1, f=1.0, alternative=False, device=0):
     """sphere_mapping.py:36-72.  Scales lines[:, 0:2] by f IN PLACE like the reference (:55-56)."""
-    if alternative:
-        raise NotImplementedError("the 'alternative' parametrisation (:58-59) is never used by the reference")
     lines[:, 0] *= f
     lines[:, 1] *= f
-    return raster_batch([lines], size=size, alpha=alpha, device=device)[0]
+    return raster_batch([lines], size=size, alpha=alpha, device=device, alternative=alternative)[0]

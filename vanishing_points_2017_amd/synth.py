@@ -6,9 +6,11 @@ with the dataset's *shape*.  One "scene" mirrors the reference's per-image datum
 (`evaluation.py:152-177`): line segments ``lp`` (N x 4, normalised image
 coordinates, y up), homogeneous lines ``l = cross(p1, p2)`` (`evaluation.py:161-168`),
 a 20 x 20 float32 ``cnn_response`` laid out like the `sigout` blob
-(`evaluation.py:34-38`; row = beta bin ascending, column = alpha bin ascending) and
-a 500 x 500 uint8 ``sphere_image`` (image row 0 = beta = +pi/2,
-`sphere_mapping.py:36-72`).
+(`evaluation.py:34-38`; row = beta bin ascending, column = alpha bin ascending).  A scene carries NO
+raster (``sphere_image`` is None): the reference makes the 500 x 500 uint8 raster from the lines
+(`evaluation.py:175`, `sphere_mapping.py:36-72`), and so does everything here -- the product through
+``vpk_sphere_raster`` (`sphere_mapping.attach_rasters`), the fixtures through the reference's own
+`sphere_line_plot` (the fixture generator, build container only), the CPU tests through the test suite's own restatement.
 
 Seeds follow SURVEY 8d: ``seed = 1000 * config_id + image_index`` with
 ``numpy.random.RandomState``.
@@ -58,32 +60,11 @@ def vp_to_cell(vp, grid=20):
     return row, col
 
 
-def raster_numpy(l, size=500, alpha=0.1, samples=4000):
-    """Cheap host rasteriser of the inverse gnomonic projection (workload generator only).
-
-    Same curve as `sphere_mapping.py:61-63` (beta(alpha) = atan((-a sin - c cos)/b)),
-    drawn without anti-aliasing: every pixel a line touches is blended once with
-    ``alpha`` (white over black), value = 255 * (1 - (1-alpha)^k) for k lines."""
-    l = np.asarray(l, dtype=np.float64)
-    n = l.shape[0]
-    a = np.linspace(-np.pi / 2, np.pi / 2, samples)
-    sa, ca = np.sin(a), np.cos(a)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        b = np.arctan((-l[:, 0:1] * sa[None, :] - l[:, 2:3] * ca[None, :]) / l[:, 1:2])
-    col = np.clip(((a + np.pi / 2) / np.pi * size).astype(np.int64), 0, size - 1)
-    row = np.clip(((np.pi / 2 - b) / np.pi * size), 0, size - 1)
-    row = np.where(np.isfinite(row), row, 0).astype(np.int64)
-    flat = row * size + col[None, :] + (np.arange(n, dtype=np.int64) * size * size)[:, None]
-    flat = np.unique(flat.ravel())
-    hits = np.bincount(flat % (size * size), minlength=size * size).reshape(size, size)
-    img = 255.0 * (1.0 - (1.0 - alpha) ** hits)
-    return np.floor(img).astype(np.uint8)
-
-
 def make_scene(seed, n_lines, n_vps=3, focal=2.1, aspect_h=0.75, outlier_frac=0.25,
-               noise=0.004, rot_mode="euler", raster=raster_numpy, size=500):
-    """One synthetic image datum.  Returns a dict with l, lp, cnn_response,
-    sphere_image, true_vps (unit, z >= 0), true_horizon (homogeneous line)."""
+               noise=0.004, rot_mode="euler", raster=None, size=500):
+    """One synthetic image datum.  Returns a dict with l, lp, cnn_response, sphere_image (None unless a
+    ``raster`` callable (lines, size, alpha) -> uint8 image is given), true_vps (unit, z >= 0), true_horizon
+    (homogeneous line)."""
     rs = np.random.RandomState(seed)
     K = np.diag([focal, focal, 1.0])
     R = _rotation(rs, rot_mode)
@@ -134,7 +115,7 @@ def make_scene(seed, n_lines, n_vps=3, focal=2.1, aspect_h=0.75, outlier_frac=0.
             "image_shape": (int(round(640 * aspect_h)), 640)}
 
 
-def config_scenes(config_id, count=None, start=0, raster=raster_numpy):
+def config_scenes(config_id, count=None, start=0, raster=None):
     """Generator over the scenes of one BASELINE.json config."""
     name, n_img, (n_lo, n_hi), (v_lo, v_hi), aspect_h = CONFIGS[config_id]
     n_img = n_img if count is None else min(n_img, count)
