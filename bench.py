@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--cnn-fusion", type=int, default=1, choices=[0, 1, 2],
                     help="conv1 + norm1 + pool1: 1 = direct-convolution kernel (default), 2 = implicit-GEMM kernel with the fused "
                          "epilogue, 0 = separate kernels")
+    ap.add_argument("--cnn-priority", type=int, default=0, choices=[-1, 0],
+                    help="HIP stream priority of the CNN stream (-1 = high: its kernels' workgroups are dispatched ahead of the EM lanes')")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -447,7 +449,7 @@ def run_workload(args, dist, rank, local_rank, world):
         n_lanes = max(1, args.em_lanes)
         lanes = [get_runtime(local_rank, "em%d" % i) for i in range(n_lanes)]
         rt = lanes[0]
-        rt_cnn = get_runtime(local_rank, "cnn")
+        rt_cnn = get_runtime(local_rank, "cnn", priority=args.cnn_priority)
         em_wgs = args.em_wgs if args.em_wgs >= 0 else (max(8, (count * 5) // 17) if args.workload == "yud" else 0)   # 30 of 102: measured optimum (26: -1.5 %, 34: -1.5 %)
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)

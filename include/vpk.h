@@ -95,11 +95,13 @@ int vpk_device_info(const vpk_handle* h, int32_t info[4]);
  * queue inside the launch, which then lasts about as long as its slowest image anyway and leaves the
  * other CUs to the CNN. */
 int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
-/* Which kernel evaluates weight_matrix (vp_localisation.py:515-524) inside the EM.  0 (default): the row-sliced
- * kernel (partial sums never leave the wave, operands by DPP row broadcast) wherever its LDS panel fits, the round-1/2
- * kernels elsewhere; 1: always the round-1/2 kernels.  Both sum every (column, VP) in the same order, so every output
- * of vpk_em_batch / vpk_weight_matrix is bit-identical under either setting (tests/test_gpu_em.py): the switch exists
- * for that test and for A/B timing. */
+/* Which kernel evaluates weight_matrix (vp_localisation.py:515-524) inside the EM.  0 (default): the row-sliced kernel
+ * (partial sums never leave the wave, operands by DPP row broadcast) wherever its LDS panel fits, the round-1/2 kernels
+ * elsewhere; 1: always the round-1/2 kernels; 2: for images of up to 448 lines the sparse kernel (the terms whose operand
+ * p_vl * lweight is exactly zero -- more than four in five -- are left out; a wave per group of VPs, lsim staged through
+ * LDS by DMA once per call; measured slower than the dense kernel, kept as an option).  All of them sum every (column,
+ * VP) in the same order, so every output of vpk_em_batch / vpk_weight_matrix is bit-identical under the three settings
+ * (tests/test_gpu_em.py): the switch exists for that test and for A/B timing. */
 int vpk_em_set_smoother(vpk_handle* h, int mode);
 /* LDS the EM workgroup may plan with for its weight_matrix operand panel and the split's cluster matrix, in doubles;
  * 0 (default) = everything a CU has beside the workgroup's state (~18 800).  A smaller budget sends images down the

@@ -6,11 +6,13 @@ import torch
 from vanishing_points_2017_amd import synth, em as gem, cnn
 from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
-scenes = list(synth.config_scenes(2, count=102))
+from vanishing_points_2017_amd import sphere_mapping
+scenes = sphere_mapping.attach_rasters(list(synth.config_scenes(2, count=102)))
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 resp = net.forward(np.stack([s["sphere_image"] for s in scenes]))
-for s, r in zip(scenes, resp):
-    s["cnn_response"] = r
+if "--fixture" not in sys.argv:                       # default: the random-weight CNN's response maps (bench.py's `value`)
+    for s, r in zip(scenes, resp):
+        s["cnn_response"] = r
 res = gem.em_batch(scenes, want_trace=True)
 rows = []
 extra = []

@@ -7,7 +7,8 @@ import torch
 from vanishing_points_2017_amd import synth, em as gem
 from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
-scenes = list(synth.config_scenes(2, count=102))
+from vanishing_points_2017_amd import sphere_mapping
+scenes = sphere_mapping.attach_rasters(list(synth.config_scenes(2, count=102)))
 for copies, wgs in ((1, 34), (1, 102), (3, 102), (3, 256), (5, 256)):
     rt.handle.em_set_workgroups(wgs)
     sc = scenes * copies

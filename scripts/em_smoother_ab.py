@@ -7,7 +7,8 @@ import torch
 from vanishing_points_2017_amd import synth, em as gem, cnn
 from vanishing_points_2017_amd.runtime import get_runtime
 rt = get_runtime(0)
-scenes = list(synth.config_scenes(2, count=102))
+from vanishing_points_2017_amd import sphere_mapping
+scenes = sphere_mapping.attach_rasters(list(synth.config_scenes(2, count=102)))
 if "--cnn" in sys.argv:     # the bench's situation: the random-weight CNN's response maps as the prior
     net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
     resp = net.forward(np.stack([s["sphere_image"] for s in scenes]))
@@ -16,7 +17,7 @@ if "--cnn" in sys.argv:     # the bench's situation: the random-weight CNN's res
 p = gem._params({})
 d = gem.upload_batch(rt, scenes)
 l0 = d["l"].clone()
-for mode in (1, 0, 1, 0):
+for mode in (0, 2, 0, 2):
     rt.handle.em_set_smoother(mode)
     best = None
     for rep in range(3):

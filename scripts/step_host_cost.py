@@ -6,7 +6,8 @@ import torch
 from vanishing_points_2017_amd import cnn, em as gem, pipeline, synth
 from vanishing_points_2017_amd.runtime import get_runtime
 rt_cnn, rt_em = get_runtime(0, "cnn"), get_runtime(0, "em0")
-scenes = list(synth.config_scenes(2, count=102))
+from vanishing_points_2017_amd import sphere_mapping
+scenes = sphere_mapping.attach_rasters(list(synth.config_scenes(2, count=102)))
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0), runtime=rt_cnn)
 params = gem._params({})
 d = gem.upload_batch(rt_em, scenes)

@@ -64,6 +64,12 @@ VPK_DEV void sched_fence() {}
 // never executed with one lane (the row-sliced smoother needs a 64-lane wave); present so that the source compiles
 template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b) { for (int q = 0; q < 8; ++q) a[q] = fma(op, b, a[q]); }
 VPK_DEV void wave_lds_order() {}
+VPK_DEV double readlane_f64(double v, int) { return v; }
+VPK_DEV unsigned lds_addr_of(const void*) { return 0; }
+VPK_DEV void lds_dma16(unsigned, const void*, unsigned) {}
+template <int N> VPK_DEV void wait_vm() {}
+VPK_DEV void raw_barrier() {}
+VPK_DEV void pin1(double&) {}   // (the sparse smoother: never executed with one lane either)
 VPK_DEV int uniform_int(int v) { return v; }
 VPK_DEV cgdp uniform_ptr(cgdp p) { return p; }
 VPK_DEV double load_at(cgdp base, unsigned byte_off) { return *reinterpret_cast<cgdp>(reinterpret_cast<const char*>(base) + byte_off); }

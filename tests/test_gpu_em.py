@@ -323,15 +323,17 @@ def test_row_sliced_smoother_gives_the_bits_of_the_round2_kernels():
     scenes = gpu_rasters(scenes)
     new = _with_smoother(0, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
     old = _with_smoother(1, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
+    rows = _with_smoother(2, lambda: gem.em_batch([dict(s, l=s["l"].copy()) for s in scenes], want_metric=True))
     ok = 0
-    for a, b in zip(new, old):
-        assert a["status"] == b["status"]
+    for a, b, r3 in zip(new, old, rows):                  # row-sliced (default) | round-1/2 kernels | sparse (round 4, optional)
+        assert a["status"] == b["status"] == r3["status"]
         if a["status"] != 0:
             continue
         ok += 1
-        assert a["iterations"] == b["iterations"]
+        assert a["iterations"] == b["iterations"] == r3["iterations"]
         for key in ("vp", "sigma", "counts", "counts_weighted", "vp_assoc", "decision_metric"):
             assert np.array_equal(a[key], b[key]), key
+            assert np.array_equal(a[key], r3[key]), key
     assert ok >= 112
 
 
@@ -353,6 +355,7 @@ def test_weight_matrix_row_sliced_vs_round2_vs_numpy(n, m):
     new = _with_smoother(0, lambda: kernels.weight_matrix(pvl, lw, lsim))
     old = _with_smoother(1, lambda: kernels.weight_matrix(pvl, lw, lsim))
     assert np.array_equal(new, old)
+    assert np.array_equal(new, _with_smoother(2, lambda: kernels.weight_matrix(pvl, lw, lsim)))
     w_ = pvl * lw
     want = (w_ + lw * (w_ @ lsim)) / (1 + lw * lsim.sum(0))
     assert relerr(new, want) <= 1e-12

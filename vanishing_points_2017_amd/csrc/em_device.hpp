@@ -102,7 +102,8 @@ struct EmCtx {
     gdp lcopy;    // N x 3 normalised lines (l points here once the setup has run)
     gdp lpcopy;   // N x 4 segment end points (lp likewise)
     gdp state;    // snapshot of Shared while the image is suspended
-    int smoother = 0; // 0: the row-sliced smoother wherever it applies; 1: always the round-1/2 kernels (A/B tests: same bits)
+    int smoother = 0; // 0: the row-sliced smoother wherever it applies; 1: always the round-1/2 kernels; 2: the sparse smoother
+                      // where it applies (slower, see smooth_sparse), the row-sliced one elsewhere -- same bits under all three
 };
 
 // point the context's scratch pointers into one slot
@@ -711,8 +712,12 @@ VPK_DEVFN void weights_setup(EmCtx& c) {
         c.lweight[n] = uw ? line_length(a) * clip(c.lscore[n], 0.2, 1.0) : 1.0;
     }
     block_sync();
-    for (int k = tid(); k < N; k += nthreads())
+    for (int k = tid(); k < N; k += nthreads()) {
         c.den[k] = 1 + c.prm.wbias * c.lweight[k] * (uw ? c.rowsum[k] : 0.0);
+        // a NaN / Inf in lsim (a segment of length 0) shows in its row sum: the sparse smoother, which leaves out the
+        // terms 0 * lsim, then stands back (0 * Inf is NaN, not 0)
+        if (uw && !(fabs(c.rowsum[k]) <= 1.7976931348623157e308)) SH().ibuf[2] = 1;
+    }
     block_sync();
 }
 
@@ -959,7 +964,7 @@ VPK_DEV int smooth_plan(const EmCtx& c, int M) {
     const int N = c.N;
     if (!c.prm.use_weights || M <= 0) return 0;
     const int Wp = ((M + MT - 1) / MT) * MT;
-    const bool rows_ok = WAVE == 64 && nwaves() == 8 && c.smoother == 0;
+    const bool rows_ok = WAVE == 64 && nwaves() == 8 && c.smoother != 1;
     const int colw = N > WAVE ? 2 * WAVE : WAVE;                   // smooth_full's column groups: when they divide evenly
     const bool direct = (((N + colw - 1) / colw) % 8) == 0;        // among the waves it sums ALL rows in one chain
     if (M <= 32) {
@@ -1529,6 +1534,225 @@ VPK_DEVFN void smooth_rows(EmCtx& c, int m0) {
     if (tid() == 0) sh.dbuf[10] += lap(tq_);        // + waiting for the other waves
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse smoother (round 4, NOT the default: vpk_em_set_smoother(h, 2)): the same sums in the same order as smooth_rows /
+// smooth_full, without the zero terms.  Built to test the lead "82-85 % of the operands are zeros" and measured SLOWER than
+// the dense row-sliced kernel on the bench's batch (smoothing 114 ms of workgroup time per YUD batch against 84 ms; 58-62
+// against 55 us per call at N = 364, M = 24): a wave issues at most one instruction every four cycles and the workgroup has
+// two waves per SIMD, so what counts is instructions per wave, and the sparse kernel spends ~45 (mostly scalar: next set
+// bit, slice boundary test, a test and a branch per VP, two v_readlane per weight) per staged row step where the dense
+// kernel spends its W = 24 v_fmac_f64_dpp and almost nothing else -- six times fewer FMAs bought with more than six times
+// the control instructions.  The LDS traffic (21 us estimated) and the staging (1 % of the time waiting for the DMA) are
+// not what bounds it; the barrier per block costs 28 % (the waves own VPs, and VPs have unequal numbers of lines).  Kept
+// as an option with its bit-equality test; DESIGN.md section 8.
+//
+// 82-85 % of the operands w_[line][vp] = p_vl * lweight are exact zeros: a line has a non-zero responsibility for two to
+// four of ~20 hypotheses, exp underflows to 0 for the rest (sigma^2 <= 1e-6, :306).  fma(0, x, acc) returns acc bit for
+// bit for a finite x (acc is never -0), so leaving those terms out changes nothing -- provided lsim holds no NaN / Inf
+// (sh.ibuf[2], set from the row sums: a line of length 0).  The dense kernels cannot skip them: one of their FMA
+// instructions covers four lines (slices) at once.  Here
+//   * a WAVE owns up to four VPs (t = wave, wave + 8, ...), a LANE owns the columns k = lane, lane + 64, ... (CMAX per lane):
+//     the accumulators of a (VP, column) never leave their lane;
+//   * lsim is staged through LDS in blocks of SP_R consecutive rows by all threads (every element fetched once per call,
+//     16-byte loads one block ahead of the block being used: the traffic of the dense kernels), two buffers, ONE
+//     workgroup barrier per block;
+//   * the wave's weights sit in registers, lane l holding w_[64 ci + l][t]; per block and VP a ballot gives the rows of
+//     the block with a non-zero weight, and for each of them the wave reads the staged row (conflict-free 8-byte reads)
+//     and issues ONE fma per column group with the weight as a scalar operand (v_readlane);
+//   * the summation order of the dense kernels is kept: rows ascending, a partial per slice of jch = ceil(N / 8) rows,
+//     the eight partials added in slice order (an empty slice adds +0) -- hence the same bits in every output
+//     (tests/test_gpu_em.py compares the three smoothers with array_equal).
+// Applies where smooth_rows applied and N <= 64 CMAX; everything else keeps its kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_R = 16;                                // rows per staged block
+constexpr int SP_CMAX = 7;                              // column groups of 64 per lane: N <= 448
+VPK_DEV int sp_cgroups(int N) { return (N + WAVE - 1) / WAVE; }
+VPK_DEV int sp_ldw(int C) { return ((C + 1) / 2) * 2 * WAVE; }   // staged row: whole 1 KB DMA pieces (128 doubles)
+VPK_DEV int sp_ring(int C) { return C <= 6 ? 3 : 2; }           // staged blocks in LDS (one in use, the others in flight)
+VPK_DEV bool sparse_smoother_fits(const EmCtx& c) {
+    const int C = sp_cgroups(c.N);
+    return WAVE == 64 && nwaves() == 8 && c.smoother == 2 && c.N > 0 && C <= SP_CMAX &&
+           sp_ring(C) * SP_R * sp_ldw(C) <= c.wt_doubles;
+}
+template <int C>                                        // C = column groups of 64 in use: ceil(N / 64)
+VPK_DEVFN void smooth_sparse(EmCtx& c, int m0) {
+    Shared& sh = SH();
+    constexpr int R = SP_R, NB = C <= 6 ? 3 : 2, VPW = 4;   // rows per block, ring size (sp_ring), VPs per wave
+    constexpr int AHEAD = NB - 1;                   // blocks in flight ahead of the one in use
+    constexpr int LDW = ((C + 1) / 2) * 2 * (WAVE >= 2 ? WAVE : 2);   // row stride of a staged row (doubles)
+    constexpr int DPR = LDW / 128 > 0 ? LDW / 128 : 1;                 // DMA pieces per row
+    constexpr int DPB = R * DPR / 8;                // DMA pieces per wave and block (8 waves: two rows' worth)
+    constexpr int BPG = (WAVE >= R ? WAVE : R) / R; // blocks per group of 64 rows
+    const int N = uniform_int(c.N);
+    m0 = uniform_int(m0);
+    const int M = uniform_int(sh.M) - m0 < 32 ? uniform_int(sh.M) - m0 : 32;   // VPs of this pass: [m0, m0 + M)
+    const int jch = rs_jchunk(N);
+    const int nblk = (N + R - 1) / R;
+    const size_t ld = (size_t)uniform_int(c.ld), ldn = (size_t)uniform_int(c.ldn);
+    const double bias = c.prm.wbias;
+    cgdp lsim = uniform_ptr(c.lsim);
+    cgdp lweight = c.lweight, den = c.den, pvl = c.pvl;
+    gdp wout = c.w;
+    double* buf = WT();                             // [NB][R][LDW]: the ring
+    const unsigned buf_lds = lds_addr_of(buf);
+    long long tq_ = clock_ticks();
+    const int wv = uniform_int(wave_id()), ln = lane();
+    // ---- this wave's weights: wreg[q][ci] = w_[64 ci + lane][m0 + wv + 8 q] = p_vl * lweight (weight_matrix :519).  All of
+    //      them up front: the main loop then has no vector-memory operation but its DMA, whose completion it counts ----
+    double wreg[VPW][C];
+    {
+        // unconditional loads (indices clamped into the arrays) so that they are issued together, selected afterwards
+        double lwv[C], raw[VPW][C];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) {
+            const int j = ci * WAVE + ln;
+            lwv[ci] = lweight[j < N ? j : N - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < VPW; ++q) {
+            const int t = wv + 8 * q;
+            cgdp row = pvl + (size_t)(m0 + (t < M ? t : M - 1)) * ldn;
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                const int j = ci * WAVE + ln;
+                raw[q][ci] = row[j < N ? j : N - 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                const double prod = raw[q][ci] * lwv[ci];
+                wreg[q][ci] = (ci * WAVE + ln < N && wv + 8 * q < M) ? prod : 0.0;
+            }
+    }
+    double part[VPW][C], tot[VPW][C];
+#pragma unroll
+    for (int q = 0; q < VPW; ++q)
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) { part[q][cc] = 0.0; tot[q][cc] = 0.0; }
+    int bound[VPW];                                 // first row of the slice after the one part[q] belongs to
+#pragma unroll
+    for (int q = 0; q < VPW; ++q) bound[q] = jch;
+    double blwk[C], dnk[C];                         // the results' per-column constants (:522), fetched now for the same reason
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const int k = cc * WAVE + ln;
+        const int kc = k < N ? k : N - 1;
+        blwk[cc] = bias * lweight[kc];
+        dnk[cc] = den[kc];
+        pin1(blwk[cc]); pin1(dnk[cc]);
+    }
+    // every weight has arrived before the first DMA is issued: from here on the compiler has no vector-memory operation of
+    // its own in flight and puts no s_waitcnt vmcnt into the main loop (one there would wait for the whole ring)
+#pragma unroll
+    for (int q = 0; q < VPW; ++q)
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) pin1(wreg[q][ci]);
+    wait_vm<0>();
+    // ---- staging by LDS-DMA: piece p of a block = (row p / DPR, 128 doubles p % DPR); wave w issues the pieces w, w + 8, ..
+    //      Rows up to 8 ceil(N / 8) - 1 exist (zero_tail_rows); a piece may run past its row's ld doubles into the next
+    //      row -- those doubles land in columns no lane owns a result for ----
+    auto issue = [&](int blk) __attribute__((always_inline)) {
+        const unsigned dst = buf_lds + (unsigned)((blk % NB) * R * LDW * 8);
+#pragma unroll
+        for (int u = 0; u < DPB; ++u) {
+            const int p = wv + 8 * u;
+            const int r = p / DPR, x = p - r * DPR;
+            cgdp src = lsim + ((size_t)(blk * R + r) * ld + (size_t)x * 128);
+            lds_dma16((unsigned)ln * 16u, (const void*)uniform_ptr(src), (unsigned)uniform_int((int)(dst + (unsigned)((r * LDW + x * 128) * 8))));
+        }
+    };
+    issue(0);
+    if (AHEAD > 1 && nblk > 1) issue(1);
+    if (AHEAD > 2 && nblk > 2) issue(2);
+    if (tid() == 0) sh.dbuf[8] += lap(tq_);
+    // ---- the blocks: group ci of 64 rows = BPG blocks; (ci, q) static so that the accumulators stay in registers ----
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+        if (ci * BPG >= nblk) break;                // uniform
+        unsigned long long nz[VPW];
+#pragma unroll
+        for (int q = 0; q < VPW; ++q) nz[q] = wave_ballot(wreg[q][ci] != 0.0);
+        for (int b8 = 0; b8 < BPG; ++b8) {
+            const int blk = ci * BPG + b8;
+            if (blk >= nblk) break;                 // uniform
+            // this wave's pieces of block blk have landed (the pieces of the AHEAD - 1 later blocks may still be in flight) ...
+            const int later = nblk - 1 - blk;
+            if (AHEAD >= 2 && later >= AHEAD - 1) wait_vm<(AHEAD - 1) * DPB>(); else wait_vm<0>();
+            raw_barrier();                          // ... and every wave's; everybody is done with block blk - 1
+            if (blk + AHEAD < nblk) issue(blk + AHEAD);   // into the buffer block blk - 1 used
+            const double* rows = buf + (size_t)(blk % NB) * R * LDW + ln;
+            unsigned mq[VPW], any = 0;              // per VP: the rows of this block with a non-zero weight; their union
+#pragma unroll
+            for (int q = 0; q < VPW; ++q) { mq[q] = (unsigned)(nz[q] >> (b8 * R)) & ((1u << R) - 1u); any |= mq[q]; }
+            if (any == 0) continue;                 // uniform
+            // One staged row serves all of the wave's VPs that have a weight for it; the row of the NEXT step is requested
+            // before the FMAs of the current one (two register sets that swap roles).
+            auto read_row = [&](int bit, double (&v)[C]) __attribute__((always_inline)) {
+                const double* rp = rows + (size_t)bit * LDW;
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) v[cc] = rp[cc * WAVE];
+            };
+            int bit = __builtin_ctz(any);
+            any &= any - 1;
+            double va[C], vb[C];
+            read_row(bit, va);
+            auto step = [&](double (&cur)[C], double (&nxt)[C]) __attribute__((always_inline)) {
+                const int cb = bit;
+                const bool more = any != 0;
+                bit = more ? __builtin_ctz(any) : cb;   // (after the last row: the same row once more -- the reads are issued
+                any &= any - 1;                         //  unconditionally so that the compiler can count them: a conditional
+                read_row(bit, nxt);                     //  request makes it wait for ALL outstanding reads before the FMAs)
+                const int j = ci * WAVE + b8 * R + cb;
+#pragma unroll
+                for (int q = 0; q < VPW; ++q) {
+                    if (!((mq[q] >> cb) & 1u)) continue;    // uniform
+                    while (j >= bound[q]) {         // the row opens a later slice: close the current partial
+#pragma unroll
+                        for (int cc = 0; cc < C; ++cc) { tot[q][cc] += part[q][cc]; part[q][cc] = 0.0; }
+                        bound[q] += jch;
+                    }
+                    const double wj = readlane_f64(wreg[q][ci], b8 * R + cb);
+#pragma unroll
+                    for (int cc = 0; cc < C; ++cc) part[q][cc] = fma(wj, cur[cc], part[q][cc]);
+                }
+                return more;
+            };
+            for (;;) {
+                if (!step(va, vb)) break;
+                if (!step(vb, va)) break;
+            }
+        }
+    }
+    if (tid() == 0) sh.dbuf[9] += lap(tq_);
+    // ---- results: w[m][k] = (w_[k][m] + bias lweight[k] sum) / den[k]  (:522) ----
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const int k = cc * WAVE + ln;
+        if (k < N) {
+#pragma unroll
+            for (int q = 0; q < VPW; ++q) {
+                const int t = wv + 8 * q;
+                if (t < M) wout[(size_t)(m0 + t) * ldn + k] = (wreg[q][cc] + blwk[cc] * (tot[q][cc] + part[q][cc])) / dnk[cc];
+            }
+        }
+    }
+    block_sync();                                   // (also: nobody reads the ring any more -- the panel region is free)
+    if (tid() == 0) sh.dbuf[10] += lap(tq_);
+}
+VPK_DEVFN void smooth_sparse_any(EmCtx& c, int m0) {
+    switch (sp_cgroups(c.N)) {
+        case 1: smooth_sparse<1>(c, m0); break;
+        case 2: smooth_sparse<2>(c, m0); break;
+        case 3: smooth_sparse<3>(c, m0); break;
+        case 4: smooth_sparse<4>(c, m0); break;
+        case 5: smooth_sparse<5>(c, m0); break;
+        case 6: smooth_sparse<6>(c, m0); break;
+        default: smooth_sparse<7>(c, m0); break;
+    }
+}
+
 VPK_DEVFN void smooth_dispatch(EmCtx& c);
 VPK_DEVFN void smooth(EmCtx& c) {
     smooth_dispatch(c);
@@ -1547,6 +1771,10 @@ VPK_DEVFN void smooth_dispatch(EmCtx& c) {
     if (M == 0) return;
     const int plan = smooth_plan(c, M);
     if (WAVE == 64 && (sh.ibuf[5] >= RS_PANEL_FLAG || plan == 2 || plan == 3)) {   // (an E-step's panel decides; none: the plan)
+        if (sparse_smoother_fits(c) && sh.ibuf[2] == 0) {   // the zero terms left out (same sums, same order, same bits)
+            for (int m0 = 0; m0 < M; m0 += 32) smooth_sparse_any(c, m0);
+            return;
+        }
         const int wpass = plan == 3 ? rs_wfit(c) : 32;      // VPs per pass
         for (int m0 = 0; m0 < M; m0 += wpass) {
             const int mm = (M - m0) < wpass ? (M - m0) : wpass;
@@ -2320,7 +2548,7 @@ VPK_DEVFN int em_run(EmCtx& c, EmOut& o, EmSlice& sl) {
         restore_state(c);
         first = sl.start_iter;
     } else {
-    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.ibuf[5] = 0; sh.active_us = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
+    if (tid() == 0) { sh.flags = 0; sh.M = 0; sh.ncomp = 0; sh.ibuf[5] = 0; sh.ibuf[2] = 0; sh.active_us = 0; for (int q = 8; q < 16; ++q) sh.dbuf[q] = 0; }
     block_sync();
     if (o.trace)
         for (int q = tid(); q < TRACE_COLS * (P.num_iter + 1); q += nthreads()) o.trace[q] = 0.0;

@@ -357,8 +357,9 @@ __global__ __launch_bounds__(EM_BOUND) void weight_matrix_kernel(int n, int m, c
     bind_scratch(c, ws, L, false);
     for (int p = tid(); p < n * n; p += nthreads())      // caller's matrix (row stride n) -> padded rows
         c.lsim[(size_t)(p / n) * c.ld + p % n] = lsim[p];
-    if (tid() == 0) { sh.M = m; sh.ibuf[5] = 0; }        // no E-step ran: the operand panel is not in LDS
+    if (tid() == 0) { sh.M = m; sh.ibuf[5] = 0; sh.ibuf[2] = 0; }   // no E-step ran: the operand panel is not in LDS
     for (int i = tid(); i < n; i += nthreads()) c.lweight[i] = lweight[i];
+    for (int p = tid(); p < m * n; p += nthreads()) c.pvl[(size_t)(p / n) * c.ldn + p % n] = p_vl[p];   // (the sparse smoother's source)
     for (int p = tid(); p < n * c.mcap; p += nthreads()) {
         int i = p / c.mcap, k = p % c.mcap;
         c.wsrc[(size_t)i * c.mcap + k] = k < m ? p_vl[(size_t)k * n + i] * lweight[i] : 0.0;
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(EM_BOUND) void weight_matrix_kernel(int n, int m, c
         double sum = 0.0;
         for (int j = 0; j < n; ++j) sum += lsim[(size_t)j * n + k];
         c.den[k] = 1 + bias * c.lweight[k] * sum;
+        if (!(fabs(sum) <= 1.7976931348623157e308)) sh.ibuf[2] = 1;       // (see weights_setup)
     }
     block_sync();
     zero_tail_rows(c);
@@ -595,7 +597,7 @@ int vpk_math_probe(vpk_handle* h, int fn, long long n, const double* x, double* 
 }
 
 int vpk_em_set_smoother(vpk_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_smoother: mode must be 0 or 1");
+    if (!h || mode < 0 || mode > 2) return vpk_fail(h, VPK_ERR_ARG, "vpk_em_set_smoother: mode must be 0, 1 or 2");
     h->em_smoother = mode;
     return VPK_OK;
 }

@@ -789,7 +789,10 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
         if (offsets[b + 1] < offsets[b]) return vpk_fail(h, VPK_ERR_ARG, "vpk_sphere_raster: offsets not monotone");
     const int samples = 10000;                            // sphere_mapping.py:40
     // images are processed in chunks of at most ~48k lines (workspace per line: outline scratch + coverage pools)
-    const long long max_lines = 49152;
+    // (the `alternative` curve has a pole: a row can be crossed three times -- left branch, the jump, right branch -- and a
+    // row range then spans half the canvas, so its lines get a canvas' worth of coverage pool each and smaller chunks)
+    const bool alt = h->raster_alternative != 0;
+    const long long max_lines = alt ? std::max<long long>(1, std::min<long long>(49152, (3ll << 30) / ((long long)size * (size + 2)))) : 49152;
     const size_t per_line = (size_t)MAXS * sizeof(V2) + (size_t)MAXV * sizeof(V2) + POLY_INTS * 4 +
                             (size_t)MAXSUB * size * sizeof(RowEnt) + 8;
     long long chunk_lines = 0;
@@ -804,7 +807,7 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     const size_t nl = (size_t)chunk_lines + 4;
     // the coverage pool: 16 KB per line on average (measured: ~6 KB) and never less than eight canvases' worth -- the row
     // ranges of ONE line can span most of the canvas (see polygon_coverage), and a call may consist of one line
-    const size_t alpha_bytes = std::max<size_t>(nl * 16384, (size_t)8 * size * (size + 2));
+    const size_t alpha_bytes = std::max<size_t>(nl * (alt ? (size_t)size * (size + 2) : (size_t)16384), (size_t)8 * size * (size + 2));
     if (alpha_bytes >= (1ull << 32))                      // RowEnt::off is 32 bits (a chunk of 49 152 lines needs 0.8 GB)
         return vpk_fail(h, VPK_ERR_LIMIT, "vpk_sphere_raster: one image has more than 262 000 lines");
     const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;   // (the slack also covers the blend's 8-byte reads at the pool's end)
@@ -930,6 +933,7 @@ int vpk_sphere_raster_flags(vpk_handle* h, int batch, uint32_t* flags_out) {
 
 int vpk_sphere_raster_set_alternative(vpk_handle* h, int on) {
     if (!h) return VPK_ERR_ARG;
+    if (h->raster_alternative != (on ? 1 : 0)) h->raster_offsets.clear();   // (the chunking, hence the cached image order, differs)
     h->raster_alternative = on ? 1 : 0;
     return VPK_OK;
 }

@@ -200,6 +200,8 @@ template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b)
         : "v"(op), "v"(b), "n"(BASE), "n"(BASE + 1), "n"(BASE + 2), "n"(BASE + 3), "n"(BASE + 4), "n"(BASE + 5),
           "n"(BASE + 6), "n"(BASE + 7));
 }
+// one value: whatever produces it (a load) is complete before this point
+VPK_DEV void pin1(double& a) { asm volatile("" : "+v"(a)); }
 // a value every lane holds identically, moved to a scalar register: loops and branches on it are scalar (values read through
 // a context pointer arrive in vector registers and would otherwise be treated as divergent)
 VPK_DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -218,6 +220,23 @@ VPK_DEV double load_at(cgdp base, unsigned byte_off) {
 VPK_DEV void wave_lds_order() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// LDS-DMA (global_load_lds_dwordx4): the 64 lanes of a wave move 16 bytes each from (sbase + voff), sbase wave-uniform, to
+// LDS at lds_dst + 16 * lane -- no staging registers, no ds_write.  Issued from inline asm: the compiler does not know that
+// the instruction writes LDS and is not asked to; completion is counted by hand (wait_vm<N>: at most N vector-memory
+// operations of this wave still outstanding; they retire in order) and published to the other waves by a barrier.  M0
+// (compiler-reserved) carries the LDS address and is saved / restored inside the statement; the s_nop covers the wait
+// states after a VALU write of the SGPR operands, which the hazard recogniser cannot see inside an asm statement.
+VPK_DEV unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+VPK_DEV void lds_dma16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> VPK_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+VPK_DEV void raw_barrier() {                        // LDS traffic of this wave done, then the workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // constant-rate (100 MHz) device clock for the optional phase timing in the EM trace
