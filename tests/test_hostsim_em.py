@@ -168,3 +168,22 @@ def test_cluster2_row_cache_against_sklearn_many_sets():
             assert np.array_equal(labels, model.labels_), n
         else:
             assert flags & 1                                   # an exact tie: sklearn's heap order decides, flagged
+
+
+def test_final_prune_scan_does_not_start_over():
+    """vp_localisation.py:423-437: after a VP with fewer than num_min_lines lines is removed the reference's scan goes on at
+    the SAME index; a VP in front of it whose count drops below the minimum through the re-assignment is never looked at
+    again.  configs[3] image 558 (stored in tests/golden/full_c4.npz: the reference keeps a VP with 2 lines, 17 VPs in
+    all); a scan that starts over removes it too (16 VPs) -- round 4 found the device code doing that."""
+    from golden_util import cpu_rasters
+    from vanishing_points_2017_amd import parity, synth
+    ref = parity.ReferenceResults(4)
+    g = ref.get(558)
+    sc = cpu_rasters(synth.config_scenes(4, count=1, start=558))[0]
+    assert parity.input_sha(sc) == g["input_sha"] and parity.raster_sha(sc["sphere_image"]) == g["raster_sha"]
+    assert g["vp"].shape[0] == 17 and g["counts"].min() == 2
+    res = simlib.em_single(sc["l"].copy(), sc["lp"], sc["cnn_response"], sc["sphere_image"])
+    assert res["status"] == 0 and res["iterations"] == g["iterations"]
+    assert res["vp"].shape == g["vp"].shape
+    assert np.array_equal(res["vp_assoc"], g["vp_assoc"]) and np.array_equal(res["counts"], g["counts"])
+    assert abserr(res["vp"], g["vp"]) <= 1e-9

@@ -2677,12 +2677,18 @@ VPK_DEVFN int em_run(EmCtx& c, EmOut& o, EmSlice& sl) {
             smooth(c);                                        // :417
             assign_lines(c, true);                            // :418
             count_lines(c);
-            for (int guard = 0; guard < MAXM + 1; ++guard) {  // :423-437
+            // :423-437.  The reference's scan does NOT start over after a removal: `vidx` stays where it is (the next VP has
+            // moved into that index), so a VP in front of it whose count drops below num_min_lines through the re-assignment
+            // that follows a removal is never looked at again and survives with fewer lines (configs[3] image 558: a VP with
+            // 2 lines in the reference's result)
+            int vscan = 0;
+            for (int guard = 0; guard < MAXM + 1; ++guard) {
                 int vidx = -1;
-                for (int m = 0; m < sh.M; ++m)
+                for (int m = vscan; m < sh.M; ++m)
                     if (sh.cnt[m] < P.num_min_lines) { vidx = m; break; }
                 block_sync();
                 if (vidx < 0) break;
+                vscan = vidx;
                 for (int m = tid(); m < sh.M; m += nthreads()) sh.removed[m] = (m == vidx);
                 block_sync();
                 compact_vps(c);
