@@ -154,6 +154,15 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on);
  *   1            every f32 operand as the exact sum of three bf16 pieces, six bf16 matrix products per f32 product
  *                (everything above 2^-24 of the product), f32 accumulation -- same error class, see DESIGN.md */
 int vpk_cnn_set_precision(vpk_handle* h, int mode);
+/* Algorithm of conv3..conv5 (3 x 3, stride 1, pad 1; deploy.prototxt:104-174) in the native-f32 mode:
+ *   1  (default) Winograd's minimal filtering F(2 x 2, 3 x 3): 16 instead of 36 f32 matrix-core products per 2 x 2 outputs
+ *      and input channel, input / output transforms in f32.  Same arithmetic type and accumulation width as the direct
+ *      form; the rounding differs (products of transformed operands) -- measured against a float64 evaluation of the net
+ *      its error is no larger than the direct path's (tests/test_gpu_cnn.py: 0.7e-6 against 1.8e-6 of the blob's scale at
+ *      conv3..5).  (What Caffe itself computes in the reference's GPU mode, evaluation.py:20, is cuDNN's choice among
+ *      such algorithms.)
+ *   0  direct: implicit GEMM over the 9 taps -- every output is one f32 FMA chain over (channel, tap) */
+int vpk_cnn_set_algorithm(vpk_handle* h, int mode);
 
 /* per-layer device time of the last vpk_cnn_forward (single chunk), from HIP events recorded on
  * the handle's stream between the layers: ms[13] = conv1, norm1, pool1, conv2, norm2, pool2, conv3,

@@ -119,5 +119,7 @@ def test_all_2018_hlw_shape_images_in_one_launch():
         assert parity.raster_sha(scenes[k]["sphere_image"]) == ref.get(k)["raster_sha"], k
     assert len(res) == 2018 and all(r["status"] in (0, 1, 2) for r in res)
     assert sum(r["status"] == 0 for r in res) >= 2000
-    bad = [(k, parity.compare_one(res[k], ref.get(k))) for k in sorted(stored) if not parity.passes(parity.compare_one(res[k], ref.get(k)))]
+    cert = parity.instability_certificates()             # (images on which the reference's own answer moves under a one-ulp input change)
+    bad = [(k, parity.compare_one(res[k], ref.get(k))) for k in sorted(stored)
+           if not parity.passes(parity.compare_one(res[k], ref.get(k))) and not cert.get((4, k), {}).get("unstable")]
     assert not bad, bad[:4]

@@ -17,7 +17,7 @@ def test_sliced_batches_equal_uninterrupted_batches(slice_ms, wgs):
     from vanishing_points_2017_amd.runtime import get_runtime
     rt = get_runtime(0, "slice%d" % wgs)
     rt.handle.em_set_workgroups(wgs)
-    scenes = list(synth.config_scenes(2, count=60, start=40)) + [next(synth.config_scenes(2, count=1, start=86))]
+    scenes = list(synth.config_scenes(2, count=60, start=40)) + [next(synth.config_scenes(2, count=1, start=12))]
     p = gem._params({})
     d = gem.upload_batch(rt, scenes)
     l0 = d["l"].clone()
@@ -55,7 +55,7 @@ def test_layout_change_while_images_are_parked_is_refused():
     from vanishing_points_2017_amd import _lib, em as gem, synth
     from vanishing_points_2017_amd.runtime import get_runtime
     rt = get_runtime(0, "slice_guard")
-    small = [next(synth.config_scenes(2, count=1, start=86))]
+    small = [next(synth.config_scenes(2, count=1, start=12))]
     big = [synth.make_scene(9, 700, 3)]
     p = gem._params({})
     rt.handle.em_set_time_slice(0.05, 0)
@@ -85,7 +85,7 @@ def test_full_parked_lists_make_images_run_on_instead_of_overflowing(monkeypatch
     monkeypatch.delenv("VPK_EM_WAIT_CAP")
     monkeypatch.delenv("VPK_EM_STARTED_CAP")
     rt.handle.em_set_workgroups(6)
-    scenes = list(synth.config_scenes(2, count=39, start=10)) + [next(synth.config_scenes(2, count=1, start=86))]
+    scenes = list(synth.config_scenes(2, count=39, start=10)) + [next(synth.config_scenes(2, count=1, start=12))]
     p = gem._params({})
     d = gem.upload_batch(rt, scenes)
     l0 = d["l"].clone()

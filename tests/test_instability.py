@@ -1,75 +1,59 @@
-"""Why configs[1] scene 86 is exempt from the bit-exact bar (tests/test_gpu_full_configs.py: UNSTABLE).
+"""What the instability certificates (tests/golden/instability.npz, oracle/make_instability_certificates.py) stand for,
+checked with the CPU oracle.
 
-The EM of that image never converges (99 iterations).  With the per-VP variance clamped to [1e-200, 1e-6]
-(vp_localisation.py:306-307) one iteration amplifies a perturbation of a VP, and over 99 iterations a ONE-ulp
-change of ONE input coordinate moves the final VPs by 1e-5 .. 1e-2 and flips line->VP assignments -- in the
-CPU oracle here, and in the reference itself (oracle/ref_instability.py, numbers in DESIGN.md section 4).
-An implementation whose exp/acos/asin differ from glibc's in the last bit (ocml on the GPU) is such a
-perturbation.  The control scene converges in a few iterations and does not move at all."""
+An image gets a certificate when the REFERENCE's own result on it moves by more than the parity bar (VPs 1e-4, any
+assignment, the iteration or VP count) after ONE input coordinate moved by ONE ulp.  Such an image has no answer to compare
+to the last bit: an implementation whose exp / acos / asin differ from NumPy's in the last bit of a few per cent of their
+arguments (tests/test_gpu_math.py measures the device's) is such a perturbation.  With the reference's own rasters (round 4)
+the configs hold one such image among 270: configs[3] image 1612 (861 lines, never converges, nine splits).
+
+The tests here show the two halves of the argument on the oracle: the certified image moves under one-ulp changes -- and
+long runs as such do NOT: configs[1] image 12 also runs the full 99 iterations (an oscillation between two states) and
+reproduces to 1e-14 under the same perturbations, as does an image that converges in a few iterations."""
 import numpy as np
+import pytest
 
 from golden_util import cpu_rasters
 from oracle import em_numpy as em
-from vanishing_points_2017_amd import synth
+from vanishing_points_2017_amd import parity, synth
 
 
-def _spread(idx, trials):
-    sc = cpu_rasters(synth.config_scenes(2, count=1, start=idx))[0]
+def _spread(cfg, idx, trials):
+    sc = cpu_rasters(synth.config_scenes(cfg, count=1, start=idx))[0]
 
     def run(lp):
         return em.expectation_maximisation(sc["l"].copy(), lp.copy(), sc["cnn_response"].copy(),
                                            sphere_image=sc["sphere_image"])
     base = run(sc["lp"])
-    rs = np.random.RandomState(0)
-    moved, flipped = [], []
+    rs = np.random.RandomState(idx)
+    moved, flipped, same_shape = [], [], []
     for t in range(trials):
         lp = sc["lp"].copy()
         i, j = rs.randint(lp.shape[0]), rs.randint(4)
         lp[i, j] = np.nextafter(lp[i, j], 10.0 if t % 2 else -10.0)
         r = run(lp)
-        assert r["vp"].shape == base["vp"].shape
-        moved.append(np.abs(r["vp"] - base["vp"]).max())
+        ok = r["vp"].shape == base["vp"].shape and r["iterations"] == base["iterations"]
+        same_shape.append(ok)
+        moved.append(np.abs(r["vp"] - base["vp"]).max() if ok else np.inf)
         flipped.append(int((r["vp_assoc"] != base["vp_assoc"]).sum()))
-    return base, moved, flipped
+    return base, moved, flipped, same_shape
 
 
-def test_scene_86_is_unstable_under_one_ulp_input_changes():
-    base, moved, flipped = _spread(86, 6)
-    assert base["iterations"] == 99
-    assert max(moved) > 1e-4          # beyond the VP-direction bar of BASELINE.json
-    assert max(flipped) >= 1          # and assignments flip
-
-
-def test_a_converging_scene_is_stable():
-    base, moved, flipped = _spread(0, 3)
-    assert base["iterations"] < 20
+def test_a_run_of_99_iterations_is_not_unstable_as_such():
+    base, moved, flipped, same = _spread(2, 12, 3)
+    assert base["iterations"] == 99 and all(same)
     assert max(moved) < 1e-9 and max(flipped) == 0
 
 
-def test_a_collapsed_vp_makes_a_converging_scene_unstable_too():
-    """configs[3]-shape image 2062 (found by scripts/sweep_fresh.py): 8 iterations, but one VP hypothesis collapses onto
-    two nearly collinear segments, so 1 - |cos| between it and those lines is exactly 0 or one ulp, its variance sits at
-    the 1e-200 floor or at 1e-32, and the whole weight distribution of the following iterations depends on that bit.  One
-    ulp on ONE coordinate of the line it sits on moves the final VPs by 2.4e-3 -- in the oracle here and, identically,
-    in the reference itself (tests/golden/unstable_c4_2062.npz, oracle/make_unstable_golden.py); one ulp elsewhere moves
-    nothing.  The HIP path lands on the perturbed member of this family (tests/test_gpu_full_configs.py)."""
-    import os
-    sc = cpu_rasters(synth.config_scenes(4, count=1, start=2062))[0]
+def test_a_converging_scene_is_stable():
+    base, moved, flipped, same = _spread(2, 0, 2)
+    assert base["iterations"] < 20 and all(same)
+    assert max(moved) < 1e-9 and max(flipped) == 0
 
-    def run(lp):
-        return em.expectation_maximisation(sc["l"].copy(), lp.copy(), sc["cnn_response"].copy(),
-                                           sphere_image=sc["sphere_image"])
-    base = run(sc["lp"])
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unstable_c4_2062.npz"))
-    assert base["iterations"] == int(g["iterations"]) == 8
-    assert np.array_equal(base["vp_assoc"], g["vp_assoc"]) and np.abs(base["vp"] - g["vp"]).max() <= 1e-9
-    line, coord, sign = [int(v) for v in g["perturbed"]]
-    q = sc["lp"].copy()
-    q[line, coord] = np.nextafter(q[line, coord], 10.0 * sign)
-    moved = run(q)
-    assert np.array_equal(moved["vp_assoc"], base["vp_assoc"])
-    assert 1e-4 < np.abs(moved["vp"] - base["vp"]).max() < 5e-3
-    assert np.abs(moved["vp"] - g["vp_perturbed"]).max() <= 1e-9        # the reference moves to the same place
-    q = sc["lp"].copy()
-    q[40, 1] = np.nextafter(q[40, 1], 10.0)
-    assert np.abs(run(q)["vp"] - base["vp"]).max() < 1e-9                 # any other line: nothing
+
+@pytest.mark.slow
+def test_the_certified_image_moves_under_one_ulp_input_changes():
+    cert = parity.instability_certificates()
+    assert cert.get((4, 1612), {}).get("unstable"), "tests/golden/instability.npz lacks the certificate of configs[3] image 1612"
+    base, moved, flipped, same = _spread(4, 1612, 2)
+    assert (not all(same)) or max(moved) > 1e-4 or max(flipped) >= 1      # the oracle, like the reference, has no stable answer here

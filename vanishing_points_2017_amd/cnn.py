@@ -84,6 +84,10 @@ class Net(object):
         """conv1 + norm1 + pool1 as one kernel (default) or as separate kernels."""
         self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
+    def set_algorithm(self, mode):
+        """conv3..5: 0 = direct implicit GEMM, 1 = Winograd F(2 x 2, 3 x 3) (include/vpk.h: vpk_cnn_set_algorithm)."""
+        self.rt.check(self.rt.lib.vpk_cnn_set_algorithm(self.rt.h, int(mode)))
+
     def set_precision(self, mode):
         """0 = native f32 matrix instructions; 1 = conv2..5 as six bf16 matrix products per f32 product (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_precision(self.rt.h, int(mode)))

@@ -954,6 +954,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 #include "cnn_split_gemm.hpp"
+#include "cnn_winograd.hpp"
 
 struct Layer {
     ConvDims d;
@@ -962,6 +963,8 @@ struct Layer {
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
     SplitDims sd;
+    float* wino = nullptr;      // conv3..5: G g G^T in the chunk order of conv3x3_winograd_kernel (cnn_winograd.hpp)
+    WinoDims wd;
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -979,6 +982,7 @@ struct vpk_cnn_state {
     // optional per-layer timing (HIP events on the handle's stream)
     int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
+    int algorithm = 1;       // vpk_cnn_set_algorithm: 1 (default) = conv3..5 by Winograd F(2 x 2, 3 x 3) (native precision only)
     int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
     bool profiling = false;
     static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
@@ -995,6 +999,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.bias) (void)hipFree(l.bias);
         if (l.ktab) (void)hipFree(l.ktab);
         if (l.wsplit) (void)hipFree(l.wsplit);
+        if (l.wino) (void)hipFree(l.wino);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
@@ -1190,7 +1195,16 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
             else go(conv_gemm_split_kernel<2, 4, 2, 3, 2, false>, 4, 512, 1);
         }
     };
+    auto conv_wino = [&](int li, const float* src, float* dst) {      // conv3 / conv4 / conv5 by Winograd F(2 x 2, 3 x 3)
+        WinoDims wd = S->L[li].wd;
+        wd.tiles = batch * WG_TILES_PER_IMAGE;
+        const int total = wd.groups * wd.ocblocks * ((wd.tiles + WG_TB - 1) / WG_TB);
+        hipLaunchKernelGGL(conv3x3_winograd_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(WG_THREADS), 0, st, wd, src,
+                           S->L[li].wino, S->L[li].bias, dst, ctr + li, total);
+    };
+    const bool wino = S->precision == 0 && S->algorithm == 1;
     auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
+        if (wino && li >= 2) return conv_wino(li, src, dst);
         if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
@@ -1217,6 +1231,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
     if (chain) conv_split(3, nullptr, s4, s5, true);
     else if (S->precision == 1) conv_split(3, R[R_CONV3], nullptr, R[R_CONV4], false);
+    else if (wino) conv_wino(3, R[R_CONV3], R[R_CONV4]);
     else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
@@ -1274,6 +1289,13 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
 int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
     h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 2 ? 1 : on);
+    return VPK_OK;
+}
+
+int vpk_cnn_set_algorithm(vpk_handle* h, int mode) {
+    if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_algorithm before vpk_cnn_load");
+    if (mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 or 1");
+    h->cnn->algorithm = mode;
     return VPK_OK;
 }
 
@@ -1393,6 +1415,15 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                             }
             VPK_HIP(h, hipMalloc((void**)&l.wsplit, pk.size() * sizeof(unsigned short)));
             VPK_HIP(h, hipMemcpy(l.wsplit, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
+        if (li >= 2 && li <= 4) {   // G g G^T of every 3 x 3 filter, in the order conv3x3_winograd_kernel streams it
+            std::vector<float> u;
+            winograd_weights(blobs[2 * li], t.G, t.OC, t.IC, u);
+            VPK_HIP(h, hipMalloc((void**)&l.wino, u.size() * sizeof(float)));
+            VPK_HIP(h, hipMemcpy(l.wino, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+            WinoDims& wd = l.wd;
+            wd.IC = t.IC; wd.OC = t.OC; wd.groups = t.G; wd.ctot_in = t.IC * t.G; wd.ctot_out = t.OC * t.G; wd.tiles = 0;
+            wd.ocblocks = t.OC / WG_OCB; wd.chunks = t.IC / WG_KC; wd.OHp = d.OHp; wd.OWp = d.OWp; wd.opad = d.opad; wd.relu = 1;
         }
         VPK_HIP(h, hipMalloc((void**)&l.bias, (size_t)t.G * t.OC * sizeof(float)));
         VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
