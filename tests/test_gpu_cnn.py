@@ -167,11 +167,11 @@ def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_
 
 
 def test_winograd_convolutions_against_the_float64_net():
-    """vpk_cnn_set_algorithm(1): conv3..5 by Winograd F(2 x 2, 3 x 3) on the f32 matrix cores (cnn_winograd.hpp).  Direct and
-    Winograd paths are measured against the SAME net evaluated in float64 (B = 3 and an odd batch of 7 whose 1 575 tiles
-    end inside a workgroup's block of 64): at conv3 / conv4 / conv5 / fc6 and at the output the Winograd path's error must
-    stay within the bar of every other CNN test (2e-5 of the blob's scale at the taps, 2e-5 at the output) and within a
-    small factor of the direct path's own rounding noise."""
+    """vpk_cnn_set_algorithm(1), the default: conv2 by Winograd F(2 x 2, 5 x 5) and conv3..5 by F(2 x 2, 3 x 3) on the f32 matrix
+    cores (cnn_winograd.hpp).  Direct and Winograd paths are measured against the SAME net evaluated in float64 (B = 3 and
+    an odd batch of 7 whose tiles end inside a workgroup's block): at conv2 / pool2 / conv3 / conv4 / conv5 / fc6 and at
+    the output the Winograd path's error must stay within the bar of every other CNN test (2e-5 of the blob's scale at
+    the taps, 2e-5 at the output) and within a small factor of the direct path's own rounding noise."""
     from oracle import cnn_torch
     from vanishing_points_2017_amd import cnn, sphere_mapping, synth
     w = cnn.synthetic_weights(0)
@@ -182,7 +182,7 @@ def test_winograd_convolutions_against_the_float64_net():
         for batch in (3, 7):
             sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=batch, start=10)])
             ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
-            for tap in (4, 5, 6, 8):                               # conv3, conv4, conv5, fc6
+            for tap in (2, 3, 4, 5, 6, 8):                         # conv2, pool2, conv3, conv4, conv5, fc6
                 want = taps[cnn_torch.TAPS[tap]]
                 err = []
                 for mode in (0, 1):

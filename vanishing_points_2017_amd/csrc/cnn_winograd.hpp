@@ -246,5 +246,249 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv2 (deploy.prototxt:56-75: 5 x 5, stride 1, pad 2, two groups of 48 -> 128 channels, 61 x 61 planes) by F(2 x 2, 5 x 5):
+// 36 instead of 100 products per 2 x 2 outputs and input channel.  Interpolation points 0, 1, -1, 2, -1/2, infinity; the rows
+// of B^T are scaled to small integers (the inverse factors go into G, applied in float64 at load), so the input transform is
+// exact multiplications and rounded additions:
+//     B^T = [ 2  3 -4 -3  2  0 ]    G = diag(1/2, 1/6, 1/6, 1/30, 16/15, 1/2) . [ 1    0    0    0     0   ]    A^T = [ 1  1  1  1   1   0 ]
+//           [ 0  2  5  1 -2  0 ]                                                [ 1    1    1    1     1   ]          [ 0  1 -1  2 -1/2  1 ]
+//           [ 0  2  1 -5  2  0 ]                                                [ 1   -1    1   -1     1   ]
+//           [ 0 -1 -2  1  2  0 ]                                                [ 1    2    4    8    16   ]
+//           [ 0 -2  1  2 -1  0 ]                                                [ 1  -1/2  1/4 -1/8  1/16  ]
+//           [ 0  2  3 -4 -3  2 ]                                                [ 0    0    0    0     1   ]
+// (f32 error against float64, measured in NumPy on this layer's data before the kernel was written: 7e-7 of the blob's
+// scale, the direct f32 sum over K = 1200: 8e-7.)  Same structure as the 3 x 3 kernel above with other sizes: 768 threads
+// (twelve waves: three of the 36 positions each), 64 output channels x 32 tiles per workgroup tile, chunks of 4 input
+// channels (U of a chunk = 36 KB by LDS-DMA).  The 6 x 6 input transform is done by ALL threads in two passes -- columns
+// (B^T d, straight from the loaded patch column), rows ((.) B) through an 18 KB LDS scratch -- because VALU work and f32
+// MFMAs of one SIMD do not overlap: a transform left to a few waves would make their SIMDs the stragglers.  The last
+// tile row / column (outputs 60, "61") reads input rows / columns up to 65 of a 65-pixel plane: the index is clamped to
+// 64, which IS the zero border the missing pixel would hold.
+constexpr int W5_THREADS = 768;
+constexpr int W5_TB = 32;            // tiles per workgroup tile
+constexpr int W5_OCB = 64;
+constexpr int W5_KC = 4;
+constexpr int W5_P = 36;
+constexpr int W5_TPI = 31 * 31;      // tiles per image (61 x 61 outputs)
+constexpr int W5_PLANE = 65 * 65;
+
+// U[g][oc block][chunk][p][kc][64] for conv2 (host, at load; float64, rounded once)
+inline void winograd5_weights(const float* w, int G, int OC, int IC, std::vector<float>& out) {
+    static const double sc[6] = {0.5, 1.0 / 6, 1.0 / 6, 1.0 / 30, 16.0 / 15, 0.5};
+    static const double E[6][5] = {{1, 0, 0, 0, 0}, {1, 1, 1, 1, 1}, {1, -1, 1, -1, 1}, {1, 2, 4, 8, 16},
+                                   {1, -0.5, 0.25, -0.125, 0.0625}, {0, 0, 0, 0, 1}};
+    const int ocb = OC / W5_OCB, chunks = IC / W5_KC;
+    out.assign((size_t)G * OC * IC * W5_P, 0.f);
+    for (int g = 0; g < G; ++g)
+        for (int oc = 0; oc < OC; ++oc)
+            for (int ic = 0; ic < IC; ++ic) {
+                const float* k = w + ((size_t)(g * OC + oc) * IC + ic) * 25;
+                double t[6][5];
+                for (int i = 0; i < 6; ++i)
+                    for (int c = 0; c < 5; ++c) {
+                        double a = 0;
+                        for (int r = 0; r < 5; ++r) a += sc[i] * E[i][r] * k[r * 5 + c];
+                        t[i][c] = a;
+                    }
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double u = 0;
+                        for (int c = 0; c < 5; ++c) u += t[i][c] * sc[j] * E[j][c];
+                        const size_t at = (((((size_t)g * ocb + oc / W5_OCB) * chunks + ic / W5_KC) * W5_P + (i * 6 + j)) * W5_KC +
+                                           ic % W5_KC) * W5_OCB + oc % W5_OCB;
+                        out[at] = (float)u;
+                    }
+            }
+}
+
+// B^T x for one vector of six
+__device__ __forceinline__ void w5_bt(const float (&x)[6], float (&o)[6]) {
+    o[0] = 2.f * x[0] + 3.f * x[1] - 4.f * x[2] - 3.f * x[3] + 2.f * x[4];
+    o[1] = 2.f * x[1] + 5.f * x[2] + x[3] - 2.f * x[4];
+    o[2] = 2.f * x[1] + x[2] - 5.f * x[3] + 2.f * x[4];
+    o[3] = -x[1] - 2.f * x[2] + x[3] + 2.f * x[4];
+    o[4] = -2.f * x[1] + x[2] + 2.f * x[3] - x[4];
+    o[5] = 2.f * x[1] + 3.f * x[2] - 4.f * x[3] - 3.f * x[4] + 2.f * x[5];
+}
+
+struct Wino5Dims {
+    int IC, OC, groups, ctot_in, ctot_out;
+    int tiles;                       // B * 961
+    int ocblocks, chunks;
+    int relu;
+};
+
+__global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Dims d, const float* __restrict__ in,
+                                                                         const float* __restrict__ U,
+                                                                         const float* __restrict__ bias,
+                                                                         float* __restrict__ out, int* __restrict__ tile_counter,
+                                                                         int total_tiles) {
+    __shared__ __attribute__((aligned(16))) float Us[2][W5_P][W5_KC][W5_OCB];    // 72 KB
+    __shared__ __attribute__((aligned(16))) float Vs[2][W5_P][W5_KC][W5_TB];     // 36 KB
+    __shared__ __attribute__((aligned(16))) float Ss[W5_KC][6][6][W5_TB];        // 18 KB: B^T d of the next chunk, [channel][i][column][tile]
+    float (*Ms)[16][W5_TB] = reinterpret_cast<float (*)[16][W5_TB]>(&Us[0][0][0][0]);   // epilogue: [p][row][tile] = 72 KB over Us
+    __shared__ int s_next;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int tc = wave % 6, th = wave / 6;             // transform role: column / row tc, channels 2 th and 2 th + 1
+    const int tch = 2 * th + khalf;                     // this lane's channel of the chunk (tile = l31)
+    const unsigned us_base = lds_addr(&Us[0][0][0][0]);
+    const int nblocks = (d.tiles + W5_TB - 1) / W5_TB;
+    for (int tile = blockIdx.x; tile < total_tiles;) {
+        if (tid == 0) s_next = atomicAdd(tile_counter, 1) + (int)gridDim.x;     // read after the K loop's barriers
+        int t = tile;
+        const int ob = t % d.ocblocks; t /= d.ocblocks;
+        const int tb = t % nblocks;
+        const int g = t / nblocks;
+        const int n_raw = tb * W5_TB + l31;
+        const bool n_ok = n_raw < d.tiles;
+        const int n = n_ok ? n_raw : d.tiles - 1;
+        const int b = n / W5_TPI, rr0 = n - b * W5_TPI;
+        const int ty = rr0 / 31, tx = rr0 - ty * 31;
+        const int b_first = (tb * W5_TB) / W5_TPI;
+        const float* in_base = in + ((size_t)b_first * d.ctot_in + (size_t)g * d.IC) * W5_PLANE;
+        unsigned doff[6];                               // byte offsets of this lane's patch column tc, rows 0..5 (clamped into the plane)
+        {
+            const int col = 2 * tx + tc < 64 ? 2 * tx + tc : 64;
+            const unsigned base = (unsigned)(((b - b_first) * d.ctot_in + tch) * W5_PLANE + col);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int row = 2 * ty + r < 64 ? 2 * ty + r : 64;
+                doff[r] = (base + (unsigned)(row * 65)) * 4u;
+            }
+        }
+        const float* u_base = U + ((size_t)(g * d.ocblocks + ob) * d.chunks) * (W5_P * W5_KC * W5_OCB);
+        float dcol[6];                                  // the patch column of the chunk after next
+        auto fetch = [&](int c) {
+            const char* p = (const char*)(in_base + (size_t)c * W5_KC * W5_PLANE);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) dcol[r] = *(const float*)(p + doff[r]);
+        };
+        auto pass1 = [&]() {                            // column tc of B^T d -> Ss[channel][i][tc][tile]
+            float o[6];
+            w5_bt(dcol, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Ss[tch][i][tc][l31] = o[i];
+        };
+        auto pass2 = [&](int buf) {                     // row tc of (B^T d) B -> Vs[buf][6 tc + j][channel][tile]
+            float x[6], o[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[c] = Ss[tch][tc][c][l31];
+            w5_bt(x, o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Vs[buf][6 * tc + j][tch][l31] = o[j];
+        };
+        auto issue_u = [&](int c, int buf) {            // 36 KB = 36 pieces of 1 KB: wave w moves pieces w, w + 12, w + 24
+            const float* src = u_base + (size_t)c * (W5_P * W5_KC * W5_OCB);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int piece = wave + 12 * q;
+                dma16((unsigned)lane * 16u, src + piece * 256,
+                      __builtin_amdgcn_readfirstlane(us_base + (unsigned)((buf * W5_P * W5_KC * W5_OCB + piece * 256) * 4)));
+            }
+        };
+        f32x16 acc[3][2];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][i][r] = 0.f;
+
+        issue_u(0, 0);
+        fetch(0);
+        pass1();
+        if (d.chunks > 1) fetch(1);
+        __syncthreads();
+        pass2(0);
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (int c = 0; c < d.chunks; ++c) {
+            const int buf = c & 1;
+            const bool more = c + 1 < d.chunks;
+            if (more) { issue_u(c + 1, buf ^ 1); pass1(); }     // (dcol holds chunk c + 1)
+            if (c + 2 < d.chunks) fetch(c + 2);
+            float af[2][3][2], bf[2][3];
+            auto operands = [&](int k2) {
+                const int o = (k2 >> 1) & 1;
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const int p = 3 * wave + pp;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[o][pp][i] = Us[buf][p][k2 + khalf][i * 32 + l31];
+                    bf[o][pp] = Vs[buf][p][k2 + khalf][l31];
+                }
+            };
+            operands(0);
+#pragma unroll
+            for (int k2 = 0; k2 < W5_KC; k2 += 2) {
+                if (k2 + 2 < W5_KC) operands(k2 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int o = (k2 >> 1) & 1;
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[pp][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[o][pp][i], bf[o][pp], acc[pp][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Ss is complete (LDS only: the DMA and the loads stay in flight)
+            if (more) pass2(buf ^ 1);
+            wait_vmcnt<0>();                            // the next chunk's U has landed (own pieces) ...
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... for every wave; this chunk's buffers are free
+        }
+
+        // ---- epilogue: Y = A^T M A per (output channel, tile), a quarter of the rows at a time through LDS ----
+        const int row = tid >> 5;                       // threads 0..511: (row 0..15, tile l31)
+        const bool last_y = 2 * ty + 1 >= 61, last_x = 2 * tx + 1 >= 61;
+        float* obase = out + ((size_t)b * d.ctot_out + (size_t)g * d.OC + (size_t)ob * W5_OCB) * 3721 + (size_t)(2 * ty) * 61 + 2 * tx;
+        const float* bbase = bias + g * d.OC + ob * W5_OCB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ms[3 * wave + pp][i * 8 + 4 * khalf + e][l31] = acc[pp][i][4 * r + e];
+            __syncthreads();
+            if (tid < 512) {
+                float s[6][2];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    float m[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) m[q] = Ms[6 * a + q][row][l31];
+                    s[a][0] = m[0] + m[1] + m[2] + m[3] + m[4];
+                    s[a][1] = m[1] - m[2] + 2.f * m[3] - 0.5f * m[4] + m[5];
+                }
+                const int ocl = (row >> 3) * 32 + 8 * r + (row & 7);
+                const float bv = bbase[ocl];
+                float y[2][2];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    y[0][cc] = s[0][cc] + s[1][cc] + s[2][cc] + s[3][cc] + s[4][cc] + bv;
+                    y[1][cc] = s[1][cc] - s[2][cc] + 2.f * s[3][cc] - 0.5f * s[4][cc] + s[5][cc] + bv;
+                }
+                if (n_ok) {
+                    float* o = obase + (size_t)ocl * 3721;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            float v = y[dy][dx];
+                            if (d.relu) v = v > 0.f ? v : 0.f;
+                            if (!(dy && last_y) && !(dx && last_x)) o[dy * 61 + dx] = v;
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        tile = __builtin_amdgcn_readfirstlane(s_next);
+    }
+}
+
 }  // namespace
 #endif

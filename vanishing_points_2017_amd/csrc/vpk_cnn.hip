@@ -963,8 +963,9 @@ struct Layer {
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
     SplitDims sd;
-    float* wino = nullptr;      // conv3..5: G g G^T in the chunk order of conv3x3_winograd_kernel (cnn_winograd.hpp)
+    float* wino = nullptr;      // conv2..5: G g G^T in the chunk order of the Winograd kernels (cnn_winograd.hpp)
     WinoDims wd;
+    Wino5Dims wd5;
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -1205,6 +1206,14 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     const bool wino = S->precision == 0 && S->algorithm == 1;
     auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
         if (wino && li >= 2) return conv_wino(li, src, dst);
+        if (wino && li == 1) {                                        // conv2 by F(2 x 2, 5 x 5)
+            Wino5Dims w5 = S->L[1].wd5;
+            w5.tiles = batch * W5_TPI;
+            const int total = w5.groups * w5.ocblocks * ((w5.tiles + W5_TB - 1) / W5_TB);
+            hipLaunchKernelGGL(conv5x5_winograd_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(W5_THREADS), 0, st, w5, src,
+                               S->L[1].wino, S->L[1].bias, dst, ctr + 1, total);
+            return;
+        }
         if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
@@ -1415,6 +1424,15 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                             }
             VPK_HIP(h, hipMalloc((void**)&l.wsplit, pk.size() * sizeof(unsigned short)));
             VPK_HIP(h, hipMemcpy(l.wsplit, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
+        if (li == 1) {              // conv2: G g G^T of every 5 x 5 filter (F(2 x 2, 5 x 5))
+            std::vector<float> u;
+            winograd5_weights(blobs[2], t.G, t.OC, t.IC, u);
+            VPK_HIP(h, hipMalloc((void**)&l.wino, u.size() * sizeof(float)));
+            VPK_HIP(h, hipMemcpy(l.wino, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+            Wino5Dims& w5 = l.wd5;
+            w5.IC = t.IC; w5.OC = t.OC; w5.groups = t.G; w5.ctot_in = t.IC * t.G; w5.ctot_out = t.OC * t.G; w5.tiles = 0;
+            w5.ocblocks = t.OC / W5_OCB; w5.chunks = t.IC / W5_KC; w5.relu = 1;
         }
         if (li >= 2 && li <= 4) {   // G g G^T of every 3 x 3 filter, in the order conv3x3_winograd_kernel streams it
             std::vector<float> u;
