@@ -731,7 +731,6 @@ def run_workload(args, dist, rank, local_rank, world):
         key = "yud_102" if (args.workload == "yud" and count == 102) else (
             "stress_512x1000x8x50" if (args.workload == "stress" and count == 512) else None)
         t = traffic.get(key) if key else None
-        tc = traffic.get(key + "_conv") if key else None
         roof_em = {"kernel": "em_batch_kernel", "bound": "hbm", "achieved": b_em / (em_ms * 1e-3) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "traffic": (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None, "traffic_source": traffic_src,
@@ -741,14 +740,30 @@ def run_workload(args, dist, rank, local_rank, world):
                            "unit takes I = 50, this run's is 54) / mean kernel time of the timed steps, measured on overlapped streams; "
                            "traffic = HBM bytes per launch from the PMC passes"}
         name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])   # the layer with the most arithmetic (conv2)
-        flop = cnn.Net.LAYER_FLOP[name] * count
-        roof_cnn = {"kernel": "conv_gemm_dma_kernel(%s)" % name, "bound": "mfma",
+        flop = cnn.Net.LAYER_FLOP[name] * count          # ALGORITHMIC flops of the layer: 2 x MACs of the direct convolution
+        wino = args.cnn_algorithm == 1 and args.cnn_precision == 0
+        kname = "conv5x5_winograd_kernel" if wino else "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0"
+        roof_cnn = {"kernel": "%s(%s)" % ("conv5x5_winograd_kernel" if wino else "conv_gemm_dma_kernel<2,2,2,2>", name), "bound": "mfma",
                     "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
-                    "traffic": (tc["hbm_read_bytes"] + tc["hbm_write_bytes"]) if tc else None,
-                    "traffic_note": "HBM bytes per launch, average over the conv2/conv3/conv5 launches of this kernel",
-                    "note": "achieved = the layer's flops / its mean duration over the timed steps (HIP events on the CNN stream, "
-                            "%d passes), i.e. with whatever ran beside it" % layer_passes}
+                    "traffic": None,
+                    "note": "achieved = the layer's algorithmic flops (2 x MACs of the direct convolution, SURVEY 8d) / its mean "
+                            "duration over the timed steps (HIP events on the CNN stream, %d passes), i.e. with whatever ran "
+                            "beside it" % layer_passes}
+        if wino:
+            # F(2 x 2, 5 x 5): 36 matrix-core products stand for 100 of the direct form.  What the matrix pipe executes is
+            # 0.36 x the algorithmic count; the rest of the kernel's time is the 6 x 6 transforms (VALU, which f32 MFMAs do
+            # not overlap with on a SIMD) and the output transform through LDS
+            roof_cnn["matrix_core_tflops"] = 0.36 * roof_cnn["achieved"]
+            roof_cnn["matrix_core_frac"] = 0.36 * roof_cnn["achieved"] / MFMA_F32_PEAK_TFLOPS
+            roof_cnn["note"] += ("; Winograd F(2x2,5x5): the matrix cores execute 36/100 of the algorithmic products "
+                                 "(matrix_core_tflops = what they actually deliver), so `frac` is the direct-equivalent rate "
+                                 "against the f32-MFMA peak and may pass 1")
+        tkey = (key + ("_conv2w" if wino else "_conv")) if key else None
+        tc = traffic.get(tkey) if tkey else None
+        if tc:
+            roof_cnn["traffic"] = tc["hbm_read_bytes"] + tc["hbm_write_bytes"]
+            roof_cnn["traffic_note"] = "HBM bytes per launch of this kernel (--pmc FETCH_SIZE / WRITE_SIZE passes)"
         if args.cnn_precision == 1:     # conv2 on the bf16 matrix cores: six bf16 MFMA products per f32 product
             roof_cnn.update({"kernel": "conv_gemm_split_kernel(%s)" % name, "achieved": 6.0 * roof_cnn["achieved"],
                              "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None,
@@ -757,8 +772,12 @@ def run_workload(args, dist, rank, local_rank, world):
                                      "here includes the split pass of the layer's input (split_nhwc_kernel)"})
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
         roof_cnn["traffic_source"] = traffic_src
-        pm = (mfma.get("bench_yud_102") or {}).get("conv_gemm_dma<2,2,2,2> (conv2/3/5)") if args.workload == "yud" else None
-        if pm and args.cnn_precision == 0:
+        pm = None
+        if args.workload == "yud" and args.cnn_precision == 0:
+            for k_, v_ in (mfma.get("bench_yud_102") or {}).items():
+                if ("winograd5" in k_ or "conv5x5" in k_) if wino else ("conv_gemm_dma<2,2,2,2>" in k_):
+                    pm = v_
+        if pm:
             # Counter view of this kernel from the --pmc pass of the bench command.  A --pmc pass SERIALISES dispatches: the
             # kernel ran with nothing beside it, so this is the kernel alone at the clock the run's power state gave it --
             # matrix-pipe busy fraction and shader clock (the 157.3 TF peak assumes 2.4 GHz) -- and says nothing about
@@ -773,13 +792,13 @@ def run_workload(args, dist, rank, local_rank, world):
         if traces and count == 102 and args.cnn_precision == 0:
             try:
                 rows = list(csv.DictReader(open(traces[-1])))
-                avg_us = [float(r["AverageUs"]) for r in rows if "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0" in r["Name"]]
+                avg_us = [float(r["AverageUs"]) for r in rows if kname in r["Name"]]
                 if avg_us:
-                    flop3 = sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
-                    roof_cnn["alone"] = {"achieved": flop3 / (avg_us[0] * 1e-6) / 1e12, "unit": "TFLOP/s",
-                                         "frac": flop3 / (avg_us[0] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    fl = flop if wino else sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
+                    roof_cnn["alone"] = {"achieved": fl / (avg_us[0] * 1e-6) / 1e12, "unit": "TFLOP/s",
+                                         "frac": fl / (avg_us[0] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                          "source": os.path.relpath(traces[-1], ROOT),
-                                         "note": "average launch of the kernel (conv2 / conv3 / conv5) in the kernel trace of the CNN alone"}
+                                         "note": "average launch of the kernel in the kernel trace of the CNN alone"}
             except (OSError, ValueError, KeyError):
                 pass
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step, each EM

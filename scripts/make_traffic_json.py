@@ -44,13 +44,16 @@ def main(prof, out):
     for key, tag in (("yud_102", "yud"), ("stress_512x1000x8x50", "stress")):
         f = per_kernel(first_db(os.path.join(prof, tag + "_fetch")))
         w = per_kernel(first_db(os.path.join(prof, tag + "_write")))
-        for kname, short in (("em_batch_kernel", ""), ("conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0", "_conv")):
+        for kname, short in (("em_batch_kernel", ""), ("conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0", "_conv"),
+                             ("conv5x5_winograd_kernel", "_conv2w"), ("conv3x3_winograd_kernel", "_conv3w")):
             fk = [k for k in f if kname in k]
             wk = [k for k in w if kname in k]
             if not fk or not wk:
                 continue
             fs, ws = f[fk[0]].get("FETCH_SIZE", 0.0), w[wk[0]].get("WRITE_SIZE", 0.0)
-            res[key + short] = {"kernel": kname if not short else "conv_gemm_dma_kernel<2,2,2,2,false> (avg of conv2/3/5)",
+            res[key + short] = {"kernel": {"": kname, "_conv": "conv_gemm_dma_kernel<2,2,2,2,false> (avg of its launches)",
+                                           "_conv2w": "conv5x5_winograd_kernel (conv2)",
+                                           "_conv3w": "conv3x3_winograd_kernel (avg of conv3/4/5)"}[short],
                                 "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws, "hbm_read_bytes": 2e3 * fs,
                                 "hbm_write_bytes": 1e3 * ws, "kernel_ms_profiled": f[fk[0]]["_ms"]}
     with open(out, "w") as fh:

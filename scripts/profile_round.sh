@@ -4,7 +4,7 @@
 # Summaries land in gpurun_out/prof/summary (copy them to profiles/).   ROUND=r03 bash scripts/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/prof
-N=${ROUND:-r03}
+N=${ROUND:-r04}
 rm -rf $R; mkdir -p $R/summary
 BENCH="python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_trace -o t -- $BENCH > $R/yud_trace.log 2>&1
@@ -15,6 +15,10 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- py
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --workload yud --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/stress_fetch -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/stress_write -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_write.log 2>&1
+# CNN alone with the direct convolutions everywhere (vpk_cnn_set_algorithm(0): rounds 1-3's default)
+export VPK_ALGORITHM=0
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_direct_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_direct_trace.log 2>&1
+export VPK_ALGORITHM=1
 # CNN alone with conv2..5 on the bf16 matrix cores (vpk_cnn_set_precision(1)) and the bench with that path
 export VPK_PRECISION=1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_split_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_split_trace.log 2>&1
@@ -24,16 +28,11 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- pytho
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/cnn_mfma -o t -- python3 scripts/time_cnn.py --passes 6 102 > $R/cnn_mfma.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/yud_mfma -o t -- python3 bench.py --workload yud --steps 4 --warmup 2 --no-cpu-baseline --no-alt > $R/yud_mfma.log 2>&1
-# the rasteriser alone: the bench's 102 line sets, three calls (scripts/time_raster.py 2); counters in two passes
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/raster_trace -o t -- python3 scripts/time_raster.py 2 > $R/raster_trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES -d $R/raster_pmc1 -o t -- python3 scripts/time_raster.py 2 > $R/raster_pmc1.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $R/raster_pmc2 -o t -- python3 scripts/time_raster.py 2 > $R/raster_pmc2.log 2>&1
-python3 scripts/rocpd_stats.py $(find $R/raster_trace -name '*.db' | head -1) $R/summary/${N}_raster_kernel_stats.csv > $R/summary/${N}_raster_top.txt
-for k in simplify outline coverage blend; do for q in raster_pmc1 raster_pmc2; do python3 scripts/rocpd_pmc.py $(find $R/$q -name '*.db' | head -1) $k; done; done > $R/summary/${N}_raster_pmc.txt 2>&1
 python3 scripts/rocpd_stats.py $(find $R/yud_trace -name '*.db' | head -1) $R/summary/${N}_yud_kernel_stats.csv > $R/summary/${N}_yud_top.txt
 python3 scripts/rocpd_stats.py $(find $R/stress_trace -name '*.db' | head -1) $R/summary/${N}_stress_kernel_stats.csv > $R/summary/${N}_stress_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_trace -name '*.db' | head -1) $R/summary/${N}_cnn_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_split_trace -name '*.db' | head -1) $R/summary/${N}_cnn_split_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_split_top.txt
+python3 scripts/rocpd_stats.py $(find $R/cnn_direct_trace -name '*.db' | head -1) $R/summary/${N}_cnn_direct_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_direct_top.txt
 python3 scripts/rocpd_stats.py $(find $R/yud_split_trace -name '*.db' | head -1) $R/summary/${N}_yud_split_kernel_stats.csv > $R/summary/${N}_yud_split_top.txt
 python3 scripts/make_traffic_json.py $R $R/summary/${N}_pmc_traffic.json > /dev/null
 python3 scripts/make_mfma_json.py $R $R/summary/${N}_pmc_mfma.json > /dev/null

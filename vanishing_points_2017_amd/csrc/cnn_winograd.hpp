@@ -260,13 +260,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
 // (f32 error against float64, measured in NumPy on this layer's data before the kernel was written: 7e-7 of the blob's
 // scale, the direct f32 sum over K = 1200: 8e-7.)  Same structure as the 3 x 3 kernel above with other sizes: 768 threads
 // (twelve waves: three of the 36 positions each), 64 output channels x 32 tiles per workgroup tile, chunks of 4 input
-// channels (U of a chunk = 36 KB by LDS-DMA).  The 6 x 6 input transform is done by ALL threads in two passes -- columns
-// (B^T d, straight from the loaded patch column), rows ((.) B) through an 18 KB LDS scratch -- because VALU work and f32
-// MFMAs of one SIMD do not overlap: a transform left to a few waves would make their SIMDs the stragglers.  The last
+// channels (U of a chunk = 36 KB by LDS-DMA).  The 6 x 6 input transform is done by ALL threads -- VALU work and f32 MFMAs
+// of one SIMD do not overlap, so a transform left to a few waves would make their SIMDs the stragglers -- in two passes:
+// columns (B^T d, straight from the loaded patch column), then rows ((.) B).  The six threads of a (tile, channel) pair
+// are six consecutive lanes of ONE wave (ten pairs per wave: 4 channels x 30 tiles = 120 pairs on twelve waves -- which
+// is why a workgroup tile has 30 tiles, two of the MFMA tile's 32 columns stay empty), so the hand-over between the
+// passes is a wave-private LDS exchange without a workgroup barrier and the K loop has ONE barrier per chunk (the first
+// version -- 32 tiles, passes on different waves, two barriers per chunk -- kept the matrix pipes busy 38 % of the time,
+// its waves waiting 43 % of their cycles: profiles/r04_pmc_mfma.json).  The last
 // tile row / column (outputs 60, "61") reads input rows / columns up to 65 of a 65-pixel plane: the index is clamped to
 // 64, which IS the zero border the missing pixel would hold.
 constexpr int W5_THREADS = 768;
-constexpr int W5_TB = 32;            // tiles per workgroup tile
+constexpr int W5_TB = 30;            // tiles per workgroup tile (of the 32 columns of an MFMA tile: see the transform's lane map)
+constexpr int W5_NB = 32;            // columns of the B operand
 constexpr int W5_OCB = 64;
 constexpr int W5_KC = 4;
 constexpr int W5_P = 36;
@@ -302,14 +308,16 @@ inline void winograd5_weights(const float* w, int G, int OC, int IC, std::vector
             }
 }
 
-// B^T x for one vector of six
+// B^T x for one vector of six, with the common differences shared (18 VALU operations instead of 26: the transform's
+// VALU time is a quarter of the kernel's)
 __device__ __forceinline__ void w5_bt(const float (&x)[6], float (&o)[6]) {
-    o[0] = 2.f * x[0] + 3.f * x[1] - 4.f * x[2] - 3.f * x[3] + 2.f * x[4];
-    o[1] = 2.f * x[1] + 5.f * x[2] + x[3] - 2.f * x[4];
-    o[2] = 2.f * x[1] + x[2] - 5.f * x[3] + 2.f * x[4];
-    o[3] = -x[1] - 2.f * x[2] + x[3] + 2.f * x[4];
-    o[4] = -2.f * x[1] + x[2] + 2.f * x[3] - x[4];
-    o[5] = 2.f * x[1] + 3.f * x[2] - 4.f * x[3] - 3.f * x[4] + 2.f * x[5];
+    const float a = x[3] - x[1], b = x[4] - x[2];
+    o[0] = fmaf(2.f, x[0] + x[4], fmaf(-3.f, a, -4.f * x[2]));       //  2 x0 + 3 x1 - 4 x2 - 3 x3 + 2 x4
+    o[1] = fmaf(2.f, x[1] - x[4], fmaf(5.f, x[2], x[3]));            //  2 x1 + 5 x2 +   x3 - 2 x4
+    o[2] = fmaf(2.f, x[1] + x[4], fmaf(-5.f, x[3], x[2]));           //  2 x1 +   x2 - 5 x3 + 2 x4
+    o[3] = fmaf(2.f, b, a);                                          //   -x1 - 2 x2 +   x3 + 2 x4
+    o[4] = fmaf(2.f, a, -b);                                         // -2 x1 +   x2 + 2 x3 -   x4
+    o[5] = fmaf(2.f, x[1] + x[5], fmaf(-3.f, b, -4.f * x[3]));       //  2 x1 + 3 x2 - 4 x3 - 3 x4 + 2 x5
 }
 
 struct Wino5Dims {
@@ -319,38 +327,53 @@ struct Wino5Dims {
     int relu;
 };
 
+#ifdef W5_TIME
+// development: shader-clock breakdown of the kernel's phases per wave (scripts/w5_phase_times.py; a build with -DW5_TIME)
+__device__ long long w5_dbg[256 * 12 * 8];
+#define W5_LAP(slot) do { const long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define W5_LAP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Dims d, const float* __restrict__ in,
                                                                          const float* __restrict__ U,
                                                                          const float* __restrict__ bias,
                                                                          float* __restrict__ out, int* __restrict__ tile_counter,
                                                                          int total_tiles) {
     __shared__ __attribute__((aligned(16))) float Us[2][W5_P][W5_KC][W5_OCB];    // 72 KB
-    __shared__ __attribute__((aligned(16))) float Vs[2][W5_P][W5_KC][W5_TB];     // 36 KB
-    __shared__ __attribute__((aligned(16))) float Ss[W5_KC][6][6][W5_TB];        // 18 KB: B^T d of the next chunk, [channel][i][column][tile]
-    float (*Ms)[16][W5_TB] = reinterpret_cast<float (*)[16][W5_TB]>(&Us[0][0][0][0]);   // epilogue: [p][row][tile] = 72 KB over Us
+    __shared__ __attribute__((aligned(16))) float Vs[2][W5_P][W5_KC][W5_NB];     // 36 KB
+    __shared__ __attribute__((aligned(16))) float Sw[12][10][6][7];              // 20 KB: per wave, B^T d of its ten pairs [pair][i][column] (row stride 7)
+    float (*Ms)[16][W5_NB] = reinterpret_cast<float (*)[16][W5_NB]>(&Us[0][0][0][0]);   // epilogue: [p][row][tile] = 72 KB over Us
     __shared__ int s_next;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
-    const int tc = wave % 6, th = wave / 6;             // transform role: column / row tc, channels 2 th and 2 th + 1
-    const int tch = 2 * th + khalf;                     // this lane's channel of the chunk (tile = l31)
+    // transform role: lane = 6 q + tc: pair q (0..9) of this wave, column (pass 1) / row (pass 2) tc; lanes 60..63 idle
+    const bool t_on = lane < 60;
+    const int tq = t_on ? lane / 6 : 9, tc = t_on ? lane - 6 * (lane / 6) : 5;
+    const int tpair = 10 * wave + tq;                   // 0..119 = channel * 30 + tile
+    const int tch = tpair / W5_TB, ttile = tpair - tch * W5_TB;
     const unsigned us_base = lds_addr(&Us[0][0][0][0]);
     const int nblocks = (d.tiles + W5_TB - 1) / W5_TB;
+    for (int q = tid; q < 2 * W5_P * W5_KC * W5_NB; q += W5_THREADS) (&Vs[0][0][0][0])[q] = 0.f;   // (columns 30, 31 stay zero)
+    __syncthreads();
+#ifdef W5_TIME
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+#endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
         if (tid == 0) s_next = atomicAdd(tile_counter, 1) + (int)gridDim.x;     // read after the K loop's barriers
         int t = tile;
         const int ob = t % d.ocblocks; t /= d.ocblocks;
         const int tb = t % nblocks;
         const int g = t / nblocks;
-        const int n_raw = tb * W5_TB + l31;
-        const bool n_ok = n_raw < d.tiles;
-        const int n = n_ok ? n_raw : d.tiles - 1;
-        const int b = n / W5_TPI, rr0 = n - b * W5_TPI;
-        const int ty = rr0 / 31, tx = rr0 - ty * 31;
         const int b_first = (tb * W5_TB) / W5_TPI;
         const float* in_base = in + ((size_t)b_first * d.ctot_in + (size_t)g * d.IC) * W5_PLANE;
         unsigned doff[6];                               // byte offsets of this lane's patch column tc, rows 0..5 (clamped into the plane)
         {
+            int n = tb * W5_TB + ttile;
+            n = n < d.tiles ? n : d.tiles - 1;
+            const int b = n / W5_TPI, rr0 = n - b * W5_TPI;
+            const int ty = rr0 / 31, tx = rr0 - ty * 31;
             const int col = 2 * tx + tc < 64 ? 2 * tx + tc : 64;
             const unsigned base = (unsigned)(((b - b_first) * d.ctot_in + tch) * W5_PLANE + col);
 #pragma unroll
@@ -360,25 +383,28 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
             }
         }
         const float* u_base = U + ((size_t)(g * d.ocblocks + ob) * d.chunks) * (W5_P * W5_KC * W5_OCB);
-        float dcol[6];                                  // the patch column of the chunk after next
+        float dcol[6];                                  // the patch column of the next chunk
         auto fetch = [&](int c) {
             const char* p = (const char*)(in_base + (size_t)c * W5_KC * W5_PLANE);
 #pragma unroll
             for (int r = 0; r < 6; ++r) dcol[r] = *(const float*)(p + doff[r]);
         };
-        auto pass1 = [&]() {                            // column tc of B^T d -> Ss[channel][i][tc][tile]
-            float o[6];
-            w5_bt(dcol, o);
+        auto transform = [&](int buf) {                 // V = B^T d B of this wave's ten pairs -> Vs[buf][p][channel][tile]
+            float o[6], x[6];
+            w5_bt(dcol, o);                             // column tc of B^T d
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Ss[tch][i][tc][l31] = o[i];
-        };
-        auto pass2 = [&](int buf) {                     // row tc of (B^T d) B -> Vs[buf][6 tc + j][channel][tile]
-            float x[6], o[6];
+            for (int i = 0; i < 6; ++i) Sw[wave][tq][i][tc] = o[i];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();            // (the LDS serves a wave's accesses in issue order: no wait needed)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) x[c] = Ss[tch][tc][c][l31];
+            for (int c = 0; c < 6; ++c) x[c] = Sw[wave][tq][tc][c];     // row tc of B^T d
             w5_bt(x, o);
+            if (t_on) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) Vs[buf][6 * tc + j][tch][l31] = o[j];
+                for (int j = 0; j < 6; ++j) Vs[buf][6 * tc + j][tch][ttile] = o[j];
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();            // (the next call's writes to Sw come after these reads)
         };
         auto issue_u = [&](int c, int buf) {            // 36 KB = 36 pieces of 1 KB: wave w moves pieces w, w + 12, w + 24
             const float* src = u_base + (size_t)c * (W5_P * W5_KC * W5_OCB);
@@ -397,19 +423,18 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pp][i][r] = 0.f;
 
+        W5_LAP(7);
         issue_u(0, 0);
         fetch(0);
-        pass1();
+        transform(0);
         if (d.chunks > 1) fetch(1);
-        __syncthreads();
-        pass2(0);
         wait_vmcnt<0>();
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        W5_LAP(3);
         for (int c = 0; c < d.chunks; ++c) {
             const int buf = c & 1;
             const bool more = c + 1 < d.chunks;
-            if (more) { issue_u(c + 1, buf ^ 1); pass1(); }     // (dcol holds chunk c + 1)
-            if (c + 2 < d.chunks) fetch(c + 2);
+            if (more) issue_u(c + 1, buf ^ 1);
             float af[2][3][2], bf[2][3];
             auto operands = [&](int k2) {
                 const int o = (k2 >> 1) & 1;
@@ -420,6 +445,16 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
                     for (int i = 0; i < 2; ++i) af[o][pp][i] = Us[buf][p][k2 + khalf][i * 32 + l31];
                     bf[o][pp] = Vs[buf][p][k2 + khalf][l31];
                 }
+            };
+            // (Tried: the three waves of a SIMD transforming at different points of the chunk -- before, between, after the
+            // MFMAs.  No gain: a wave's VALU instructions queue behind the other waves' 64-cycle matrix instructions either
+            // way -- the hardware serves the older waves' MFMAs first, so the waves drift apart by themselves -- and the
+            // transform costs 26 % of a wave's time against 36 % for the MFMA phase, scripts/w5_phase_times.py.)
+            auto next_v = [&]() {                       // (dcol holds chunk c + 1; Vs[buf ^ 1] was last read in chunk c - 1)
+                W5_LAP(1);
+                if (more) transform(buf ^ 1);
+                if (c + 2 < d.chunks) fetch(c + 2);
+                W5_LAP(0);
             };
             operands(0);
 #pragma unroll
@@ -434,14 +469,20 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
                         acc[pp][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[o][pp][i], bf[o][pp], acc[pp][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Ss is complete (LDS only: the DMA and the loads stay in flight)
-            if (more) pass2(buf ^ 1);
+            next_v();
+            W5_LAP(1);
             wait_vmcnt<0>();                            // the next chunk's U has landed (own pieces) ...
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... for every wave; this chunk's buffers are free
+            W5_LAP(2);
         }
 
         // ---- epilogue: Y = A^T M A per (output channel, tile), a quarter of the rows at a time through LDS ----
         const int row = tid >> 5;                       // threads 0..511: (row 0..15, tile l31)
+        const int n_raw = tb * W5_TB + l31;
+        const bool n_ok = l31 < W5_TB && n_raw < d.tiles;
+        const int n = n_ok ? n_raw : d.tiles - 1;
+        const int b = n / W5_TPI, rr0 = n - b * W5_TPI;
+        const int ty = rr0 / 31, tx = rr0 - ty * 31;
         const bool last_y = 2 * ty + 1 >= 61, last_x = 2 * tx + 1 >= 61;
         float* obase = out + ((size_t)b * d.ctot_out + (size_t)g * d.OC + (size_t)ob * W5_OCB) * 3721 + (size_t)(2 * ty) * 61 + 2 * tx;
         const float* bbase = bias + g * d.OC + ob * W5_OCB;
@@ -453,7 +494,9 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Ms[3 * wave + pp][i * 8 + 4 * khalf + e][l31] = acc[pp][i][4 * r + e];
+            W5_LAP(4);
             __syncthreads();
+            W5_LAP(5);
             if (tid < 512) {
                 float s[6][2];
 #pragma unroll
@@ -484,11 +527,18 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
                         }
                 }
             }
+            W5_LAP(6);
             __syncthreads();
+            W5_LAP(5);
         }
         tile = __builtin_amdgcn_readfirstlane(s_next);
     }
+#ifdef W5_TIME
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 8; ++i) w5_dbg[(blockIdx.x * 12 + wave) * 8 + i] = tacc[i];
+#endif
 }
+
 
 }  // namespace
 #endif

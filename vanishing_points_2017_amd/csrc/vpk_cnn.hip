@@ -1301,6 +1301,10 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     return VPK_OK;
 }
 
+#ifdef W5_TIME
+int vpk_dbg_w5(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w5_dbg), sizeof(long long) * 256 * 12 * 8); }
+#endif
+
 int vpk_cnn_set_algorithm(vpk_handle* h, int mode) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_algorithm before vpk_cnn_load");
     if (mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 or 1");
