@@ -76,8 +76,8 @@ def parse():
                     help="0: native f32 matrix instructions (default); 1: conv2..5 as six bf16 matrix products per f32 "
                          "product (vpk_cnn_set_precision, same error class; reported as its own dtype)")
     ap.add_argument("--cnn-algorithm", type=int, default=1, choices=[0, 1],
-                    help="conv3..5: 1 = Winograd F(2x2, 3x3) on the f32 matrix cores (default, the library's default), 0 = direct "
-                         "implicit GEMM (vpk_cnn_set_algorithm)")
+                    help="conv2..5: 1 = Winograd minimal filtering, F(2x2,5x5) / F(2x2,3x3), on the f32 matrix cores (default, the "
+                         "library's default), 0 = direct implicit GEMM (vpk_cnn_set_algorithm)")
     ap.add_argument("--cnn-fusion", type=int, default=1, choices=[0, 1, 2],
                     help="conv1 + norm1 + pool1: 1 = direct-convolution kernel (default), 2 = implicit-GEMM kernel with the fused "
                          "epilogue, 0 = separate kernels")
@@ -828,8 +828,8 @@ def run_workload(args, dist, rank, local_rank, world):
                          "header copy once five launches are queued on a handle",
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "cnn_algorithm": ("conv1, conv2, fc6-8: direct / implicit GEMM; conv3-5: Winograd F(2x2,3x3), all on v_mfma_f32 (f32 in, f32 "
-                              "accumulate)" if args.cnn_algorithm == 1 and args.cnn_precision == 0 else "direct / implicit GEMM"),
+            "cnn_algorithm": ("conv1, fc6-8: direct / implicit GEMM; conv2: Winograd F(2x2,5x5); conv3-5: Winograd F(2x2,3x3); all on "
+                              "v_mfma_f32 (f32 in, f32 accumulate)" if args.cnn_algorithm == 1 and args.cnn_precision == 0 else "direct / implicit GEMM"),
             "dtype": "f32 (CNN, MFMA) + f64 (EM)" if args.cnn_precision == 0 else
                      "f32 as 3 bf16 pieces x 6 bf16-MFMA products, f32 accumulate (conv2-5) + f32 MFMA (conv1, fc6-8) + f64 (EM)",
             "data": "synthetic (seeded line sets of the config's shape; their rasters made by vpk_sphere_raster = the reference's "

@@ -89,7 +89,8 @@ def test_fused_first_stage_equals_separate_kernels(net_and_ref):
 def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
     """vpk_cnn_set_precision(1): conv2..5 as six bf16 matrix products per f32 product (cnn_split_gemm.hpp).  Both
     precisions are measured against the SAME net evaluated in float64: the split path's error must be of the size of
-    the native f32 path's (f32 accumulation noise), at every tap and at the output."""
+    the native f32 DIRECT path's (f32 accumulation noise; vpk_cnn_set_algorithm(0) -- the default Winograd kernels sum
+    fewer products and are more accurate than either), at every tap and at the output."""
     from oracle import cnn_torch
     from vanishing_points_2017_amd import cnn, synth
     w = cnn.synthetic_weights(0)
@@ -98,6 +99,7 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
     sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=3)])
     ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
     net = cnn.Net(w, mean)
+    net.set_algorithm(0)
     try:
         for tap in (2, 4, 5, 6, 8):                            # conv2, conv3, conv4, conv5, fc6
             want = taps[cnn_torch.TAPS[tap]]
@@ -112,6 +114,7 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
             assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
         net.set_precision(0)
+        net.set_algorithm(1)
 
 
 def test_split_path_beyond_4_gib_of_activations():

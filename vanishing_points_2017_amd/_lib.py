@@ -64,6 +64,9 @@ def load():
     if not os.path.exists(SO_PATH):
         raise VpkError("libvpk.so is missing (%s): build it with `python -m vanishing_points_2017_amd.build`"
                        "; there is no CPU fallback" % SO_PATH)
+    # torch first: the device buffers handed to the library are torch's, so the process must hold ONE HIP runtime -- the
+    # one torch ships; loaded the other way round (libvpk.so's /opt/rocm runtime first) hipGetDeviceCount fails later
+    import torch  # noqa: F401
     lib = ctypes.CDLL(SO_PATH)
     lib.vpk_last_error.restype = ctypes.c_char_p
     lib.vpk_last_error.argtypes = [c_void]
