@@ -22,13 +22,20 @@ from ref_shim import load_reference  # noqa: E402
 from vanishing_points_2017_amd import synth  # noqa: E402
 
 
-def perturbations(lp, trials, seed=0):
+def perturbations(lp, trials, seed=0, trials_all=0):
+    """`trials` copies with ONE coordinate of ONE line moved by one ulp, then `trials_all` copies with EVERY coordinate moved
+    by -1, 0 or +1 ulp (seeded): still an input within one ulp of the original everywhere, but one that reaches every
+    intermediate of the EM the way another exp / acos implementation does (yields line = coordinate = -1 for those)."""
     rs = np.random.RandomState(seed)
     for t in range(trials):
         q = lp.copy()
         i, j = rs.randint(lp.shape[0]), rs.randint(4)
         q[i, j] = np.nextafter(q[i, j], 10.0 if t % 2 else -10.0)
         yield i, j, q
+    for t in range(trials_all):
+        step = rs.randint(-1, 2, size=lp.shape)
+        q = np.where(step > 0, np.nextafter(lp, 10.0), np.where(step < 0, np.nextafter(lp, -10.0), lp))
+        yield -1, -1, q
 
 
 def main(argv):
