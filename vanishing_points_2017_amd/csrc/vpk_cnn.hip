@@ -1027,8 +1027,10 @@ const Topo TOPO[8] = {
     {4096, 1, 1, 4096, 1, 1, 1, 1, 1, 0, 128, 0},        // fc7 (:224-242)
     {4096, 1, 1, 400, 1, 1, 1, 1, 1, 0, 128, 0},         // fc8_20x20 (:257-275)
 };
-// split-K of the dense layers: enough workgroups for ~3 per CU at the default batch (fc6: 32 m-tiles x 24)
-const int KSPLIT[8] = {1, 1, 1, 1, 1, 24, 16, 32};
+// split-K of the dense layers.  fc6: 32 m-tiles x 72 = 2304 tiles of 50 K-steps for the 768 resident workgroups' queue: with
+// 24 (one tile per workgroup) the layer took 0.40 ms alone but 0.79 ms beside the EM -- the workgroups of the ~166 free CUs
+// each needed a second whole tile --, with 72 it takes 0.40 / 0.66 ms (round 4; the partials grow from 40 to 120 MB)
+const int KSPLIT[8] = {1, 1, 1, 1, 1, 72, 16, 32};
 
 // Activation arena: one region per blob, floats per image.  Regions are carved by the CAPACITY batch,
 // so an image's planes sit at the same address for every batch size <= capacity and the zero borders
@@ -1047,7 +1049,7 @@ constexpr size_t REGION_FLOATS[R_COUNT] = {
     256ull * 900,            // conv5, dense
     256ull * 225,            // pool5 = fc6 input
     4096, 4096,              // fc6 / fc7 outputs
-    24ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
+    72ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
     96ull * 65 * 65 * 3 / 2, // the current conv layer's input as three bf16 NHWC pieces (largest: pool1)
     384ull * 32 * 32 * 3 / 2, // conv4's / conv5's input in that format, written by the previous layer's epilogue (interior
     384ull * 32 * 32 * 3 / 2, //  only: the zero border comes from the arena's allocation)
