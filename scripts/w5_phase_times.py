@@ -28,3 +28,13 @@ print("per wave, mean over workgroups: cycles (share); per-wave means w0..w11")
 for i, n in enumerate(names):
     print("%-26s %10.0f  %5.1f%%   " % (n, b[:, :, i].mean(), 100 * b[:, :, i].mean() / tot), " ".join("%7.0f" % b[:, w, i].mean() for w in range(12)))
 print("total", tot)
+
+# the 3 x 3 kernel (its last launch of the pass: conv5, 24 chunks of 8 channels; same slots)
+buf3 = np.zeros(256 * 8 * 8, dtype=np.int64)
+lib.vpk_dbg_w3(buf3.ctypes.data_as(ctypes.c_void_p))
+b3 = buf3.reshape(256, 8, 8).astype(np.float64)
+tot3 = b3.sum(axis=2).mean()
+print("conv3x3_winograd_kernel (conv5), ms:", net.last_layer_ms()["conv5"])
+for i, n in enumerate(names):
+    print("%-26s %10.0f  %5.1f%%   " % (n, b3[:, :, i].mean(), 100 * b3[:, :, i].mean() / tot3), " ".join("%7.0f" % b3[:, w, i].mean() for w in range(8)))
+print("total", tot3)

@@ -65,6 +65,14 @@ inline void winograd_weights(const float* w, int G, int OC, int IC, std::vector<
             }
 }
 
+#ifdef W5_TIME
+// development: shader-clock breakdown of the kernel's phases per wave (scripts/w5_phase_times.py; a build with -DW5_TIME)
+__device__ long long w5_dbg[256 * 12 * 8];
+__device__ long long w3_dbg[256 * 8 * 8];       // the 3 x 3 kernel's (its last launch: conv5)
+#define W5_LAP(slot) do { const long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define W5_LAP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDims d, const float* __restrict__ in,
                                                                          const float* __restrict__ U,
                                                                          const float* __restrict__ bias,
@@ -81,6 +89,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
     // persistent workgroups over a dynamic tile queue (the first gridDim.x tiles are static): beside another stream's kernel
     // that holds CUs (the EM), a static deal leaves the workgroups of the busy XCDs behind
     __shared__ int s_next;
+#ifdef W5_TIME
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+#endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
         if (tid == 0) s_next = atomicAdd(tile_counter, 1) + (int)gridDim.x;   // read after the K loop's barriers
         int t = tile;
@@ -146,12 +158,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[pp][i][j][r] = 0.f;
 
+        W5_LAP(7);
         issue_u(0, 0);
         fetch(0);
         transform(0);
         wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        W5_LAP(3);
         for (int c = 0; c < d.chunks; ++c) {
             const int buf = c & 1;
             const bool more = c + 1 < d.chunks;
@@ -185,10 +199,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
                             acc[pp][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[o][pp][i], bf[o][pp][j], acc[pp][i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            W5_LAP(1);
             if (more) transform(buf ^ 1);
+            W5_LAP(0);
             wait_vmcnt<0>();                            // the next chunk's U has landed (own pieces) ...
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();               // ... for every wave; this chunk's buffers are free
+            W5_LAP(2);
         }
 
         // ---- epilogue: Y = A^T M A per (output channel, tile), a quarter of the rows at a time through LDS ----
@@ -207,7 +224,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             Ms[2 * wave + pp][i * 8 + 4 * khalf + e][j * 32 + l31] = acc[pp][i][j][4 * r + e];
+            W5_LAP(4);
             __syncthreads();
+            W5_LAP(5);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int row = wave + 8 * u;           // id = tid + 512 u: row = id / 64, tile = lane
@@ -240,10 +259,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
                         }
                 }
             }
+            W5_LAP(6);
             __syncthreads();
+            W5_LAP(5);
         }
         tile = __builtin_amdgcn_readfirstlane(s_next);
     }
+#ifdef W5_TIME
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 8; ++i) w3_dbg[(blockIdx.x * 8 + wave) * 8 + i] = tacc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -327,13 +352,6 @@ struct Wino5Dims {
     int relu;
 };
 
-#ifdef W5_TIME
-// development: shader-clock breakdown of the kernel's phases per wave (scripts/w5_phase_times.py; a build with -DW5_TIME)
-__device__ long long w5_dbg[256 * 12 * 8];
-#define W5_LAP(slot) do { const long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define W5_LAP(slot) do { } while (0)
-#endif
 __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Dims d, const float* __restrict__ in,
                                                                          const float* __restrict__ U,
                                                                          const float* __restrict__ bias,

@@ -1305,6 +1305,7 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on) {
 
 #ifdef W5_TIME
 int vpk_dbg_w5(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w5_dbg), sizeof(long long) * 256 * 12 * 8); }
+int vpk_dbg_w3(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w3_dbg), sizeof(long long) * 256 * 8 * 8); }
 #endif
 
 int vpk_cnn_set_algorithm(vpk_handle* h, int mode) {
