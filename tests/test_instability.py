@@ -57,3 +57,27 @@ def test_the_certified_image_moves_under_one_ulp_input_changes():
     assert cert.get((4, 1612), {}).get("unstable"), "tests/golden/instability.npz lacks the certificate of configs[3] image 1612"
     base, moved, flipped, same = _spread(4, 1612, 2)
     assert (not all(same)) or max(moved) > 1e-4 or max(flipped) >= 1      # the oracle, like the reference, has no stable answer here
+
+
+def test_certificate_perturbations_stay_within_one_ulp():
+    """oracle/ref_instability.perturbations: the single-coordinate trials change ONE coordinate by one ulp, the
+    all-coordinate trials (--all) move every coordinate by at most one ulp -- both are inputs the parity bar's
+    'identical inputs' cannot tell from the original beyond the last bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "ref_instability.py")).read()
+    ns = {"np": np}
+    start = src.index("def perturbations(")
+    exec(src[start:src.index("\ndef main(")], ns)           # the generator only (the module's imports need /root/reference)
+    lp = next(synth.config_scenes(2, count=1, start=3))["lp"]
+    got = list(ns["perturbations"](lp, 3, seed=7, trials_all=3))
+    assert len(got) == 6
+    for k, (i, j, q) in enumerate(got):
+        changed = q != lp
+        one_ulp = (q == np.nextafter(lp, 10.0)) | (q == np.nextafter(lp, -10.0))
+        assert (one_ulp | ~changed).all()
+        if k < 3:
+            assert changed.sum() == 1 and changed[i, j]
+        else:
+            assert i == -1 and changed.mean() > 0.5
