@@ -405,7 +405,16 @@ def extra_workloads(args, local_rank):
     a.em_wgs, a.cnn_precision = -1, 0
     s = run_workload(a, None, 0, local_rank, 1)
     out["stress"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "stage_ms",
-                                       "em_stats", "roofline", "roofline_secondary")}
+                                       "cnn_layer_ms", "em_stats", "roofline", "roofline_secondary")}
+    layers = sum(s["cnn_layer_ms"].values())
+    out["stress"]["overlap"] = {
+        "cnn_layers_sum_ms": layers, "em_kernel_ms": s["stage_ms"]["em"], "step_ms": s["ms_per_step"],
+        "note": "no overlap to speak of at this shape: an EM workgroup holds a whole CU (254 VGPRs x 512 threads, the whole LDS) and "
+                "512 of them per launch leave no CU idle, so the step is the sum of the two kernels' CU-times (EM launch + the "
+                "CNN's ~22 ms for 512 images alone).  The CNN stream's kernels wait for CUs the EM lanes hold: that wait lands in "
+                "whichever layer is in flight when an EM launch starts (cnn_layer_ms shows which one in THIS run; a profiled "
+                "run shifts it -- profiles/r04_stress_kernel_stats.csv has it in conv2's kernel), so roofline_secondary's "
+                "figure for conv2 is that layer's rate when it had the CUs, not the CNN's share of the step"}
     out["hlw"] = hlw_pass(local_rank)
     return out
 
