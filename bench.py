@@ -411,10 +411,11 @@ def extra_workloads(args, local_rank):
         "cnn_layers_sum_ms": layers, "em_kernel_ms": s["stage_ms"]["em"], "step_ms": s["ms_per_step"],
         "note": "no overlap to speak of at this shape: an EM workgroup holds a whole CU (254 VGPRs x 512 threads, the whole LDS) and "
                 "512 of them per launch leave no CU idle, so the step is the sum of the two kernels' CU-times (EM launch + the "
-                "CNN's ~22 ms for 512 images alone).  The CNN stream's kernels wait for CUs the EM lanes hold: that wait lands in "
-                "whichever layer is in flight when an EM launch starts (cnn_layer_ms shows which one in THIS run; a profiled "
-                "run shifts it -- profiles/r04_stress_kernel_stats.csv has it in conv2's kernel), so roofline_secondary's "
-                "figure for conv2 is that layer's rate when it had the CUs, not the CNN's share of the step"}
+                "CNN's ~22 ms for 512 images alone).  The CNN stream waits for CUs the EM lanes hold -- in front of the forward "
+                "(stage_ms.cnn, from the forward's enqueue to its end, includes that wait; cnn_layers_sum_ms is the kernels' own time) "
+                "or inside whichever layer is in flight when an EM launch starts (a profiled run shifts it there: "
+                "profiles/r04_stress_kernel_stats.csv has it in conv2's kernel) -- so roofline_secondary's figure for conv2 is that "
+                "layer's rate when it had the CUs, not the CNN's share of the step"}
     out["hlw"] = hlw_pass(local_rank)
     return out
 
