@@ -88,13 +88,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
     const int nblocks = (d.tiles + WG_TB - 1) / WG_TB;
     // persistent workgroups over a dynamic tile queue (the first gridDim.x tiles are static): beside another stream's kernel
     // that holds CUs (the EM), a static deal leaves the workgroups of the busy XCDs behind
-    __shared__ int s_next;
+    // (two slots used in turn, like the other persistent kernels: with one, thread 0 of a wave that has gone round could
+    //  overwrite the index before a slower wave has read it -- no barrier separates that read from the next write)
+    __shared__ int s_next[2];
+    int parity = 0;
 #ifdef W5_TIME
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_readcyclecounter();
 #endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
-        if (tid == 0) s_next = atomicAdd(tile_counter, 1) + (int)gridDim.x;   // read after the K loop's barriers
+        if (tid == 0) s_next[parity] = atomicAdd(tile_counter, 1) + (int)gridDim.x;   // read after the K loop's barriers
         int t = tile;
         const int ob = t % d.ocblocks; t /= d.ocblocks;     // output-channel blocks of the same tiles next to each other (L2)
         const int tb = t % nblocks;
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void conv3x3_winograd_kernel(WinoDim
             __syncthreads();
             W5_LAP(5);
         }
-        tile = __builtin_amdgcn_readfirstlane(s_next);
+        tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
+        parity ^= 1;
     }
 #ifdef W5_TIME
     if (lane == 0 && blockIdx.x < 256)
@@ -361,7 +365,8 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
     __shared__ __attribute__((aligned(16))) float Vs[2][W5_P][W5_KC][W5_NB];     // 36 KB
     __shared__ __attribute__((aligned(16))) float Sw[12][10][6][7];              // 20 KB: per wave, B^T d of its ten pairs [pair][i][column] (row stride 7)
     float (*Ms)[16][W5_NB] = reinterpret_cast<float (*)[16][W5_NB]>(&Us[0][0][0][0]);   // epilogue: [p][row][tile] = 72 KB over Us
-    __shared__ int s_next;
+    __shared__ int s_next[2];                          // two slots used in turn (see the 3 x 3 kernel)
+    int parity = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
     long long tlast = __builtin_readcyclecounter();
 #endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
-        if (tid == 0) s_next = atomicAdd(tile_counter, 1) + (int)gridDim.x;     // read after the K loop's barriers
+        if (tid == 0) s_next[parity] = atomicAdd(tile_counter, 1) + (int)gridDim.x;     // read after the K loop's barriers
         int t = tile;
         const int ob = t % d.ocblocks; t /= d.ocblocks;
         const int tb = t % nblocks;
@@ -549,7 +554,8 @@ __global__ __launch_bounds__(W5_THREADS, 1) void conv5x5_winograd_kernel(Wino5Di
             __syncthreads();
             W5_LAP(5);
         }
-        tile = __builtin_amdgcn_readfirstlane(s_next);
+        tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
+        parity ^= 1;
     }
 #ifdef W5_TIME
     if (lane == 0 && blockIdx.x < 256)

@@ -1565,6 +1565,7 @@ VPK_DEVFN void smooth_rows(EmCtx& c, int m0) {
 // Applies where smooth_rows applied and N <= 64 CMAX; everything else keeps its kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int SP_R = 16;                                // rows per staged block
+static_assert((size_t)SP_R + 1 <= vpk::EM_LSIM_PAD_ROWS, "smooth_sparse stages rows up to 16 ceil(N / 16) - 1 plus one piece's overrun: em_layout must pad lsim for them");
 constexpr int SP_CMAX = 7;                              // column groups of 64 per lane: N <= 448
 VPK_DEV int sp_cgroups(int N) { return (N + WAVE - 1) / WAVE; }
 VPK_DEV int sp_ldw(int C) { return ((C + 1) / 2) * 2 * WAVE; }   // staged row: whole 1 KB DMA pieces (128 doubles)
@@ -1651,8 +1652,9 @@ VPK_DEVFN void smooth_sparse(EmCtx& c, int m0) {
         for (int ci = 0; ci < C; ++ci) pin1(wreg[q][ci]);
     wait_vm<0>();
     // ---- staging by LDS-DMA: piece p of a block = (row p / DPR, 128 doubles p % DPR); wave w issues the pieces w, w + 8, ..
-    //      Rows up to 8 ceil(N / 8) - 1 exist (zero_tail_rows); a piece may run past its row's ld doubles into the next
-    //      row -- those doubles land in columns no lane owns a result for ----
+    //      Rows up to 8 ceil(N / 8) - 1 are zeros (zero_tail_rows), rows up to N + EM_LSIM_PAD_ROWS - 1 belong to lsim
+    //      (em_layout): a block's last rows and a piece that runs past its row's ld doubles into the next row stay inside
+    //      the matrix; what they hold meets zero operand bits / columns no lane owns a result for ----
     auto issue = [&](int blk) __attribute__((always_inline)) {
         const unsigned dst = buf_lds + (unsigned)((blk % NB) * R * LDW * 8);
 #pragma unroll

@@ -25,6 +25,8 @@ inline size_t em_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // doubles reserved per slot for the snapshot of the workgroup's LDS state (em_device.hpp: Shared) that a
 // suspended image resumes from (time-sliced launches, vpk_em_set_time_slice)
 constexpr size_t EM_STATE_DOUBLES = 2048;
+// rows of lsim beyond the image's N (see em_layout)
+constexpr size_t EM_LSIM_PAD_ROWS = 24;
 
 inline int em_mcap(int num_init_vp, int n_init, bool has_init, bool do_split, int num_iter, int freq,
                    int maxm) {
@@ -51,7 +53,11 @@ inline EmLayout em_layout(int nmax, int mcap, int nwaves, bool use_weights, bool
     L.nwaves = nwaves;
     size_t o = 0;
     const size_t n = (size_t)L.ldn;
-    L.lsim = o;    o += use_weights ? (n + 8) * n : 8;   // + 8 zero rows: the row-sliced smoother walks 8 ceil(N / 8) rows
+    // + 8 zero rows: the row-sliced smoother walks 8 ceil(N / 8) rows (zero_tail_rows).  + 16 more that are only ever READ:
+    // the sparse smoother stages blocks of SP_R = 16 rows by DMA (rows up to 16 ceil(N / 16) - 1, and a 1 KB piece may run
+    // past its row's ld doubles into the next row); their operand bits are zero, so the values never reach a sum, but the
+    // addresses must belong to lsim whatever region follows it (static_assert in em_device.hpp ties SP_R to EM_LSIM_PAD_ROWS)
+    L.lsim = o;    o += use_weights ? (n + EM_LSIM_PAD_ROWS) * n : 8;
     L.pdist = o;   o += use_weights ? n * n : 8;       // pair distances (setup only: the kNN rating reads rows of it)
     L.den = o;     o += n;
     L.lweight = o; o += n;

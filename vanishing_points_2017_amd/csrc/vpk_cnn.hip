@@ -1017,7 +1017,7 @@ namespace {
 // P = convolution padding (the input planes are stored with that zero border), OP = border of the
 // OUTPUT planes (= padding of the layer that consumes them; 0 = dense).
 struct Topo { int IC, H, W, OC, OH, OW, G, KH, S, P, BM, OP; };
-const Topo TOPO[8] = {
+constexpr Topo TOPO[8] = {
     {1, 500, 500, 96, 123, 123, 1, 11, 4, 0, 96, 0},     // conv1 (:9-27)      -> LRN/pool (dense)
     {48, 61, 61, 128, 61, 61, 2, 5, 1, 2, 128, 0},       // conv2 (:56-75) g2  -> LRN/pool (dense)
     {256, 30, 30, 384, 30, 30, 1, 3, 1, 1, 128, 1},      // conv3 (:104-122)   -> conv4 (pad 1)
@@ -1030,7 +1030,12 @@ const Topo TOPO[8] = {
 // split-K of the dense layers.  fc6: 32 m-tiles x 72 = 2304 tiles of 50 K-steps for the 768 resident workgroups' queue: with
 // 24 (one tile per workgroup) the layer took 0.40 ms alone but 0.79 ms beside the EM -- the workgroups of the ~166 free CUs
 // each needed a second whole tile --, with 72 it takes 0.40 / 0.66 ms (round 4; the partials grow from 40 to 120 MB)
-const int KSPLIT[8] = {1, 1, 1, 1, 1, 72, 16, 32};
+constexpr int KSPLIT[8] = {1, 1, 1, 1, 1, 72, 16, 32};
+constexpr size_t splitk_partials_per_image() {          // the partials region: max over the dense layers of ksplit x outputs
+    size_t m = 0;
+    for (int li = 5; li < 8; ++li) m = (size_t)KSPLIT[li] * TOPO[li].OC > m ? (size_t)KSPLIT[li] * TOPO[li].OC : m;
+    return m;
+}
 
 // Activation arena: one region per blob, floats per image.  Regions are carved by the CAPACITY batch,
 // so an image's planes sit at the same address for every batch size <= capacity and the zero borders
@@ -1049,7 +1054,7 @@ constexpr size_t REGION_FLOATS[R_COUNT] = {
     256ull * 900,            // conv5, dense
     256ull * 225,            // pool5 = fc6 input
     4096, 4096,              // fc6 / fc7 outputs
-    72ull * 4096,            // split-K partials (max over fc6..8 of ksplit x outputs)
+    splitk_partials_per_image(),   // split-K partials (fc6: 72 x 4096 floats = 1.2 MB per capacity image)
     96ull * 65 * 65 * 3 / 2, // the current conv layer's input as three bf16 NHWC pieces (largest: pool1)
     384ull * 32 * 32 * 3 / 2, // conv4's / conv5's input in that format, written by the previous layer's epilogue (interior
     384ull * 32 * 32 * 3 / 2, //  only: the zero border comes from the arena's allocation)

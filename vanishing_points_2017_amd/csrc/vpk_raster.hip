@@ -808,8 +808,14 @@ int vpk_sphere_raster(vpk_handle* h, const double* l, const int64_t* offsets, in
     // the coverage pool: 16 KB per line on average (measured: ~6 KB) and never less than eight canvases' worth -- the row
     // ranges of ONE line can span most of the canvas (see polygon_coverage), and a call may consist of one line
     const size_t alpha_bytes = std::max<size_t>(nl * (alt ? (size_t)size * (size + 2) : (size_t)16384), (size_t)8 * size * (size + 2));
-    if (alpha_bytes >= (1ull << 32))                      // RowEnt::off is 32 bits (a chunk of 49 152 lines needs 0.8 GB)
-        return vpk_fail(h, VPK_ERR_LIMIT, "vpk_sphere_raster: one image has more than 262 000 lines");
+    if (alpha_bytes >= (1ull << 32)) {                    // RowEnt::off is 32 bits (a chunk of 49 152 lines needs 0.8 GB)
+        // one image is one chunk at least; the pool per line is 16 KB, or a whole canvas in `alternative` mode
+        char msg[160];
+        snprintf(msg, sizeof msg, "vpk_sphere_raster: one image has more than %lld lines (the 4 GiB coverage pool at %s per line)",
+                 (long long)((1ull << 32) / (alt ? (size_t)size * (size + 2) : (size_t)16384)) - 4,
+                 alt ? "one canvas (alternative mode)" : "16 KB");
+        return vpk_fail(h, VPK_ERR_LIMIT, msg);
+    }
     const size_t need = ob + fb + tb + nl * per_line + alpha_bytes + 8192;   // (the slack also covers the blend's 8-byte reads at the pool's end)
     const size_t had_bytes = h->raster_hdr_bytes;
     int rc = vpk_reserve(h, &h->raster_hdr, &h->raster_hdr_bytes, need, "hipMalloc(raster workspace)");
