@@ -870,6 +870,14 @@ def run_workload(args, dist, rank, local_rank, world):
                                          note="the same K steps with the CNN executed and the EM fed the generator's response maps "
                                               "(the priors the 'parity' object and the reference's stored results use) instead of "
                                               "the random-weight CNN's output, which 'value' uses (em_stats: its iteration counts)")
+        if dist is not None:            # the one collective of the path, as this run executed it
+            rec = out.get("records")
+            line["gather"] = {"backend": dist.get_backend(), "records": None if rec is None else int(rec.shape[0]),
+                              "width": None if rec is None else int(rec.shape[1]),
+                              "image_ids_complete": None if rec is None else bool(
+                                  torch.equal(rec[:, 0].to(torch.int64).cpu(), torch.arange(count * world, dtype=torch.int64))),
+                              "note": "per step: one all_gather of the ranks' fixed-size result records on the EM lane's stream "
+                                      "(sharding.gather_device); the figures are the last timed step's gathered block"}
         if alt:
             line["alt_precision"] = alt
         if from_lines is not None:

@@ -89,3 +89,57 @@ def test_reference_result_pickles_load(tmp_path):
     assert type(got["EM_result"]["distribution"]).__name__ == "PDF"
     assert got["EM_result"]["distribution"]._fields == ("v", "lv", "vl", "l", "lvsq", "angles")
     assert np.array_equal(got["EM_result"]["vp"], np.eye(3))
+
+
+# ---- the reader against files encoded by Google's protobuf runtime (oracle/make_caffe_proto_fixtures.py) ------------------
+def _proto_fixtures():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caffe_proto.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.mark.parametrize("tag", ["packed", "unpacked"])
+def test_reader_on_protobuf_encoded_layer_messages(tag):
+    """NetParameter.layer (field 100) as google.protobuf serialises it: BlobShape + data with a diff beside it, double_data,
+    legacy num / channels / height / width, layers without blobs, and the fields a reader has to skip (strings, enums,
+    32-bit floats, nested ParamSpec / ConvolutionParameter messages, repeated input / input_dim of the net)."""
+    g = _proto_fixtures()
+    layers = caffe_io.parse_caffemodel(g["net_layer_" + tag].tobytes())
+    assert sorted(layers) == ["conv1", "conv2", "fc6"]                     # "data" and "relu1" carry no blobs
+    for name, shapes in (("conv1", None), ("conv2", None), ("fc6", ((1, 1, 5, 36), (1, 1, 1, 5)))):
+        w, b = layers[name]
+        assert w.dtype == np.float32 and b.dtype == np.float32
+        want_w, want_b = g["want_%s_w" % name], g["want_%s_b" % name]
+        if shapes:                                                          # legacy 4-D blobs keep Caffe's leading ones
+            assert (w.shape, b.shape) == shapes
+        else:
+            assert w.shape == want_w.shape and b.shape == want_b.shape
+        assert np.array_equal(w.reshape(-1), want_w.reshape(-1)) and np.array_equal(b.reshape(-1), want_b.reshape(-1))
+
+
+@pytest.mark.parametrize("tag", ["packed", "unpacked"])
+def test_reader_on_protobuf_encoded_v1_layers(tag):
+    """NetParameter.layers (field 2, V1LayerParameter: name = 4, blobs = 6) -- the format of models saved before Caffe's
+    LayerParameter rewrite; evaluation.init_caffe loads whichever the file holds."""
+    g = _proto_fixtures()
+    layers = caffe_io.parse_caffemodel(g["net_v1_" + tag].tobytes())
+    assert sorted(layers) == ["conv1", "fc8_20x20"]
+    assert layers["conv1"][0].shape == (4, 1, 3, 3) and np.array_equal(layers["conv1"][0], g["want_conv1_w"])
+    assert layers["conv1"][1].shape == (1, 1, 1, 4) and np.array_equal(layers["conv1"][1].reshape(-1), g["want_conv1_b"])
+    assert layers["fc8_20x20"][0].shape == (1, 1, 3, 5) and np.array_equal(layers["fc8_20x20"][0].reshape(3, 5), g["want_fc8_w"])
+    assert layers["fc8_20x20"][1].shape == (3,) and np.array_equal(layers["fc8_20x20"][1], g["want_fc8_b"])
+
+
+@pytest.mark.parametrize("form", ["legacy", "shape", "double"])
+@pytest.mark.parametrize("tag", ["packed", "unpacked"])
+def test_reader_on_protobuf_encoded_mean_blobs(form, tag):
+    """mean.binaryproto = one BlobProto (evaluation.py:25-31 turns it into a (1, 1, H, W) array)."""
+    g = _proto_fixtures()
+    got = caffe_io.parse_binaryproto(g["mean_%s_%s" % (form, tag)].tobytes())
+    assert got.shape == (1, 1, 6, 7) and got.dtype == np.float32 and np.array_equal(got, g["want_mean"])
+
+
+def test_own_writer_matches_the_protobuf_encoding():
+    """caffe_io's writer (BlobShape + packed data) must produce what google.protobuf produces for the same blob: the two
+    encodings of the mean are compared byte for byte."""
+    g = _proto_fixtures()
+    assert caffe_io._enc_blob(g["want_mean"]) == g["mean_shape_packed"].tobytes()

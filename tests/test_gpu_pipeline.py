@@ -202,6 +202,71 @@ def test_bench_ranks_sharing_one_gpu(ranks):
     assert line["host_threads_per_rank"] * ranks <= (os.cpu_count() or 1) or line["host_threads_per_rank"] == 1
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_on_the_rccl_backend_one_rank():
+    """The code path the driver's N > 1 runs take, with the backend they take it with: bench.py --force-dist initialises
+    torch.distributed with the default backend "nccl" (= RCCL) on this box's one GPU -- process group bound to the device,
+    dist.barrier() inside the runtime's stream context, the per-step all_gather of the device-resident records on an EM
+    lane's stream, the all_gather of the ranks' elapsed times, RCCL's banner flushed before the JSON line -- as a child
+    process.  (Every multi-rank test on this box forces gloo: RCCL refuses several ranks on one device.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VPK_DIST_BACKEND")}
+    env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--images", "12", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]     # ONE JSON line, and it is the last line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["steps"] == 3 and line["value"] > 0
+    g = line["gather"]
+    assert g["backend"] == "nccl" and g["records"] == 12 and g["image_ids_complete"] is True
+    from vanishing_points_2017_amd import sharding
+    assert g["width"] == sharding.REC_WIDTH
+    assert line["em_stats"]["ok_images"] == 12 and line["parity"]["all_criteria"] == 12
+    assert line["alt_precision"]["value"] > 0 and line["from_lines"]["results_equal_unpipelined_pass"] is True   # their gathers too
+
+
+def test_sharded_benchmark_on_the_rccl_backend_one_rank(tmp_path):
+    """benchmark.py --hlw --synthetic launched the way an 8-GPU run launches it (torch.distributed.run) with ONE rank and
+    the default nccl backend: process group on the device, barriers, the ragged record gather on GPU tensors
+    (sharding.gather_records), AUC on rank 0 -- the same AUC as without torch.distributed, and a clean exit."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VPK_DIST_BACKEND")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = ["--hlw", "--synthetic", "--count", "40", "--update_datafiles", "--run_em"]
+    one = subprocess.run([sys.executable, "-m", "vanishing_points_2017_amd.benchmark", "--result_dir", str(tmp_path / "one")] + args,
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "vanishing_points_2017_amd.benchmark",
+                          "--result_dir", str(tmp_path / "two"), "--force-dist"] + args,
+                         capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    assert "records gathered over nccl" in two.stdout
+    auc1 = float(re.search(r"AUC:\s+([0-9.eE+-]+)", one.stdout).group(1))
+    auc2 = float(re.search(r"AUC:\s+([0-9.eE+-]+)", two.stdout).group(1))
+    assert auc1 == auc2 and 0.5 < auc1 <= 1.0
+
+
 def test_pipeline_step_equals_separate_calls():
     """vpk_pipeline_step (CNN -> EM of one batch enqueued by one host call, on two streams) against vpk_cnn_forward
     followed by vpk_em_batch: the same response maps and the same EM outputs, bit for bit; its records are

@@ -34,6 +34,9 @@ def build_parser():
     p.add_argument('--run_em', dest='run_em', action='store_true', help='Run EM refinement on the data')
     p.add_argument('--synthetic', action='store_true', help='use the seeded synthetic set of the dataset shape')
     p.add_argument('--count', type=int, default=None, help='number of synthetic images (default: dataset size)')
+    p.add_argument('--force-dist', action='store_true',
+                   help='initialise torch.distributed (RCCL unless VPK_DIST_BACKEND says otherwise) even with one rank: the N > 1 '
+                        'code path -- process group, barriers, the record gather on the GPU -- on a one-GPU box')
     p.add_argument('--gpus', type=int, default=1,
                    help='GPUs of this node to shard the images over (one process per GPU; results gathered with one '
                         'RCCL all_gather).  Without a launcher environment the ranks are started as child processes.')
@@ -165,10 +168,14 @@ def main(argv=None):
     dist = None
     device = args.gpu
     backend = os.environ.get("VPK_DIST_BACKEND", "nccl")      # "gloo": ranks may share a GPU (tests on a one-GPU box)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         device = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(device)
         if backend == "nccl":
@@ -199,7 +206,7 @@ def main(argv=None):
     auc, errors, _ = run_sharded(dataset, rank, world, dist, device=device, start=start, run_em=args.run_em,
                                  gather_on=tdev)
     if rank == 0:
-        print("EM + scoring time (%d rank(s)): " % world, time.time() - t0)
+        print("EM + scoring time (%d rank(s)%s): " % (world, "" if dist is None else ", records gathered over " + backend), time.time() - t0)
         print("AUC: ", auc)
     if dist is not None:
         dist.barrier()

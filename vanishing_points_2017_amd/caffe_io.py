@@ -10,7 +10,10 @@ numbers are those of upstream BVLC caffe.proto (they are not in the reference re
   BlobProto:         num=1, channels=2, height=3, width=4, data=5 (packed float), shape=7,
                      double_data=8 (packed double)
   BlobShape:         dim=1 (packed int64)
-A writer for the same subset exists so tests can round-trip files without Caffe.
+A writer for the same subset exists so tests can round-trip files without Caffe; the reader is also pinned against files
+encoded by Google's protobuf runtime from upstream's field numbers (tests/golden/caffe_proto.npz, written by
+oracle/make_caffe_proto_fixtures.py: `layer` and V1 `layers` messages, packed and unpacked arrays, legacy 4-D dims,
+double_data, BlobShape).
 """
 import re
 import struct
@@ -91,7 +94,12 @@ def _parse_blob(buf):
 
 def read_caffemodel(path):
     """{layer name: [blob arrays]} for every layer that carries blobs."""
-    buf = memoryview(open(path, "rb").read())
+    return parse_caffemodel(open(path, "rb").read())
+
+
+def parse_caffemodel(data):
+    """read_caffemodel on the file's bytes (a serialised NetParameter)."""
+    buf = memoryview(data)
     layers = {}
     for fnum, wt, val in _fields(buf):
         if wt != 2 or fnum not in (2, 100):
@@ -111,7 +119,12 @@ def read_caffemodel(path):
 
 def read_binaryproto(path):
     """mean.binaryproto -> ndarray shaped like caffe.io.blobproto_to_array (num, channels, h, w)."""
-    arr = _parse_blob(memoryview(open(path, "rb").read()))
+    return parse_binaryproto(open(path, "rb").read())
+
+
+def parse_binaryproto(data):
+    """read_binaryproto on the file's bytes (a serialised BlobProto)."""
+    arr = _parse_blob(memoryview(data))
     if arr.ndim == 3:
         arr = arr[None]
     return arr
@@ -137,7 +150,7 @@ def _enc_ld(fnum, payload):
 def _enc_blob(arr):
     arr = np.ascontiguousarray(arr, dtype="<f4")
     shape = _enc_ld(1, b"".join(_enc_varint(int(d)) for d in arr.shape))
-    return _enc_ld(7, shape) + _enc_ld(5, arr.tobytes())
+    return _enc_ld(5, arr.tobytes()) + _enc_ld(7, shape)      # field-number order, as protobuf serialises it
 
 
 def write_binaryproto(path, arr):
