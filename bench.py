@@ -78,9 +78,10 @@ def parse():
     ap.add_argument("--cnn-algorithm", type=int, default=1, choices=[0, 1],
                     help="conv2..5: 1 = Winograd minimal filtering, F(2x2,5x5) / F(2x2,3x3), on the f32 matrix cores (default, the "
                          "library's default), 0 = direct implicit GEMM (vpk_cnn_set_algorithm)")
-    ap.add_argument("--cnn-fusion", type=int, default=1, choices=[0, 1, 2],
-                    help="conv1 + norm1 + pool1: 1 = direct-convolution kernel (default), 2 = implicit-GEMM kernel with the fused "
-                         "epilogue, 0 = separate kernels")
+    ap.add_argument("--cnn-fusion", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="conv1 + norm1 + pool1: 3 = direct convolution on the bf16 matrix cores with exact operands (uint8 raster = one "
+                         "bf16 piece, weights = three; default), 1 = direct convolution on the f32 matrix cores, 2 = implicit-GEMM "
+                         "kernel with the fused epilogue, 0 = separate kernels")
     ap.add_argument("--cnn-priority", type=int, default=0, choices=[-1, 0],
                     help="HIP stream priority of the CNN stream (-1 = high: its kernels' workgroups are dispatched ahead of the EM lanes')")
     ap.add_argument("--force-dist", action="store_true",

@@ -7,7 +7,7 @@ rt = get_runtime(0)
 net = cnn.Net(cnn.synthetic_weights(0), cnn.synthetic_mean(0))
 net.set_profiling(True)
 import os
-net.set_fusion(int(os.environ.get("VPK_FUSION", "1")))
+net.set_fusion(int(os.environ.get("VPK_FUSION", "3")))
 net.set_precision(int(os.environ.get("VPK_PRECISION", "0")))
 net.set_algorithm(int(os.environ.get("VPK_ALGORITHM", "1")))
 args = sys.argv[1:]

@@ -77,13 +77,47 @@ def test_fused_first_stage_equals_separate_kernels(net_and_ref):
     net, sphere, ref, taps = net_and_ref
     net.set_fusion(0)
     out_s, pool_s = net.forward(sphere, tap=1)
-    for mode in (1, 2):                # 1: direct-convolution kernel (default), 2: implicit-GEMM kernel with the fused epilogue
-        net.set_fusion(mode)
+    for mode in (1, 2, 3):             # 1: direct f32 kernel, 2: implicit-GEMM kernel with the fused epilogue, 3 (default): direct
+        net.set_fusion(mode)           #    kernel on the bf16 matrix cores with exact operands (cnn_conv1_pieces.hpp)
         out_f, pool_f = net.forward(sphere, tap=1)
         # (separate compilations and, for mode 1, another summation order over the 121 taps)
         assert np.abs(pool_f - pool_s).max() <= 2e-5 * (1 + np.abs(pool_s).max()), mode
-        assert np.abs(out_f - out_s).max() <= 2e-6, mode
-    net.set_fusion(1)
+        # (mode 3 rounds differently -- exact products, one accumulator rounding per 32 of them -- and every later layer amplifies it)
+        assert np.abs(out_f - out_s).max() <= (2e-6 if mode != 3 else 6e-6), mode
+    net.set_fusion(3)
+
+
+def test_conv1_on_exact_bf16_pieces_against_the_float64_net():
+    """vpk_cnn_set_fusion(3), the default first stage: conv1 as THREE bf16 matrix products per f32 product -- the uint8 raster
+    is exact in one bf16 piece, each weight in three, `- mean` is a constant map added to the accumulators
+    (cnn_conv1_pieces.hpp).  Measured against the SAME net evaluated in float64, beside the f32-input direct kernel
+    (vpk_cnn_set_fusion(1)): at pool1 (what the stage writes) and at the output its error must not exceed the f32
+    kernel's (the rule for a layer on bf16 pieces: factor 1, plus 2^-24 of the blob's scale for ties), at B = 3 and at an
+    odd batch of 11 that ends inside a work item's group of images."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, sphere_mapping, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    net = cnn.Net(w, mean)
+    report = {}
+    try:
+        for batch in (3, 11):
+            sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=batch, start=20)])
+            ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
+            want = taps[cnn_torch.TAPS[1]]
+            scale = float(np.abs(want).max())
+            err = {}
+            for mode in (1, 3):
+                net.set_fusion(mode)
+                out, got = net.forward(sphere, tap=1)
+                err[mode] = (float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(out - ref).max()))
+            report[batch] = (err, scale)
+            assert err[3][0] <= 2e-5 * scale, (batch, err, scale)
+            assert err[3][0] <= err[1][0] + 6e-8 * scale, (batch, err, scale)
+            assert err[3][1] <= 2e-5 and err[1][1] <= 2e-5
+    finally:
+        net.set_fusion(3)
+    print({k: ([round(e[0] / v[1], 9) for e in v[0].values()]) for k, v in report.items()})
 
 
 def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
@@ -163,9 +197,9 @@ def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_
     rt.synchronize()
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-5
-    net.set_fusion(False)
+    net.set_fusion(0)
     unf = net.forward(sphere)
-    net.set_fusion(True)
+    net.set_fusion(3)
     assert np.abs(got - unf).max() <= 2e-5
 
 

@@ -80,8 +80,9 @@ class Net(object):
                   "conv4": 2 * 384 * 900 * 1728, "conv5": 2 * 256 * 900 * 1728, "fc6": 2 * 57600 * 4096,
                   "fc7": 2 * 4096 * 4096, "fc8": 2 * 4096 * 400}
 
-    def set_fusion(self, on=True):
-        """conv1 + norm1 + pool1 as one kernel (default) or as separate kernels."""
+    def set_fusion(self, on=3):
+        """conv1 + norm1 + pool1: 3 (default) one kernel on the bf16 matrix cores with exact operands, 1 one kernel on the f32
+        matrix cores, 2 the implicit-GEMM kernel with the fused epilogue, 0 separate kernels (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
     def set_algorithm(self, mode):

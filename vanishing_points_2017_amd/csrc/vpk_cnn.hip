@@ -954,6 +954,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 #include "cnn_split_gemm.hpp"
+#include "cnn_conv1_pieces.hpp"
 #include "cnn_winograd.hpp"
 
 struct Layer {
@@ -964,6 +965,8 @@ struct Layer {
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
     SplitDims sd;
     float* wino = nullptr;      // conv2..5: G g G^T in the chunk order of the Winograd kernels (cnn_winograd.hpp)
+    unsigned short* c1frag = nullptr;   // conv1: three bf16 pieces of every weight in MFMA fragment order (cnn_conv1_pieces.hpp)
+    float* c1map = nullptr;     // conv1: bias - conv1(mean), 123 x 123 x 96
     WinoDims wd;
     Wino5Dims wd5;
 };
@@ -984,7 +987,9 @@ struct vpk_cnn_state {
     int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
     int algorithm = 1;       // vpk_cnn_set_algorithm: 1 (default) = conv3..5 by Winograd F(2 x 2, 3 x 3) (native precision only)
-    int fuse_conv1 = 1;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct, 2 = GEMM-fused
+    int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
+                             // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
+    int conv1_group = 4;     // images per work item of conv1_pieces_kernel (VPK_CONV1_GROUP: development knob)
     bool profiling = false;
     static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
     hipEvent_t ev[EV_RING][14] = {};
@@ -1001,6 +1006,8 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.ktab) (void)hipFree(l.ktab);
         if (l.wsplit) (void)hipFree(l.wsplit);
         if (l.wino) (void)hipFree(l.wino);
+        if (l.c1frag) (void)hipFree(l.c1frag);
+        if (l.c1map) (void)hipFree(l.c1map);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
@@ -1151,7 +1158,12 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     } else {
         // conv1 + relu1 + norm1 + pool1 in one kernel: 21 x 8 patches of 7 x 17 conv outputs per image, straight into
         // pool1's planes (with conv2's border of 2); the conv1 blob only exists when a caller taps it
-        if (S->fuse_conv1 == 2) {                         // the implicit-GEMM kernel with the fused epilogue (kept for comparison)
+        if (S->fuse_conv1 == 3) {                         // exact bf16 pieces on the bf16 matrix cores (cnn_conv1_pieces.hpp)
+            const int group = S->conv1_group;
+            const int total = C1B_PATCHES * ((batch + group - 1) / group);
+            hipLaunchKernelGGL(conv1_pieces_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
+                               S->L[0].c1frag, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, ctr + 0, total);
+        } else if (S->fuse_conv1 == 2) {                  // the implicit-GEMM kernel with the fused epilogue (kept for comparison)
             ConvDims df = dims(0);
             df.N = batch * C1_TR * C1_TC * 128;           // one 128-column tile per patch
             df.OHp = 65; df.OWp = 65; df.opad = 2;
@@ -1304,7 +1316,7 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
 
 int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
-    h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 2 ? 1 : on);
+    h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 3 ? 3 : on);
     return VPK_OK;
 }
 
@@ -1436,6 +1448,17 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                             }
             VPK_HIP(h, hipMalloc((void**)&l.wsplit, pk.size() * sizeof(unsigned short)));
             VPK_HIP(h, hipMemcpy(l.wsplit, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
+        if (li == 0) {              // conv1 on the bf16 matrix cores: weight pieces in fragment order, bias - conv1(mean)
+            std::vector<unsigned short> fr;
+            conv1_pieces_weights(blobs[0], fr);
+            VPK_HIP(h, hipMalloc((void**)&l.c1frag, fr.size() * sizeof(unsigned short)));
+            VPK_HIP(h, hipMemcpy(l.c1frag, fr.data(), fr.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            std::vector<float> cm;
+            conv1_pieces_cmap(blobs[0], blobs[1], mean, cm);
+            VPK_HIP(h, hipMalloc((void**)&l.c1map, cm.size() * sizeof(float)));
+            VPK_HIP(h, hipMemcpy(l.c1map, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (const char* e = getenv("VPK_CONV1_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) S->conv1_group = v; }
         }
         if (li == 1) {              // conv2: G g G^T of every 5 x 5 filter (F(2 x 2, 5 x 5))
             std::vector<float> u;
