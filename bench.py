@@ -75,9 +75,10 @@ def parse():
     ap.add_argument("--cnn-precision", type=int, default=0, choices=[0, 1],
                     help="0: native f32 matrix instructions (default); 1: conv2..5 as six bf16 matrix products per f32 "
                          "product (vpk_cnn_set_precision, same error class; reported as its own dtype)")
-    ap.add_argument("--cnn-algorithm", type=int, default=1, choices=[0, 1],
-                    help="conv2..5: 1 = Winograd minimal filtering, F(2x2,5x5) / F(2x2,3x3), on the f32 matrix cores (default, the "
-                         "library's default), 0 = direct implicit GEMM (vpk_cnn_set_algorithm)")
+    ap.add_argument("--cnn-algorithm", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="conv2..5: 2 = conv2 direct on exact bf16 pieces + conv3..5 Winograd F(2x2,3x3) on the f32 matrix cores (default, the "
+                         "library's default), 1 = Winograd everywhere (conv2: F(2x2,5x5)), 0 = direct implicit GEMM on the f32 matrix cores "
+                         "(vpk_cnn_set_algorithm)")
     ap.add_argument("--cnn-fusion", type=int, default=3, choices=[0, 1, 2, 3],
                     help="conv1 + norm1 + pool1: 3 = direct convolution on the bf16 matrix cores with exact operands (uint8 raster = one "
                          "bf16 piece, weights = three; default), 1 = direct convolution on the f32 matrix cores, 2 = implicit-GEMM "
@@ -358,10 +359,7 @@ def hlw_pass(local_rank):
            "em_roofline": {"bound": "hbm", "achieved": b_em / em_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": b_em / em_s / 1e9 / HBM_PEAK_GBS,
                            "note": "B_EM (SURVEY 8d) of the 2018 images / the launch's wall time (host clock around a synchronised launch)"},
-           "cnn_roofline": {"bound": "mfma", "achieved": sum(net.LAYER_FLOP.values()) * len(scenes) / cnn_s / 1e12,
-                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": sum(net.LAYER_FLOP.values()) * len(scenes) / cnn_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                            "note": "whole net (6.73 GFLOP per image) x 2018 images / the forward's wall time, nothing beside it"},
+           "cnn_roofline": hlw_cnn_roofline(net, len(scenes), cnn_s),
            "horizon_auc": float(auc_mod.calc_auc(errs.copy(), cutoff=0.25)[0]),
            "rasters_equal_untimed_pass": rasters_same,
            "setup_s_outside_timing": setup_s,
@@ -396,6 +394,20 @@ def hlw_pass(local_rank):
     return res
 
 
+def hlw_cnn_roofline(net, images, cnn_s):
+    """Whole-net figure of the HLW pass's forward (library defaults): the time the matrix pipes would need at their peaks for what
+    the kernels execute / the forward's wall time -- a fraction of a bound, never above 1; the algorithmic rate beside it."""
+    pipe_s, ex = 0.0, {"f32": 0.0, "bf16": 0.0}
+    for lname in net.LAYER_FLOP:
+        f_, p_ = net.executed_flop(lname, batch=101)           # (the forward runs in chunks of ~100 images)
+        ex[p_] += f_ * images / 1e12
+        pipe_s += f_ * images / ((MFMA_F32_PEAK_TFLOPS if p_ == "f32" else MFMA_BF16_PEAK_TFLOPS) * 1e12)
+    return {"bound": "mfma", "frac": pipe_s / cnn_s, "executed_tflop_f32_mfma": ex["f32"], "executed_tflop_bf16_mfma": ex["bf16"],
+            "direct_equivalent_tflops": sum(net.LAYER_FLOP.values()) * images / cnn_s / 1e12, "unit": "TFLOP/s",
+            "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF) / the forward's wall time, nothing "
+                    "beside it; direct_equivalent_tflops = 6.73 GFLOP per image (SURVEY 8d) x images / the same time"}
+
+
 def extra_workloads(args, local_rank):
     """The other two BASELINE workloads, after the headline run (one GPU, default invocation only)."""
     import copy
@@ -406,7 +418,12 @@ def extra_workloads(args, local_rank):
     a.em_wgs, a.cnn_precision = -1, 0
     s = run_workload(a, None, 0, local_rank, 1)
     out["stress"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "stage_ms",
-                                       "cnn_layer_ms", "em_stats", "roofline", "roofline_secondary")}
+                                       "cnn_layer_ms", "em_stats", "roofline")}
+    out["stress"]["roofline_secondary"] = {
+        "kernel": s["roofline_secondary"]["kernel"], "achieved": None, "frac": None,
+        "note": "not reported for this shape: the EM holds every CU, so the CNN's kernels run parked behind it (in a kernel trace of this run "
+                "conv2's launch lasts as long as the EM launch it waits for) and a per-layer rate from the stream's events describes the "
+                "moments the layer had the CUs, not the step; the CNN's rates are the headline workload's (roofline / cnn_stream above)"}
     layers = sum(s["cnn_layer_ms"].values())
     out["stress"]["overlap"] = {
         "cnn_layers_sum_ms": layers, "em_kernel_ms": s["stage_ms"]["em"], "step_ms": s["ms_per_step"],
@@ -419,6 +436,36 @@ def extra_workloads(args, local_rank):
                 "layer's rate when it had the CUs, not the CNN's share of the step"}
     out["hlw"] = hlw_pass(local_rank)
     return out
+
+
+def cnn_algorithm_text(args):
+    c1 = {3: "conv1: direct on the bf16 matrix cores, exact operands (uint8 raster = 1 bf16 piece, weights = 3 pieces: 3 products per f32 product)",
+          1: "conv1: direct on v_mfma_f32", 2: "conv1: implicit GEMM on v_mfma_f32", 0: "conv1: implicit GEMM on v_mfma_f32, separate LRN / pool"}[args.cnn_fusion]
+    if args.cnn_precision == 1:
+        rest = "conv2-5: implicit GEMM on exact bf16 pieces (6 bf16 products per f32 product)"
+    elif args.cnn_algorithm >= 2:
+        rest = ("conv2: direct on exact bf16 pieces (3 + 3 pieces, 6 bf16 products per f32 product, block sums rounded once per kernel row x 16 "
+                "channels); conv3-5: Winograd F(2x2,3x3) on v_mfma_f32")
+    elif args.cnn_algorithm == 1:
+        rest = "conv2: Winograd F(2x2,5x5), conv3-5: Winograd F(2x2,3x3), on v_mfma_f32"
+    else:
+        rest = "conv2-5: implicit GEMM on v_mfma_f32"
+    return c1 + "; " + rest + "; fc6-8: v_mfma_f32; f32 operands, f32 accumulation and f32 results throughout"
+
+
+def dtype_text(args):
+    bf = []
+    if args.cnn_fusion == 3:
+        bf.append("conv1")
+    if args.cnn_precision == 1:
+        bf.append("conv2-5")
+    elif args.cnn_algorithm >= 2:
+        bf.append("conv2")
+    if not bf:
+        return "f32 (CNN, MFMA) + f64 (EM)"
+    return ("f32 (CNN: f32 operands / accumulation / results; %s multiply EXACT bf16 pieces of the f32 operands on the bf16 matrix cores -- "
+            "error against float64 no larger than the f32-input kernels' at any tap, tests/test_gpu_cnn.py; the other layers on v_mfma_f32) "
+            "+ f64 (EM)" % " and ".join(bf))
 
 
 _NETS = {}
@@ -750,53 +797,37 @@ def run_workload(args, dist, rank, local_rank, world):
                            "iterations + 1 initial + 4 in the finalisation; evaluations_I = its mean; SURVEY's figure for the stress "
                            "unit takes I = 50, this run's is 54) / mean kernel time of the timed steps, measured on overlapped streams; "
                            "traffic = HBM bytes per launch from the PMC passes"}
-        name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])   # the layer with the most arithmetic (conv2)
-        flop = cnn.Net.LAYER_FLOP[name] * count          # ALGORITHMIC flops of the layer: 2 x MACs of the direct convolution
-        wino = args.cnn_algorithm == 1 and args.cnn_precision == 0
-        kname = "conv5x5_winograd_kernel" if wino else "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0"
-        roof_cnn = {"kernel": "%s(%s)" % ("conv5x5_winograd_kernel" if wino else "conv_gemm_dma_kernel<2,2,2,2>", name), "bound": "mfma",
-                    "achieved": flop / (layer_ms[name] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s",
-                    "traffic": None,
-                    "note": "achieved = the layer's algorithmic flops (2 x MACs of the direct convolution, SURVEY 8d) / its mean "
-                            "duration over the timed steps (HIP events on the CNN stream, %d passes), i.e. with whatever ran "
-                            "beside it" % layer_passes}
-        if wino:
-            # F(2 x 2, 5 x 5): 36 matrix-core products stand for 100 of the direct form.  What the matrix pipe executes is
-            # 0.36 x the algorithmic count; the rest of the kernel's time is the 6 x 6 transforms (VALU, which f32 MFMAs do
-            # not overlap with on a SIMD) and the output transform through LDS
-            roof_cnn["matrix_core_tflops"] = 0.36 * roof_cnn["achieved"]
-            roof_cnn["matrix_core_frac"] = 0.36 * roof_cnn["achieved"] / MFMA_F32_PEAK_TFLOPS
-            roof_cnn["note"] += ("; Winograd F(2x2,5x5): the matrix cores execute 36/100 of the algorithmic products "
-                                 "(matrix_core_tflops = what they actually deliver), so `frac` is the direct-equivalent rate "
-                                 "against the f32-MFMA peak and may pass 1")
-        tkey = (key + ("_conv2w" if wino else "_conv")) if key else None
-        tc = traffic.get(tkey) if tkey else None
-        if tc:
-            roof_cnn["traffic"] = tc["hbm_read_bytes"] + tc["hbm_write_bytes"]
-            roof_cnn["traffic_note"] = "HBM bytes per launch of this kernel (--pmc FETCH_SIZE / WRITE_SIZE passes)"
-        if args.cnn_precision == 1:     # conv2 on the bf16 matrix cores: six bf16 MFMA products per f32 product
-            roof_cnn.update({"kernel": "conv_gemm_split_kernel(%s)" % name, "achieved": 6.0 * roof_cnn["achieved"],
-                             "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                             "f32_equivalent_tflops": roof_cnn["achieved"],
-                             "note": "achieved = bf16 MFMA flops issued (6 x the layer's f32 flops) / live layer time, which "
-                                     "here includes the split pass of the layer's input (split_nhwc_kernel)"})
+        # ---- the CNN stream's dominant kernel: conv2's (the layer with the most arithmetic and the longest kernel).  `achieved` and
+        #      `frac` count what the matrix pipes EXECUTE (tile padding, Winograd's product count, the six bf16 products per f32
+        #      product included) against the peak of the instruction type the kernel issues -- a distance to that kernel's own bound,
+        #      never above 1; the layer's algorithmic rate (2 x MACs of the direct convolution) is `direct_equivalent_tflops`
+        name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])
+        setting = dict(fusion=args.cnn_fusion, precision=args.cnn_precision, algorithm=args.cnn_algorithm, batch=count)
+        peak_of = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS}
+        ex_flop, pipe = cnn.Net.executed_flop(name, **setting)
+        if args.cnn_precision == 1:
+            kname, klabel = "conv_gemm_split_kernel", "conv_gemm_split_kernel(conv2)"
+        elif args.cnn_algorithm >= 2:
+            kname, klabel = "conv_pieces_kernelILi5E", "conv_pieces_kernel<5>(conv2)"
+        elif args.cnn_algorithm == 1:
+            kname, klabel = "conv5x5_winograd_kernel", "conv5x5_winograd_kernel(conv2)"
+        else:
+            kname, klabel = "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0", "conv_gemm_dma_kernel<2,2,2,2>(conv2)"
+        roof_cnn = {"kernel": klabel, "bound": "mfma", "matrix_instruction": "v_mfma_f32_32x32x16_bf16" if pipe == "bf16" else "v_mfma_f32_32x32x2_f32",
+                    "achieved": ex_flop * count / (layer_ms[name] * 1e-3) / 1e12, "peak": peak_of[pipe], "unit": "TFLOP/s", "traffic": None,
+                    "direct_equivalent_tflops": cnn.Net.LAYER_FLOP[name] * count / (layer_ms[name] * 1e-3) / 1e12,
+                    "executed_gflop_per_launch": ex_flop * count / 1e9,
+                    "note": "achieved = matrix-core flops the kernel executes per launch (cnn.Net.executed_flop: %s) / the layer's mean duration "
+                            "over the timed steps (HIP events on the CNN stream, %d passes; includes the layer's input conversion kernel), "
+                            "i.e. with whatever ran beside it; peak = dense peak of that instruction type; direct_equivalent_tflops = the "
+                            "layer's algorithmic flops (2 x MACs of the direct f32 convolution, SURVEY 8d) over the same time"
+                            % ("6 bf16 products per f32 product on 4 x 32-pixel tiles" if pipe == "bf16" else "f32 products", layer_passes)}
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
+        tc = traffic.get(key + "_conv2") if key else None        # HBM bytes per launch of THIS kernel (--pmc FETCH_SIZE / WRITE_SIZE passes)
+        if tc and tc.get("kernel", "") in klabel:
+            roof_cnn["traffic"] = tc["hbm_read_bytes"] + tc["hbm_write_bytes"]
         roof_cnn["traffic_source"] = traffic_src
-        pm = None
-        if args.workload == "yud" and args.cnn_precision == 0:
-            for k_, v_ in (mfma.get("bench_yud_102") or {}).items():
-                if ("winograd5" in k_ or "conv5x5" in k_) if wino else ("conv_gemm_dma<2,2,2,2>" in k_):
-                    pm = v_
-        if pm:
-            # Counter view of this kernel from the --pmc pass of the bench command.  A --pmc pass SERIALISES dispatches: the
-            # kernel ran with nothing beside it, so this is the kernel alone at the clock the run's power state gave it --
-            # matrix-pipe busy fraction and shader clock (the 157.3 TF peak assumes 2.4 GHz) -- and says nothing about
-            # co-running with the EM; the live `achieved` above is the co-running figure.
-            roof_cnn["pmc_serialised_pass"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"],
-                                               "source": mfma_src,
-                                               "note": "rocprofv3 --pmc serialises dispatches: kernel alone, not beside the EM"}
-        # the same kernel without the EM beside it: kernel-trace of the CNN alone (scripts/time_cnn.py, 12 timed passes)
+        # the same kernel without the EM beside it: kernel trace of the CNN alone (scripts/time_cnn.py; profiles/rNN_cnn_kernel_stats.csv)
         import csv
         import glob
         traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cnn_kernel_stats.csv")))
@@ -805,13 +836,33 @@ def run_workload(args, dist, rank, local_rank, world):
                 rows = list(csv.DictReader(open(traces[-1])))
                 avg_us = [float(r["AverageUs"]) for r in rows if kname in r["Name"]]
                 if avg_us:
-                    fl = flop if wino else sum(cnn.Net.LAYER_FLOP[k] for k in ("conv2", "conv3", "conv5")) * count / 3.0
-                    roof_cnn["alone"] = {"achieved": fl / (avg_us[0] * 1e-6) / 1e12, "unit": "TFLOP/s",
-                                         "frac": fl / (avg_us[0] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    a_tf = ex_flop * count / (avg_us[0] * 1e-6) / 1e12
+                    roof_cnn["alone"] = {"achieved": a_tf, "unit": "TFLOP/s", "frac": a_tf / peak_of[pipe], "kernel_us": avg_us[0],
                                          "source": os.path.relpath(traces[-1], ROOT),
-                                         "note": "average launch of the kernel in the kernel trace of the CNN alone"}
+                                         "note": "average launch of the kernel in the kernel trace of the CNN alone (executed flops, as above)"}
             except (OSError, ValueError, KeyError):
                 pass
+        pm = None
+        if args.workload == "yud" and args.cnn_precision == 0:
+            for k_, v_ in (mfma.get("cnn_alone_B102") or {}).items():
+                if kname.split("IL")[0] in k_ and "conv2" in k_:
+                    pm = v_
+        if pm:
+            roof_cnn["pmc_serialised_pass"] = {"mfma_util": pm["mfma_util"], "shader_clock_ghz": pm["shader_clock_ghz"], "source": mfma_src,
+                                               "note": "SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles and GRBM_GUI_ACTIVE / duration from a rocprofv3 --pmc pass of "
+                                                       "the CNN alone (dispatches serialised)"}
+        # the whole CNN stream: time the matrix pipes would need at their peaks for what the net executes, against the stream's period
+        pipe_ms = 0.0
+        ex_tf = {"f32": 0.0, "bf16": 0.0}
+        for lname in cnn.Net.LAYER_FLOP:
+            f_, p_ = cnn.Net.executed_flop(lname, **setting)
+            ex_tf[p_] += f_ * count / 1e12
+            pipe_ms += f_ * count / (peak_of[p_] * 1e12) * 1e3
+        cnn_stream = {"period_ms": cnn_ms, "executed_tflop_f32_mfma": ex_tf["f32"], "executed_tflop_bf16_mfma": ex_tf["bf16"],
+                      "matrix_pipe_ms_at_peak": pipe_ms, "frac": pipe_ms / cnn_ms,
+                      "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF) / the CNN stream's period per step "
+                              "(HIP events around the forward on its stream, beside the EM): the share of the period the matrix pipes would be "
+                              "busy at their peak rates"}
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step, each EM
         # stream one batch every n_lanes steps; whichever takes longer per step
         roof = roof_em if (em_ms / n_lanes >= cnn_ms or args.workload == "stress") else roof_cnn
@@ -839,10 +890,8 @@ def run_workload(args, dist, rank, local_rank, world):
                          "header copy once five launches are queued on a handle",
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "cnn_algorithm": ("conv1, fc6-8: direct / implicit GEMM; conv2: Winograd F(2x2,5x5); conv3-5: Winograd F(2x2,3x3); all on "
-                              "v_mfma_f32 (f32 in, f32 accumulate)" if args.cnn_algorithm == 1 and args.cnn_precision == 0 else "direct / implicit GEMM"),
-            "dtype": "f32 (CNN, MFMA) + f64 (EM)" if args.cnn_precision == 0 else
-                     "f32 as 3 bf16 pieces x 6 bf16-MFMA products, f32 accumulate (conv2-5) + f32 MFMA (conv1, fc6-8) + f64 (EM)",
+            "cnn_algorithm": cnn_algorithm_text(args),
+            "dtype": dtype_text(args),
             "data": "synthetic (seeded line sets of the config's shape; their rasters made by vpk_sphere_raster = the reference's "
                     "own, hash-checked in 'parity'; random-init AlexNet-500 weights)",
             "config": {"workload": "configs[1] YUD-shape: %d images/GPU, N~U{100..400} lines, 3 VPs, CNN+EM"
@@ -864,6 +913,7 @@ def run_workload(args, dist, rank, local_rank, world):
                          "ok_images": int((status == 0).sum()), "lines_mean": float(n_lines.mean())},
             "roofline": roof,
             "roofline_secondary": roof_cnn if roof is roof_em else roof_em,
+            "cnn_stream": cnn_stream,
         }
         if fixture:
             line["value_fixture_prior"] = fixture["value"]

@@ -146,22 +146,35 @@ int vpk_cnn_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out)
 int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap,
                         float* tap_out);
 
-/* conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55) run as ONE kernel by default (the 96 x 123 x 123 conv1 blob is
- * never written); on = 0 selects the separate conv1 and LRN/pool kernels (also used whenever tap 0 is requested). */
-int vpk_cnn_set_fusion(vpk_handle* h, int on);
-/* Arithmetic of conv2..conv5 (the reference runs Caffe in fp32, deploy.prototxt:56-174):
- *   0 (default)  f32-input matrix instructions (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 FMA chain
+/* How the net's layers are computed.  The reference runs Caffe in fp32 (deploy.prototxt, evaluation.py:20: cuDNN's pick of
+ * algorithm per layer); every setting below keeps f32 operands, f32 accumulation and f32 results -- what changes is which matrix
+ * instruction multiplies and where the sums are rounded.  Each setting's error against the SAME net evaluated in float64 is
+ * measured by tests/test_gpu_cnn.py; the defaults are, at every tap, no further from it than the f32-input direct kernels.
+ *
+ * conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55):
+ *   3 (default)  ONE kernel on the bf16 matrix cores with EXACT operands: the uint8 raster is one bf16 piece, each weight the sum
+ *                of three, `- mean` (evaluation.py:35) a constant map made in float64 at load -- three bf16 products per f32
+ *                product, none of them rounded (csrc/cnn_conv1_pieces.hpp).  The 96 x 123 x 123 conv1 blob is never written.
+ *   1            ONE kernel on the f32-input matrix instructions (v_mfma_f32_16x16x4_f32: an f32 FMA chain over the 121 taps)
+ *   2            the implicit-GEMM kernel with the fused LRN / pooling epilogue
+ *   0            separate conv1 and LRN / pooling kernels (also used whenever tap 0 is requested) */
+int vpk_cnn_set_fusion(vpk_handle* h, int mode);
+/* Arithmetic of conv2..conv5 (deploy.prototxt:56-174) when vpk_cnn_set_algorithm is 0:
+ *   0 (default)  f32-input matrix instructions (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 FMA chain per output
  *   1            every f32 operand as the exact sum of three bf16 pieces, six bf16 matrix products per f32 product
- *                (everything above 2^-24 of the product), f32 accumulation -- same error class, see DESIGN.md */
+ *                (everything above 2^-24 of the product), f32 accumulation, implicit GEMM (csrc/cnn_split_gemm.hpp) */
 int vpk_cnn_set_precision(vpk_handle* h, int mode);
-/* Algorithm of conv3..conv5 (3 x 3, stride 1, pad 1; deploy.prototxt:104-174) in the native-f32 mode:
- *   1  (default) Winograd's minimal filtering F(2 x 2, 3 x 3): 16 instead of 36 f32 matrix-core products per 2 x 2 outputs
- *      and input channel, input / output transforms in f32.  Same arithmetic type and accumulation width as the direct
- *      form; the rounding differs (products of transformed operands) -- measured against a float64 evaluation of the net
- *      its error is no larger than the direct path's (tests/test_gpu_cnn.py: 0.7e-6 against 1.8e-6 of the blob's scale at
- *      conv3..5).  (What Caffe itself computes in the reference's GPU mode, evaluation.py:20, is cuDNN's choice among
- *      such algorithms.)
- *   0  direct: implicit GEMM over the 9 taps -- every output is one f32 FMA chain over (channel, tap) */
+/* Algorithm of conv2..conv5 (precision 0):
+ *   2  (default) conv2 (5 x 5, 2 x 48 -> 128 channels) as a DIRECT convolution on the bf16 matrix cores with exact operands --
+ *      three bf16 pieces per operand, six products per f32 product, the products of a kernel row x 16 channels summed from zero
+ *      and added to the accumulator with ONE rounding (csrc/cnn_conv_pieces.hpp; error against float64 0.2e-6 of the blob's
+ *      scale, the f32 direct kernel's is 1.0e-6) --; conv3..conv5 as in 1
+ *   1  Winograd's minimal filtering on the f32-input matrix instructions: conv2 by F(2 x 2, 5 x 5) (36 instead of 100 products per
+ *      2 x 2 outputs and input channel), conv3..conv5 by F(2 x 2, 3 x 3) (16 instead of 36); input / output transforms in f32.
+ *      Same arithmetic type and accumulation width as the direct form; the rounding differs (products of transformed
+ *      operands, shorter sums): error 0.6-0.8e-6 against 1.0-2.0e-6 for the direct kernels (csrc/cnn_winograd.hpp)
+ *   0  direct: implicit GEMM over the taps -- every output is one f32 FMA chain over (channel, tap)
+ *   3  (measurements) conv2, conv3 and conv5 as in 2's conv2, conv4 as in 1 */
 int vpk_cnn_set_algorithm(vpk_handle* h, int mode);
 
 /* per-layer device time of the last vpk_cnn_forward (single chunk), from HIP events recorded on

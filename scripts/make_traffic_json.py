@@ -45,7 +45,8 @@ def main(prof, out):
         f = per_kernel(first_db(os.path.join(prof, tag + "_fetch")))
         w = per_kernel(first_db(os.path.join(prof, tag + "_write")))
         for kname, short in (("em_batch_kernel", ""), ("conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0", "_conv"),
-                             ("conv5x5_winograd_kernel", "_conv2w"), ("conv3x3_winograd_kernel", "_conv3w")):
+                             ("conv5x5_winograd_kernel", "_conv2w"), ("conv3x3_winograd_kernel", "_conv3w"),
+                             ("conv_pieces_kernelILi5E", "_conv2"), ("conv1_pieces_kernel", "_conv1")):
             fk = [k for k in f if kname in k]
             wk = [k for k in w if kname in k]
             if not fk or not wk:
@@ -53,7 +54,8 @@ def main(prof, out):
             fs, ws = f[fk[0]].get("FETCH_SIZE", 0.0), w[wk[0]].get("WRITE_SIZE", 0.0)
             res[key + short] = {"kernel": {"": kname, "_conv": "conv_gemm_dma_kernel<2,2,2,2,false> (avg of its launches)",
                                            "_conv2w": "conv5x5_winograd_kernel (conv2)",
-                                           "_conv3w": "conv3x3_winograd_kernel (avg of conv3/4/5)"}[short],
+                                           "_conv3w": "conv3x3_winograd_kernel (avg of conv3/4/5)",
+                                           "_conv2": "conv_pieces_kernel<5>(conv2)", "_conv1": "conv1_pieces_kernel"}[short],
                                 "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws, "hbm_read_bytes": 2e3 * fs,
                                 "hbm_write_bytes": 1e3 * ws, "kernel_ms_profiled": f[fk[0]]["_ms"]}
     with open(out, "w") as fh:

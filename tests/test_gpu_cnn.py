@@ -148,7 +148,7 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
             assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
         net.set_precision(0)
-        net.set_algorithm(1)
+        net.set_algorithm(2)
 
 
 def test_split_path_beyond_4_gib_of_activations():
@@ -203,8 +203,43 @@ def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_
     assert np.abs(got - unf).max() <= 2e-5
 
 
+def test_default_path_is_no_further_from_the_float64_net_than_the_f32_direct_kernels():
+    """The rule for moving a layer onto bf16 pieces (or onto another algorithm): against the SAME net evaluated in float64 its
+    error must not exceed, at any tap, that of the f32-input DIRECT kernels (vpk_cnn_set_fusion(1), vpk_cnn_set_algorithm(0):
+    one f32 FMA chain per output) -- factor 1, plus 2^-24 of the blob's scale for ties.  The defaults: conv1 on exact bf16
+    pieces (cnn_conv1_pieces.hpp), conv2 direct on exact bf16 pieces with block sums (cnn_conv_pieces.hpp), conv3..5 Winograd
+    F(2 x 2, 3 x 3) on the f32 matrix cores, fc6..8 f32.  B = 3 and an odd batch of 7."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, sphere_mapping, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    net = cnn.Net(w, mean)
+    report = {}
+    try:
+        for batch in (3, 7):
+            sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=batch, start=10)])
+            ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
+            for tap in (1, 2, 3, 4, 5, 6, 8):                      # pool1, conv2, pool2, conv3, conv4, conv5, fc6
+                want = taps[cnn_torch.TAPS[tap]]
+                scale = float(np.abs(want).max())
+                err = {}
+                for name, (fusion, algorithm) in (("direct_f32", (1, 0)), ("default", (3, 2))):
+                    net.set_fusion(fusion)
+                    net.set_algorithm(algorithm)
+                    out, got = net.forward(sphere, tap=tap)
+                    err[name] = (float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(out - ref).max()))
+                report[(batch, cnn_torch.TAPS[tap])] = (err, scale)
+                assert err["default"][0] <= err["direct_f32"][0] + 6e-8 * scale, (batch, cnn_torch.TAPS[tap], err, scale)
+                assert err["default"][1] <= err["direct_f32"][1] + 6e-8, (batch, cnn_torch.TAPS[tap], err)
+                assert err["default"][1] <= 2e-5
+    finally:
+        net.set_fusion(3)
+        net.set_algorithm(2)
+    print({k: {n: round(e[0] / v[1], 9) for n, e in v[0].items()} for k, v in report.items()})
+
+
 def test_winograd_convolutions_against_the_float64_net():
-    """vpk_cnn_set_algorithm(1), the default: conv2 by Winograd F(2 x 2, 5 x 5) and conv3..5 by F(2 x 2, 3 x 3) on the f32 matrix
+    """vpk_cnn_set_algorithm(1): conv2 by Winograd F(2 x 2, 5 x 5) and conv3..5 by F(2 x 2, 3 x 3) on the f32 matrix
     cores (cnn_winograd.hpp).  Direct and Winograd paths are measured against the SAME net evaluated in float64 (B = 3 and
     an odd batch of 7 whose tiles end inside a workgroup's block): at conv2 / pool2 / conv3 / conv4 / conv5 / fc6 and at
     the output the Winograd path's error must stay within the bar of every other CNN test (2e-5 of the blob's scale at
@@ -232,5 +267,5 @@ def test_winograd_convolutions_against_the_float64_net():
                 assert err[1][0] <= 6.0 * err[0][0] + 1e-7 * scale, (batch, cnn_torch.TAPS[tap], err)
                 assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
-        net.set_algorithm(1)                                       # the library's default
+        net.set_algorithm(2)                                       # the library's default
     print({k: ([round(e[0] / v[1], 9) for e in v[0]]) for k, v in report.items()})

@@ -80,17 +80,41 @@ class Net(object):
                   "conv4": 2 * 384 * 900 * 1728, "conv5": 2 * 256 * 900 * 1728, "fc6": 2 * 57600 * 4096,
                   "fc7": 2 * 4096 * 4096, "fc8": 2 * 4096 * 400}
 
+    @classmethod
+    def executed_flop(cls, layer, fusion=3, precision=0, algorithm=2, batch=102):
+        """(matrix-core flops the kernels EXECUTE for `layer` per image, which pipe: "f32" or "bf16") under a setting -- tile padding,
+        Winograd's product count and the six (conv1: three) bf16 products per f32 product included; the roofline's numerator."""
+        alg = cls.LAYER_FLOP[layer]
+        if layer == "conv1":
+            if fusion == 3:      # 168 tiles x 12 waves x 72 v_mfma_f32_16x16x32_bf16 (cnn_conv1_pieces.hpp)
+                return 168 * 12 * 72 * 2.0 * 16 * 16 * 32, "bf16"
+            if fusion == 1:      # 168 tiles x 8 waves x 186 v_mfma_f32_16x16x4_f32
+                return 168 * 8 * 186 * 2.0 * 16 * 16 * 4, "f32"
+            return alg * 128.0 / 121.0, "f32"
+        if layer in ("conv2", "conv3", "conv4", "conv5"):
+            if precision == 1:
+                return 6.0 * alg, "bf16"
+            if layer == "conv2" and algorithm >= 2:      # 64 tiles x 4 waves x 75 steps x 24 v_mfma_f32_32x32x16_bf16
+                return 64 * 4 * 75 * 24 * 2.0 * 32 * 32 * 16, "bf16"
+            if algorithm >= 1:
+                return alg * (36.0 / 100.0 if layer == "conv2" else 16.0 / 36.0), "f32"
+            return alg, "f32"
+        pad = (-(-batch // 128) * 128) / float(batch)     # dense layers: 128-column tiles
+        return alg * pad, "f32"
+
     def set_fusion(self, on=3):
         """conv1 + norm1 + pool1: 3 (default) one kernel on the bf16 matrix cores with exact operands, 1 one kernel on the f32
         matrix cores, 2 the implicit-GEMM kernel with the fused epilogue, 0 separate kernels (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
     def set_algorithm(self, mode):
-        """conv3..5: 0 = direct implicit GEMM, 1 = Winograd F(2 x 2, 3 x 3) (include/vpk.h: vpk_cnn_set_algorithm)."""
+        """conv2..5: 2 (default) = conv2 direct on exact bf16 pieces + conv3..5 Winograd F(2 x 2, 3 x 3) on the f32 matrix cores,
+        1 = Winograd everywhere (conv2: F(2 x 2, 5 x 5)), 0 = direct implicit GEMM on the f32 matrix cores (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_algorithm(self.rt.h, int(mode)))
 
     def set_precision(self, mode):
-        """0 = native f32 matrix instructions; 1 = conv2..5 as six bf16 matrix products per f32 product (include/vpk.h)."""
+        """conv2..5 under set_algorithm(0): 0 = f32-input matrix instructions; 1 = implicit GEMM on exact bf16 pieces (include/vpk.h).
+        Mode 1 overrides the algorithm setting."""
         self.rt.check(self.rt.lib.vpk_cnn_set_precision(self.rt.h, int(mode)))
 
     def set_profiling(self, on=True):

@@ -229,6 +229,33 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WPE) void conv_gemm_split_k
                     bfr[p] = *reinterpret_cast<const bf16x8*>(stage + (NA + (wn * TN + j) * 3) * 1024 +
                                                               ((lane & 31) * 6 + p * 2 + (lane >> 5)) * 16);
                 // the six partial products, smallest first
+#ifdef SG_SMALL_SEPARATE
+                // (experiment) the five small products of a step are summed on their own -- from zero, so their roundings are
+                // 2^-8 of the accumulator's -- and join the accumulator with ONE addition: two roundings of the running sum per
+                // step instead of six
+                f32x16 tsm[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tsm[i][e] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tsm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[0], tsm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tsm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[1], tsm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tsm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[2], tsm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tsm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[0], tsm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tsm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[1], tsm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] += tsm[i];
+                }
+                if (false)
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[0], acc[i][j], 0, 0, 0);

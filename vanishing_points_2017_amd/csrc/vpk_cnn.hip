@@ -955,6 +955,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 #include "cnn_split_gemm.hpp"
 #include "cnn_conv1_pieces.hpp"
+#include "cnn_conv_pieces.hpp"
 #include "cnn_winograd.hpp"
 
 struct Layer {
@@ -969,6 +970,7 @@ struct Layer {
     float* c1map = nullptr;     // conv1: bias - conv1(mean), 123 x 123 x 96
     WinoDims wd;
     Wino5Dims wd5;
+    PieceDims pd;               // conv2..5 on exact bf16 pieces from an LDS-resident patch (cnn_conv_pieces.hpp)
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -986,7 +988,8 @@ struct vpk_cnn_state {
     // optional per-layer timing (HIP events on the handle's stream)
     int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
-    int algorithm = 1;       // vpk_cnn_set_algorithm: 1 (default) = conv3..5 by Winograd F(2 x 2, 3 x 3) (native precision only)
+    int algorithm = 2;       // vpk_cnn_set_algorithm: 0 = direct f32, 1 = Winograd on the f32 matrix cores, 2 (default) = conv2..5 as
+                             // direct convolutions on exact bf16 pieces (cnn_conv_pieces.hpp)
     int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
                              // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
     int conv1_group = 4;     // images per work item of conv1_pieces_kernel (VPK_CONV1_GROUP: development knob)
@@ -1048,7 +1051,7 @@ constexpr size_t splitk_partials_per_image() {          // the partials region: 
 // so an image's planes sit at the same address for every batch size <= capacity and the zero borders
 // written at allocation time stay valid.  Nothing is reused between layers (17.6 MB per image; 288 GB
 // of HBM3E makes ping-pong buffers unnecessary, and the borders must not be overwritten).
-enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_SPLIT, R_SPLIT4, R_SPLIT5, R_COUNT };
+enum Region { R_IN, R_CONV1, R_POOL1, R_CONV2, R_POOL2, R_CONV3, R_CONV4, R_CONV5, R_POOL5, R_FCA, R_FCB, R_PART, R_SPLIT, R_SPLIT4, R_SPLIT5, R_P6_2, R_P6_3, R_P6_5, R_COUNT };
 constexpr size_t CTR_FLOATS = 64;   // tile-queue counters of the 8 GEMM launches, behind the regions
 constexpr size_t REGION_FLOATS[R_COUNT] = {
     500ull * 500,            // fp32 input (raster - mean)
@@ -1065,6 +1068,9 @@ constexpr size_t REGION_FLOATS[R_COUNT] = {
     96ull * 65 * 65 * 3 / 2, // the current conv layer's input as three bf16 NHWC pieces (largest: pool1)
     384ull * 32 * 32 * 3 / 2, // conv4's / conv5's input in that format, written by the previous layer's epilogue (interior
     384ull * 32 * 32 * 3 / 2, //  only: the zero border comes from the arena's allocation)
+    96ull * 65 * 65 * 3 / 2,  // conv2's input as P6 planes (cnn_conv_pieces.hpp: [channel group][piece x k half][y][x] 16-byte words)
+    256ull * 32 * 32 * 3 / 2, // conv3's (vpk_cnn_set_algorithm(3) only: measurements)
+    384ull * 32 * 32 * 3 / 2, // conv5's (vpk_cnn_set_algorithm(3) only: measurements)
 };
 constexpr size_t arena_floats_per_image() {
     size_t t = 0;
@@ -1222,7 +1228,25 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         hipLaunchKernelGGL(conv3x3_winograd_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(WG_THREADS), 0, st, wd, src,
                            S->L[li].wino, S->L[li].bias, dst, ctr + li, total);
     };
-    const bool wino = S->precision == 0 && S->algorithm == 1;
+    const bool wino = S->precision == 0 && S->algorithm >= 1;      // Winograd for the layers that are not on pieces
+    const bool pieces = S->precision == 0 && S->algorithm >= 2;     // conv2 (mode 3, measurements: conv3 and conv5 too) on exact bf16 pieces
+    // conv2..5 as direct convolutions on exact bf16 pieces (cnn_conv_pieces.hpp): the layer's input as P6 planes
+    auto to_p6 = [&](const float* src, unsigned short* dst, int C, int Hp, int Wp) {
+        hipLaunchKernelGGL(to_p6_kernel, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
+    };
+    auto conv_pieces = [&](int li, const unsigned short* src6, float* dst) {
+        PieceDims pd = S->L[li].pd;
+        pd.B = batch;
+        const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
+        const unsigned blocks = (unsigned)std::min(total, 2 * h->num_cu);     // two 4-wave workgroups per CU
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, S->L[li].wsplit, S->L[li].bias, dst, ctr + li, total);
+        };
+        if (li == 1) go(conv_pieces_kernel<5>); else go(conv_pieces_kernel<3>);
+    };
+    unsigned short* p6_2 = reinterpret_cast<unsigned short*>(R[R_P6_2]);
+    unsigned short* p6_3 = reinterpret_cast<unsigned short*>(R[R_P6_3]);
+    unsigned short* p6_5 = reinterpret_cast<unsigned short*>(R[R_P6_5]);
     auto conv_main = [&](int li, const float* src, float* dst) {      // conv2 / conv3 / conv5: 128 x 128 tiles
         if (wino && li >= 2) return conv_wino(li, src, dst);
         if (wino && li == 1) {                                        // conv2 by F(2 x 2, 5 x 5)
@@ -1236,7 +1260,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
-    conv_main(1, R[R_POOL1], R[R_CONV2]);
+    if (pieces) { to_p6(R[R_POOL1], p6_2, 96, 65, 65); conv_pieces(1, p6_2, R[R_CONV2]); }
+    else conv_main(1, R[R_POOL1], R[R_CONV2]);
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
     // norm2 + pool2 (fused), written with conv3's border
@@ -1253,7 +1278,9 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     const bool chain = S->precision == 1 && tap != 4 && tap != 5;
     unsigned short* s4 = reinterpret_cast<unsigned short*>(R[R_SPLIT4]);
     unsigned short* s5 = reinterpret_cast<unsigned short*>(R[R_SPLIT5]);
-    if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
+    // (pieces: conv3 -> conv4 -> conv5 hand over P6 planes; a tapped f32 blob is converted for the next layer instead)
+    if (pieces && S->algorithm == 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3]); }
+    else if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
     else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
@@ -1263,7 +1290,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
+    if (pieces && S->algorithm == 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
+    else if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
     else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
     if ((rc = tapcopy(6, R[R_CONV5], A_CONV5))) return rc;
@@ -1320,6 +1348,9 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     return VPK_OK;
 }
 
+#ifdef CP_TIME
+int vpk_dbg_cp(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cp_dbg), sizeof(long long) * 2 * 256 * 8 * 8); }
+#endif
 #ifdef W5_TIME
 int vpk_dbg_w5(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w5_dbg), sizeof(long long) * 256 * 12 * 8); }
 int vpk_dbg_w3(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w3_dbg), sizeof(long long) * 256 * 8 * 8); }
@@ -1327,7 +1358,7 @@ int vpk_dbg_w3(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL
 
 int vpk_cnn_set_algorithm(vpk_handle* h, int mode) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_algorithm before vpk_cnn_load");
-    if (mode < 0 || mode > 1) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 or 1");
+    if (mode < 0 || mode > 3) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 .. 3");
     h->cnn->algorithm = mode;
     return VPK_OK;
 }
@@ -1448,6 +1479,12 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
                             }
             VPK_HIP(h, hipMalloc((void**)&l.wsplit, pk.size() * sizeof(unsigned short)));
             VPK_HIP(h, hipMemcpy(l.wsplit, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            PieceDims& pd = l.pd;                                     // the same fragments feed conv_pieces_kernel
+            pd.B = 0; pd.Cg16 = t.IC / 16; pd.CGtot = t.IC * t.G / 16; pd.Hp = d.Hp; pd.Wp = d.Wp; pd.OC = t.OC; pd.OH = t.OH; pd.OW = t.OW;
+            pd.groups = t.G; pd.KW = t.KH; pd.ntaps = t.KH * t.KH; pd.ksteps = sd.ksteps; pd.mblocks = sd.mblocks;
+            pd.mtiles = sd.mblocks / blk; pd.rtiles = (t.OH + CP_TR - 1) / CP_TR; pd.ctiles = (t.OW + CP_TC - 1) / CP_TC; pd.relu = 1;
+            pd.OHp = d.OHp; pd.OWp = d.OWp; pd.opad = d.opad;
+            pd.in_image = (long long)pd.CGtot * 6 * d.Hp * d.Wp * 16;
         }
         if (li == 0) {              // conv1 on the bf16 matrix cores: weight pieces in fragment order, bias - conv1(mean)
             std::vector<unsigned short> fr;
