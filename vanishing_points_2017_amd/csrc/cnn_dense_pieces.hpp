@@ -1,0 +1,200 @@
+// cnn_dense_pieces.hpp -- fc6 of cnn/deploy.prototxt (:192-210: InnerProduct 57 600 -> 4 096, weights (out, in)) on the bf16 matrix
+// cores with exact operands.  Included by vpk_cnn.hip (after cnn_split_gemm.hpp: bf16x8, split3, dma16, lds_addr).
+//
+// Why: at B = 102 the layer is 48 GFLOP over a 0.94 GB weight matrix.  On the f32-input matrix instructions (157 TF) the products
+// take 0.31 ms at peak -- longer than streaming the weights from HBM (0.17 ms at 5.5 TB/s) -- so the layer was matrix-pipe-bound
+// at 0.40 ms and paid twice beside the EM.  With every f32 operand split into three bf16 pieces (exact; six bf16 products per f32
+// product carry everything above 2^-24 of it, cnn_split_gemm.hpp) the products need 0.13 ms of the bf16 pipes and the layer is
+// what it should be: a weight stream.
+//   * weights stay f32 in HBM in Caffe's own layout (no 1.4 GB pre-split copy): a lane reads 64 contiguous bytes of its row
+//     (two lanes = one 128-byte line) two chunks ahead and splits them in registers (~160 integer / f32 operations per 48 matrix
+//     instructions: free);
+//   * activations (pool5, 102 x 57 600 f32) are split once per forward into B-fragment order (dense_split_kernel, 35 MB) and come
+//     through a three-stage LDS ring by DMA, shared by the workgroup's eight waves;
+//   * K order inside a chunk of 32: matrix step A takes k = 16 h + 0..7, step B k = 16 h + 8..15 (h = k half of the lane) -- any
+//     assignment of k to the instruction's 16 slots is valid as long as both operands use it, and this one makes a lane's 16
+//     values contiguous in memory;
+//   * block sums as in cnn_conv_pieces.hpp: the products of 8 chunks accumulate from zero and join the accumulator with one
+//     addition; split-K partials are reduced by splitk_reduce_kernel in a fixed order (deterministic).
+#ifndef VPK_CNN_DENSE_PIECES_HPP_
+#define VPK_CNN_DENSE_PIECES_HPP_
+
+namespace {
+
+constexpr int DP_THREADS = 512;
+constexpr int DP_BM = 256, DP_BN = 128;         // rows (outputs) x columns (images) of a tile
+constexpr int DP_CHUNK = 32;                    // k per chunk = two K16 steps
+constexpr int DP_STAGE = 3 * 2 * 4 * 1024;      // bytes of one chunk's B fragments: [piece][step][column block][lane][8 bf16]
+constexpr int DP_NST = 3;
+constexpr int DP_FOLD = 8;                      // chunks per block sum
+
+struct DenseDims {
+    int N, K, OC;                               // images, inputs, outputs
+    int chunks, kparts, cpp;                    // K / 32; split-K parts; chunks per part
+    int mtiles, ntiles;
+};
+
+// X f32 [N][K] -> B fragments [column tile][chunk][piece][step][column block][lane][8] bf16 (columns >= N: zeros)
+__global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int N, int K,
+                                                          int chunks) {
+    const int c = blockIdx.x, nt = blockIdx.y;
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = nt * DP_BN + 32 * j + (lane & 31), h = lane >> 5;
+    float v[16];
+    if (n < N) {
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(x + (size_t)n * K + (size_t)c * DP_CHUNK + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4v t = src[q];
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    }
+    unsigned short p[3][16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)nt * chunks + c) * (DP_STAGE / 2));
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 w4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = (unsigned)p[q][8 * s + 2 * e] | ((unsigned)p[q][8 * s + 2 * e + 1] << 16);
+            dst[(((q * 2 + s) * 4 + j) * 64) + lane] = w4;
+        }
+}
+
+__global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d, const float* __restrict__ w,
+                                                                     const unsigned short* __restrict__ xfrag, float* __restrict__ part,
+                                                                     int* __restrict__ item_counter, int total_items) {
+    __shared__ __attribute__((aligned(16))) unsigned char dp_lds[DP_NST * DP_STAGE];
+    __shared__ int s_next[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const unsigned lds0 = lds_addr(dp_lds);
+    typedef __attribute__((address_space(3))) const bf16x8 lds_cbf8;
+    int parity = 0;
+    for (int item = blockIdx.x; item < total_items;) {
+        int nx = 0;
+        if (tid == 0)
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(nx) : "v"(0), "v"(1), "s"(item_counter) : "memory");
+        int t = item;
+        const int mt = t % d.mtiles; t /= d.mtiles;
+        const int nt = t % d.ntiles;
+        const int ks = t / d.ntiles;
+        const int c0 = ks * d.cpp, c1 = c0 + d.cpp < d.chunks ? c0 + d.cpp : d.chunks;
+        const int row = mt * DP_BM + 32 * wave + r31;
+        const bool row_ok = row < d.OC;
+        const f32x4v* wrow = reinterpret_cast<const f32x4v*>(w + (size_t)(row_ok ? row : d.OC - 1) * d.K + 16 * h);
+        const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(xfrag) + (size_t)nt * d.chunks * DP_STAGE;
+        f32x4v araw[2][4];                                   // the 16 weights of this lane for chunks c and c + 1 (two register sets)
+        auto load_a = [&](int c, auto o_tag) {
+            constexpr int o = decltype(o_tag)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) araw[o][q] = wrow[(size_t)c * (DP_CHUNK / 4) + q];
+        };
+        auto issue_b = [&](int c) {                           // 24 fragments of 1 KB: wave w brings 3 w .. 3 w + 2
+            const unsigned char* src = xsrc + (size_t)c * DP_STAGE;
+            const unsigned dst = lds0 + (unsigned)((c % DP_NST) * DP_STAGE);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int f = 3 * wave + k;
+                dma16((unsigned)(f * 1024 + lane * 16), src, __builtin_amdgcn_readfirstlane(dst + (unsigned)f * 1024u));
+            }
+        };
+        f32x16 acc[4], tq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; tq[j][e] = 0.f; }
+        __builtin_amdgcn_s_barrier();                        // (every wave has left the previous item's stages)
+        load_a(c0, std::integral_constant<int, 0>());
+        issue_b(c0);
+        if (c0 + 1 < c1) { load_a(c0 + 1, std::integral_constant<int, 1>()); issue_b(c0 + 1); }
+        int fold = 0;
+        // (Round 5, measured: making the NEXT chunk's pieces between the groups of matrix instructions of the current one -- two
+        // operand sets, scheduling barriers, B fragments fetched per group -- was slower, 0.42 ms against 0.33: every group then waits
+        // for its own LDS reads.)
+        auto chunk = [&](auto o_tag, int c) {
+            constexpr int o = decltype(o_tag)::value;
+            // chunk c's weights and B fragments (own pieces) have landed; younger: chunk c + 1's 4 + 3 requests
+            if (c + 1 < c1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c == c0 && tid == 0) { asm volatile("" : "+v"(nx)); s_next[parity] = nx + (int)gridDim.x; }
+            __builtin_amdgcn_s_barrier();                    // ... for every wave; and every wave is done with chunk c - 1's stage
+            // split this lane's 16 weights: step A = values 0..7, step B = values 8..15
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                unsigned short p[3][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split3(row_ok ? araw[o][2 * s + (e >> 2)][e & 3] : 0.f, p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u32x4 w4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = (unsigned)p[q][2 * e] | ((unsigned)p[q][2 * e + 1] << 16);
+                    af[s][q] = __builtin_bit_cast(bf16x8, w4);
+                }
+            }
+            if (c + 2 < c1) { load_a(c + 2, o_tag); issue_b(c + 2); }   // (stage (c + 2) % 3 held chunk c - 1)
+            const unsigned stage = lds0 + (unsigned)((c % DP_NST) * DP_STAGE + lane * 16);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 bfr[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bfr[j][q] = *(lds_cbf8*)(stage + (unsigned)((((q * 2 + s) * 4) + j) * 1024));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2], bfr[j][0], tq[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bfr[j][1], tq[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][2], tq[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bfr[j][0], tq[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][1], tq[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][0], tq[j], 0, 0, 0);
+            }
+            if (++fold == DP_FOLD || c + 1 == c1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] += tq[j];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tq[j][e] = 0.f;
+                }
+                fold = 0;
+            }
+        };
+        int c = c0;
+        for (; c + 1 < c1; c += 2) {
+            chunk(std::integral_constant<int, 0>(), c);
+            chunk(std::integral_constant<int, 1>(), c + 1);
+        }
+        if (c < c1) chunk(std::integral_constant<int, 0>(), c);
+        // ---- partials [k part][image][output]: accumulator register 4 q + e = row 8 q + 4 h + e of this wave's 32-row block ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nt * DP_BN + 32 * j + r31;
+            if (n >= d.N) continue;
+            float* prow = part + ((size_t)ks * d.N + n) * d.OC + mt * DP_BM + 32 * wave + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mt * DP_BM + 32 * wave + 8 * q >= d.OC) continue;
+                f32x4v v4 = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                *reinterpret_cast<f32x4v*>(prow + 8 * q) = v4;
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(s_next[parity]);
+        parity ^= 1;
+    }
+}
+
+}  // namespace
+#endif

@@ -956,6 +956,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 #include "cnn_split_gemm.hpp"
 #include "cnn_conv1_pieces.hpp"
 #include "cnn_conv_pieces.hpp"
+#include "cnn_dense_pieces.hpp"
 #include "cnn_winograd.hpp"
 
 struct Layer {
@@ -971,6 +972,7 @@ struct Layer {
     WinoDims wd;
     Wino5Dims wd5;
     PieceDims pd;               // conv2..5 on exact bf16 pieces from an LDS-resident patch (cnn_conv_pieces.hpp)
+    float* wraw = nullptr;      // fc6: the weights in Caffe's own (out, in) layout, read by dense_pieces_kernel (cnn_dense_pieces.hpp)
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -985,6 +987,8 @@ struct vpk_cnn_state {
     float* act = nullptr;
     size_t act_bytes = 0;
     int act_batch = 0;
+    unsigned short* xfrag = nullptr;   // fc6's input as bf16 B fragments (dense_split_kernel), grown on demand
+    size_t xfrag_bytes = 0;
     // optional per-layer timing (HIP events on the handle's stream)
     int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
@@ -1011,9 +1015,11 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.wino) (void)hipFree(l.wino);
         if (l.c1frag) (void)hipFree(l.c1frag);
         if (l.c1map) (void)hipFree(l.c1map);
+        if (l.wraw) (void)hipFree(l.wraw);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
+    if (h->cnn->xfrag) (void)hipFree(h->cnn->xfrag);
     if (h->cnn->ev_ready)
         for (auto& set : h->cnn->ev)
             for (auto& e : set) (void)hipEventDestroy(e);
@@ -1304,6 +1310,20 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     float* fc_out = R[R_FCA];
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
+        if (li == 5 && pieces) {
+            // fc6 on exact bf16 pieces: the input split into B fragments, the weights streamed as they are (cnn_dense_pieces.hpp)
+            DenseDims dd;
+            dd.N = batch; dd.K = d.K; dd.OC = d.OC; dd.chunks = d.K / DP_CHUNK; dd.kparts = 45; dd.cpp = dd.chunks / dd.kparts;
+            dd.mtiles = (d.OC + DP_BM - 1) / DP_BM; dd.ntiles = (batch + DP_BN - 1) / DP_BN;
+            const size_t need = (size_t)dd.ntiles * dd.chunks * DP_STAGE;
+            if ((rc = vpk_reserve(h, (void**)&S->xfrag, &S->xfrag_bytes, need, "hipMalloc(fc6 input fragments)"))) return rc;
+            hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch, d.K,
+                               dd.chunks);
+            const int total = dd.mtiles * dd.ntiles * dd.kparts;
+            hipLaunchKernelGGL(dense_pieces_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
+                               S->xfrag, R[R_PART], ctr + li, total);
+            d.ksplit = dd.kparts;
+        } else
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], R[R_PART], 1, ctr + li);
         const long long tot = (long long)d.N * d.OC;
         float* dst = li == 7 ? out : fc_out;
@@ -1432,7 +1452,8 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((p_floats + 255) / 256)), dim3(256), 0, h->stream, raw,
                            l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
         VPK_HIP(h, hipStreamSynchronize(h->stream));
-        VPK_HIP(h, hipFree(raw));
+        if (li == 5) l.wraw = raw;      // fc6: also read in its own layout (cnn_dense_pieces.hpp)
+        else VPK_HIP(h, hipFree(raw));
         if (li < 5) {   // convolution: byte offset of tap k from the patch origin, in the bordered planes;
                         // the K padding (conv1: 121 -> 128) points at offset 0 and meets zero weights
             std::vector<unsigned> tab(d.Kp, 0u);
