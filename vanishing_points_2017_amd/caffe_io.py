@@ -11,8 +11,8 @@ numbers are those of upstream BVLC caffe.proto (they are not in the reference re
                      double_data=8 (packed double)
   BlobShape:         dim=1 (packed int64)
 A writer for the same subset exists so tests can round-trip files without Caffe; the reader is also pinned against files
-encoded by Google's protobuf runtime from upstream's field numbers (tests/golden/caffe_proto.npz, written by
-oracle/make_caffe_proto_fixtures.py: `layer` and V1 `layers` messages, packed and unpacked arrays, legacy 4-D dims,
+encoded by Google's protobuf runtime from upstream's field numbers (tests/golden/caffe_proto.npz, written by a
+build-container script of the test infrastructure: `layer` and V1 `layers` messages, packed and unpacked arrays, legacy 4-D dims,
 double_data, BlobShape).
 """
 import re

@@ -36,7 +36,7 @@
 namespace {
 
 constexpr int CP_THREADS = 256;            // four waves; TWO workgroups per CU (one's prologue / epilogue under the other's products)
-constexpr int CP_TR = 4, CP_TC = 32;            // output pixels of a tile: rows x columns
+constexpr int CP_TC = 32;                       // columns of a tile (its rows: the kernel's NB)
 constexpr int CP_NST = 4;                       // weight stages in LDS (stage s + 4 takes the slot of stage s, which is in registers by then)
 
 struct PieceDims {
@@ -85,12 +85,13 @@ __device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // KH: kernel size (5: conv2; 3 is kept for measurements on the 3 x 3 layers).  A tile = 128 output channels x (4 rows x 32 columns).
 // Four waves, one per 32-row block of the output channels, each all 4 x 32 pixels (four 32 x 32 blocks).
-template <int KH>
-__global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
+template <int KH, int NB>
+__global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
                                                                      const unsigned short* __restrict__ wfrag,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int* __restrict__ tile_counter, int total_tiles) {
     constexpr int MB = 4;                                    // 32-row blocks per tile
+    constexpr int CP_TR = NB;                                // rows of a tile = 32 x 32 blocks per wave
     constexpr int PR = CP_TR + KH - 1, PC = CP_TC + KH - 1;  // patch rows / columns
     constexpr int PRW = PR * PC;                             // 16-byte words per plane
     constexpr int KPP = (PRW + 63) / 64;                     // DMA instructions per plane
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * 3 * 1024 + lane * 16;
         const size_t wstep = (size_t)d.mblocks * 3 * 1024;
-        bf16x8 af[2][3], bfr[4][3];
+        bf16x8 af[2][3], bfr[NB][3];
         auto load_a = [&](int s, auto o_tag) {
             constexpr int o = decltype(o_tag)::value;
             const unsigned char* src = wgrp + (size_t)s * wstep;
@@ -159,13 +160,13 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         auto fetch_b = [&](int cg_, int kh__, int kw__) {   // the B operands of the step at that position -> bfr
             const unsigned bt = bbase + (unsigned)((cg_ & 1) * PBUF + (kh__ * PC + kw__) * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bfr[j][p] = *(lds_cbf8*)(bt + (unsigned)(j * PC * 16 + p * 2 * PLANE));
         };
-        f32x16 acc[4], tq[4];
+        f32x16 acc[NB], tq[NB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; tq[j][e] = 0.f; }
         const int S = d.ksteps;
@@ -209,17 +210,17 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
 #ifndef CP_X_NOMFMA
             // six products per block into the block sums, the five small ones first
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][2], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][2], bfr[j][0], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][1], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][1], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][2], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][2], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][0], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][1], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][1], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][0], tq[j], 0, 0, 0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
             CP_LAP(0);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
 #endif
             {                                                // the block sums join the accumulators: ONE rounding per FP steps
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     acc[j] += tq[j];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) tq[j][e] = 0.f;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         const int ow = x0 + n31;
         const int m_blk = (mt * MB + wmq) * 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int oh = y0 + j;
             if (oh >= d.OH || ow >= d.OW) continue;
             float* ocol = out + ((size_t)b * d.groups + g) * d.OC * d.OHp * d.OWp + (size_t)(oh + d.opad) * d.OWp + ow + d.opad;

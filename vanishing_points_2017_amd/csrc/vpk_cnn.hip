@@ -997,6 +997,7 @@ struct vpk_cnn_state {
     int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
                              // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
     int conv1_group = 4;     // images per work item of conv1_pieces_kernel (VPK_CONV1_GROUP: development knob)
+    int pieces_rows = 4;     // rows per tile of conv_pieces_kernel (VPK_PIECES_ROWS: development knob)
     bool profiling = false;
     static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
     hipEvent_t ev[EV_RING][14] = {};
@@ -1243,12 +1244,15 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     auto conv_pieces = [&](int li, const unsigned short* src6, float* dst) {
         PieceDims pd = S->L[li].pd;
         pd.B = batch;
+        const int nb = S->pieces_rows;                                     // rows of a tile: 4 (two workgroups per CU) or 2 (three)
+        pd.rtiles = (pd.OH + nb - 1) / nb;
         const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
-        const unsigned blocks = (unsigned)std::min(total, 2 * h->num_cu);     // two 4-wave workgroups per CU
+        const unsigned blocks = (unsigned)std::min(total, (nb == 4 ? 2 : 3) * h->num_cu);
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, S->L[li].wsplit, S->L[li].bias, dst, ctr + li, total);
         };
-        if (li == 1) go(conv_pieces_kernel<5>); else go(conv_pieces_kernel<3>);
+        if (li == 1) { if (nb == 4) go(conv_pieces_kernel<5, 4>); else go(conv_pieces_kernel<5, 2>); }
+        else { if (nb == 4) go(conv_pieces_kernel<3, 4>); else go(conv_pieces_kernel<3, 2>); }
     };
     unsigned short* p6_2 = reinterpret_cast<unsigned short*>(R[R_P6_2]);
     unsigned short* p6_3 = reinterpret_cast<unsigned short*>(R[R_P6_3]);
@@ -1503,7 +1507,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             PieceDims& pd = l.pd;                                     // the same fragments feed conv_pieces_kernel
             pd.B = 0; pd.Cg16 = t.IC / 16; pd.CGtot = t.IC * t.G / 16; pd.Hp = d.Hp; pd.Wp = d.Wp; pd.OC = t.OC; pd.OH = t.OH; pd.OW = t.OW;
             pd.groups = t.G; pd.KW = t.KH; pd.ntaps = t.KH * t.KH; pd.ksteps = sd.ksteps; pd.mblocks = sd.mblocks;
-            pd.mtiles = sd.mblocks / blk; pd.rtiles = (t.OH + CP_TR - 1) / CP_TR; pd.ctiles = (t.OW + CP_TC - 1) / CP_TC; pd.relu = 1;
+            pd.mtiles = sd.mblocks / blk; pd.rtiles = (t.OH + 3) / 4; pd.ctiles = (t.OW + CP_TC - 1) / CP_TC; pd.relu = 1;
             pd.OHp = d.OHp; pd.OWp = d.OWp; pd.opad = d.opad;
             pd.in_image = (long long)pd.CGtot * 6 * d.Hp * d.Wp * 16;
         }
@@ -1517,6 +1521,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             VPK_HIP(h, hipMalloc((void**)&l.c1map, cm.size() * sizeof(float)));
             VPK_HIP(h, hipMemcpy(l.c1map, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
             if (const char* e = getenv("VPK_CONV1_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) S->conv1_group = v; }
+            if (const char* e = getenv("VPK_PIECES_ROWS")) { const int v = atoi(e); if (v == 2 || v == 4) S->pieces_rows = v; }
         }
         if (li == 1) {              // conv2: G g G^T of every 5 x 5 filter (F(2 x 2, 5 x 5))
             std::vector<float> u;
