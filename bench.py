@@ -61,12 +61,12 @@ def parse():
                     help="default: yud, followed (one GPU only) by a short stress run and the HLW-shape pass, reported under 'workloads'")
     ap.add_argument("--no-extra", action="store_true", help="skip the 'workloads' part of the default run")
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: 102 yud / 512 stress)")
-    ap.add_argument("--em-mode", default="lanes", choices=["lanes", "slice", "serial"],
+    ap.add_argument("--em-mode", default="slice", choices=["lanes", "slice", "serial"],
                     help="slice: one CNN stream + one EM stream whose launches are time-sliced (vpk_em_set_time_slice): a launch "
                          "holds --em-wgs CUs for at most --em-slice-ms, images unfinished by then are parked and resumed by the "
                          "next launch, so no launch waits for a 99-iteration straggler; serial: ONE stream, CNN(k) then a sliced EM "
                          "launch on all CUs; lanes: round 1's scheme, whole EM batches on --em-lanes streams beside the CNN stream")
-    ap.add_argument("--em-slice-ms", type=float, default=-1.0, help="time budget of one sliced EM launch (default 8 slice / 1.6 serial)")
+    ap.add_argument("--em-slice-ms", type=float, default=-1.0, help="time budget of one sliced EM launch (default 4 slice / 1.6 serial)")
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--em-wgs", type=int, default=-1,
@@ -273,7 +273,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
     if world > 1:       # N ranks share one host: divide its cores (torch's intra-op pool, OpenMP / MKL in NumPy)
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
-    extra = args.workload is None and not args.no_extra and world == 1 and args.em_mode == "lanes"
+    extra = args.workload is None and not args.no_extra and world == 1
     if args.workload is None:
         args.workload = "yud"
     line = run_workload(args, dist, rank, local_rank, world)
@@ -532,8 +532,10 @@ def run_workload(args, dist, rank, local_rank, world):
         #   serial: one stream, CNN(k) on all CUs, then an EM launch on all CUs
         n_lanes = 1
         serial = args.em_mode == "serial"
-        em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else 64)
-        slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 8.0)
+        # (round 5, CNN at 3.9 ms alone: 96 workgroups x 4 ms 16.4-16.5 k images/s, 128 x 3 16.6 k, 112 x 4 16.2 k, 72 x 5 15.1 k;
+        #  whole-batch launches on three lanes 15.6 k -- each lane is held for its slowest image, ~17 ms)
+        em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else max(8, (count * 16) // 17))
+        slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 4.0)
         rt = get_runtime(local_rank, "main" if serial else "em")
         rt_cnn = rt if serial else get_runtime(local_rank, "cnn")
         rt.handle.em_set_workgroups(em_wgs)
@@ -570,21 +572,24 @@ def run_workload(args, dist, rank, local_rank, world):
     image_ids = torch.arange(rank * count, (rank + 1) * count, dtype=torch.int64, device=rt.tdev)
     alive = []                                           # sliced mode: a step's buffers live until the flush
 
-    def step_sliced(k):
+    def step_sliced(k, prior=None, sphere=None):
+        """prior: response maps the EM uses instead of this step's CNN output (the CNN runs all the same); sphere: the step's own
+        raster buffer (from_lines leg) instead of the resident rasters"""
+        sph = sphere_cnn if sphere is None else sphere
         with rt_cnn.on_stream():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-            resp = net.forward_device(sphere_cnn)        # B x 20 x 20 fp32
+            resp = net.forward_device(sph)               # B x 20 x 20 fp32
             e[1].record()
         with rt.on_stream():
             if rt is not rt_cnn:
                 rt.stream.wait_event(e[1])               # EM(k) needs CNN(k)
             l_buf = l_pristine.clone()                   # parked images keep reading their step's inputs
             e[2].record()
-            out = gem.em_batch_device(rt, d["offsets"], l_buf, d["lp"], resp.reshape(-1, 400), d["sphere"],
+            out = gem.em_batch_device(rt, d["offsets"], l_buf, d["lp"], (resp if prior is None else prior).reshape(-1, 400), sph,
                                       d["init_vp"], params, max_vp=max_vp)
             e[3].record()
-        alive.append((resp, l_buf, out))
+        alive.append((resp, l_buf, out, sph))
         return e, out
 
     def finish_sliced():
@@ -592,7 +597,7 @@ def run_workload(args, dist, rank, local_rank, world):
         with rt.on_stream():
             rt.handle.em_flush()
             if dist is not None:
-                rec = torch.cat([sharding.device_records(torch, image_ids, o) for _, _, o in alive], 0)
+                rec = torch.cat([sharding.device_records(torch, image_ids, a[2]) for a in alive], 0)
                 alive[-1][2]["records"] = sharding.gather_device(dist, rec)
 
     # lanes mode: a step is ONE call into the library (vpk_pipeline_step: CNN, stream dependency, copy of the lines, EM
@@ -671,16 +676,20 @@ def run_workload(args, dist, rank, local_rank, world):
     # what the parity object runs) instead of the random-weight CNN's output.  The CNN is executed all the same (its output is
     # written and left unused): the work of a deployment whose net produces the priors the fixtures stand for.
     fixture = None
-    if args.workload == "yud" and not sliced and not args.no_alt:
-        ring_fix = [pipeline.Step(rt_cnn, lanes[j % n_lanes], d, params, l_in=l_pristine, max_vp=max_vp, records=dist is not None,
-                                  image_ids=image_ids, timing=False, em_prior=d["cnn"]) for j in range(2 * n_lanes)]
-        active["ring"] = ring_fix
+    if args.workload == "yud" and not args.no_alt:
+        if sliced:
+            step_fix = lambda k: step_sliced(k, prior=d["cnn"])
+        else:
+            ring_fix = [pipeline.Step(rt_cnn, lanes[j % n_lanes], d, params, l_in=l_pristine, max_vp=max_vp, records=dist is not None,
+                                      image_ids=image_ids, timing=False, em_prior=d["cnn"]) for j in range(2 * n_lanes)]
+            active["ring"] = ring_fix
+            step_fix = step
         for k in range(max(args.warmup, n_lanes)):
-            step(k)
+            step_fix(k)
         sync_all()
         t1 = time.perf_counter()
         for k in range(args.steps):
-            e_fix, out_fix = step(args.warmup + k)
+            e_fix, out_fix = step_fix(args.warmup + k)
         sync_all()
         fix_elapsed = time.perf_counter() - t1
         if dist is not None:
@@ -696,8 +705,8 @@ def run_workload(args, dist, rank, local_rank, world):
     # operand, six products per f32 product -- f32-class accuracy, tests/test_gpu_cnn.py).  Reported beside the headline
     # number, never as it: `value` is the native-f32 run above.
     alt = None
-    if args.workload == "yud" and args.cnn_precision == 0 and not sliced and not args.no_alt:
-        alt_wgs = args.em_wgs if args.em_wgs >= 0 else max(8, (count * 47) // 100)   # the faster CNN leaves the EM more CUs
+    if args.workload == "yud" and args.cnn_precision == 0 and not args.no_alt:
+        alt_wgs = em_wgs if sliced else (args.em_wgs if args.em_wgs >= 0 else max(8, (count * 47) // 100))
         net.set_precision(1)
         for r in lanes:
             r.handle.em_set_workgroups(alt_wgs)
@@ -728,17 +737,19 @@ def run_workload(args, dist, rank, local_rank, world):
     # of its own; the CNN of the step waits for it on the device), i.e. sphere raster -> CNN -> EM, SURVEY 8d's full metric.
     # Reported beside the headline number (whose inputs include the rasters, as the contract's "resident in HBM" says).
     from_lines = None
-    if args.workload == "yud" and not sliced and not args.no_alt and not args.no_from_lines:
+    if args.workload == "yud" and not args.no_alt and not args.no_from_lines:
         from vanishing_points_2017_amd import sphere_mapping, _lib
         rt_r = get_runtime(local_rank, "raster")
         offs = _lib.host_i64(d["offsets"])
         size_px = int(d["sphere"].shape[-1])
+        n_ring = max(len(ring), 2)
         with rt_r.on_stream():
-            spheres = [torch.empty_like(d["sphere"]) for _ in ring]
-            ev_r = [torch.cuda.Event(enable_timing=False) for _ in ring]
+            spheres = [torch.empty_like(d["sphere"]) for _ in range(n_ring)]
+            ev_r = [torch.cuda.Event(enable_timing=False) for _ in range(n_ring)]
             ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ring_r = [pipeline.Step(rt_cnn, lanes[j % n_lanes], dict(d, sphere=spheres[j]), params, l_in=l_pristine, max_vp=max_vp,
-                                records=dist is not None, image_ids=image_ids, timing=False) for j in range(len(ring))]
+        ring_r = [] if sliced else [pipeline.Step(rt_cnn, lanes[j % n_lanes], dict(d, sphere=spheres[j]), params, l_in=l_pristine,
+                                                  max_vp=max_vp, records=dist is not None, image_ids=image_ids, timing=False)
+                                    for j in range(len(ring))]
         rt_r.synchronize()
         ev_t[0].record(rt_r.stream)                      # the raster alone, once (also its workspace allocation and table)
         sphere_mapping.raster_batch_device(rt_r, l_pristine, offs, size_px, 0.1, out=spheres[0])
@@ -755,10 +766,19 @@ def run_workload(args, dist, rank, local_rank, world):
         with rt.on_stream():
             plain = gem.em_batch_device(rt, d["offsets"], l_pristine.clone(), d["lp"], resp0.reshape(-1, 400), spheres[0],
                                         d["init_vp"], params, max_vp=max_vp)
+            rt.handle.em_flush()                         # (time-sliced mode: finish what the launch parked)
         rt.synchronize()
         plain = {q: plain[q].clone() for q in ("iterations", "status", "num_vp", "vp_assoc", "vp")}
 
         def step_from_lines(k):
+            if sliced:                                   # a raster buffer of its own per step: parked images read theirs until the flush
+                with rt_r.on_stream():
+                    sph = torch.empty_like(d["sphere"])
+                    ev = torch.cuda.Event(enable_timing=False)
+                sphere_mapping.raster_batch_device(rt_r, l_pristine, offs, size_px, 0.1, out=sph)
+                ev.record(rt_r.stream)
+                rt_cnn.stream.wait_event(ev)
+                return step_sliced(k, sphere=sph)[1]
             j = k % len(ring_r)
             st = ring_r[j]
             rt_r.stream.wait_event(st.guard)             # the EM that read this raster buffer last has finished
@@ -775,7 +795,7 @@ def run_workload(args, dist, rank, local_rank, world):
             rt_r.synchronize()
             sync_all()
 
-        for k in range(max(args.warmup, len(ring_r))):
+        for k in range(max(args.warmup, len(ring_r), 2)):
             step_from_lines(k)
         sync_lines()
         t1 = time.perf_counter()
@@ -959,12 +979,19 @@ def run_workload(args, dist, rank, local_rank, world):
                                               "the random-weight CNN's output, which 'value' uses (em_stats: its iteration counts)")
         if dist is not None:            # the one collective of the path, as this run executed it
             rec = out.get("records")
-            line["gather"] = {"backend": dist.get_backend(), "records": None if rec is None else int(rec.shape[0]),
-                              "width": None if rec is None else int(rec.shape[1]),
-                              "image_ids_complete": None if rec is None else bool(
-                                  torch.equal(rec[:, 0].to(torch.int64).cpu(), torch.arange(count * world, dtype=torch.int64))),
-                              "note": "per step: one all_gather of the ranks' fixed-size result records on the EM lane's stream "
-                                      "(sharding.gather_device); the figures are the last timed step's gathered block"}
+            g_info = {"backend": dist.get_backend(), "records": None, "width": None, "image_ids_complete": None}
+            if rec is not None:
+                # lanes mode: one all_gather per step (world x B rows); slice mode: one at the flush that ends a run of steps, with the
+                # records of every step still alive (world x steps x B rows, rank-major)
+                per_rank = int(rec.shape[0]) // world
+                g_steps = per_rank // count
+                ids = rec[:, 0].to(torch.int64).cpu().reshape(world, g_steps, count)
+                want = (torch.arange(world, dtype=torch.int64)[:, None, None] * count + torch.arange(count, dtype=torch.int64)[None, None, :])
+                g_info.update(records=int(rec.shape[0]), width=int(rec.shape[1]), steps_in_gather=g_steps, records_per_step=count * world,
+                              image_ids_complete=bool(torch.equal(ids, want.expand(world, g_steps, count))))
+            g_info["note"] = ("slice mode: ONE all_gather of the ranks' fixed-size result records at the flush that ends the run (the records of "
+                              "every step whose buffers are alive); lanes mode: one per step on the EM lane's stream (sharding.gather_device)")
+            line["gather"] = g_info
         if alt:
             line["alt_precision"] = alt
         if from_lines is not None:
