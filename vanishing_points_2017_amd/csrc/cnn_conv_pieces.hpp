@@ -148,7 +148,10 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * 3 * 1024 + lane * 16;
         const size_t wstep = (size_t)d.mblocks * 3 * 1024;
-        bf16x8 af[2][3], bfr[NB][3];
+        // B operand register sets.  With two, the next step's operands are requested BEFORE this step's matrix instructions: measured
+        // (round 5) on the 2-block / three-workgroups-per-CU build, the only one with room for it: 1.36 ms against 1.29 -- not used
+        constexpr int BSETS = 1;
+        bf16x8 af[2][3], bfr[BSETS][NB][3];
         auto load_a = [&](int s, auto o_tag) {
             constexpr int o = decltype(o_tag)::value;
             const unsigned char* src = wgrp + (size_t)s * wstep;
@@ -157,12 +160,13 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
         };
         const unsigned bbase = lds0 + (unsigned)(kh_ * PLANE + n31 * 16);
         int cg = 0, tap = 0, kh = 0, kw = 0;                 // position of the current step
-        auto fetch_b = [&](int cg_, int kh__, int kw__) {   // the B operands of the step at that position -> bfr
+        auto fetch_b = [&](auto set_tag, int cg_, int kh__, int kw__) {   // the B operands of the step at that position -> bfr[set]
+            constexpr int st = decltype(set_tag)::value;
             const unsigned bt = bbase + (unsigned)((cg_ & 1) * PBUF + (kh__ * PC + kw__) * 16);
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bfr[j][p] = *(lds_cbf8*)(bt + (unsigned)(j * PC * 16 + p * 2 * PLANE));
+                for (int p = 0; p < 3; ++p) bfr[st][j][p] = *(lds_cbf8*)(bt + (unsigned)(j * PC * 16 + p * 2 * PLANE));
         };
         f32x16 acc[NB], tq[NB];
 #pragma unroll
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
         if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // patch 0 is complete for every wave
-        fetch_b(0, 0, 0);
+        fetch_b(std::integral_constant<int, 0>(), 0, 0, 0);
         CP_LAP(7);
         int fold = 0;
         // One K16 step.  The waves of a workgroup are NOT in lockstep: weights come per wave from L2 (two steps ahead, two register
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
                 __builtin_amdgcn_s_barrier();
 #endif
 #ifndef CP_X_NOFETCH
-                fetch_b(cg, 0, 0);
+                fetch_b(std::integral_constant<int, BSETS == 2 ? o : 0>(), cg, 0, 0);
 #endif
             } else {
                 // the weights of this step (younger: the next step's three loads -- and the patch, when it was issued a step ago)
@@ -207,20 +211,29 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             CP_LAP(4);
+            // the next step's position
+            int n_kw = kw + 1, n_kh = kh, n_tap = tap + 1, n_cg = cg;
+            if (n_kw == d.KW) { n_kw = 0; ++n_kh; }
+            if (n_tap == d.ntaps) { n_tap = 0; n_kh = 0; ++n_cg; }
+#ifndef CP_X_NOFETCH
+            if (BSETS == 2 && n_tap != 0 && s_ + 1 < S) fetch_b(std::integral_constant<int, BSETS == 2 ? (o ^ 1) : 0>(), n_cg, n_kh, n_kw);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int bs = BSETS == 2 ? o : 0;
 #ifndef CP_X_NOMFMA
             // six products per block into the block sums, the five small ones first
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][2], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][2], bfr[bs][j][0], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][1], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[bs][j][1], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][2], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][2], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[bs][j][0], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][1], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][1], tq[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[j][0], tq[j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][0], tq[j], 0, 0, 0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
             CP_LAP(0);
@@ -233,10 +246,9 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
 #ifndef CP_X_NOA
             if (s_ + 2 < S) load_a(s_ + 2, o_tag);
 #endif
-            if (++kw == d.KW) { kw = 0; ++kh; }
-            if (++tap == d.ntaps) { tap = 0; kh = 0; ++cg; }
+            kw = n_kw; kh = n_kh; tap = n_tap; cg = n_cg;
 #ifndef CP_X_NOFETCH
-            if (tap != 0 && s_ + 1 < S) fetch_b(cg, kh, kw);
+            if (BSETS == 1 && tap != 0 && s_ + 1 < S) fetch_b(std::integral_constant<int, 0>(), cg, kh, kw);
 #endif
             CP_LAP(3);
 #ifdef CP_X_NOFOLD
