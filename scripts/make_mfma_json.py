@@ -20,6 +20,7 @@ XCDS = 8
 
 def short(name):
     for tag, s in (("conv_pieces_kernelILi5E", "conv_pieces_kernel<5> (conv2)"), ("conv1_pieces_kernel", "conv1_pieces_kernel (conv1+norm1+pool1)"),
+                   ("dense_pieces_kernel", "dense_pieces_kernel (fc6)"),
                    ("conv5x5_winograd_kernel", "conv5x5_winograd_kernel (conv2)"),
                    ("conv3x3_winograd_kernel", "conv3x3_winograd_kernel (conv3/4/5)"),
                    ("ILi2ELi2ELi2ELi2ELb0ELb0", "conv_gemm_dma<2,2,2,2> (conv2/3/5)"),

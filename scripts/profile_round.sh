@@ -4,7 +4,7 @@
 # Summaries land in gpurun_out/prof/summary (copy them to profiles/).   ROUND=r03 bash scripts/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/prof
-N=${ROUND:-r04}
+N=${ROUND:-r05}
 rm -rf $R; mkdir -p $R/summary
 BENCH="python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_trace -o t -- $BENCH > $R/yud_trace.log 2>&1
@@ -15,15 +15,18 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- py
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --workload yud --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/stress_fetch -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/stress_write -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_write.log 2>&1
-# CNN alone with the direct convolutions everywhere (vpk_cnn_set_algorithm(0): rounds 1-3's default)
-export VPK_ALGORITHM=0
+# CNN alone with the f32 direct kernels everywhere (vpk_cnn_set_fusion(1), vpk_cnn_set_algorithm(0): rounds 1-3's default) and with
+# round 4's defaults (f32 direct conv1, Winograd conv2..5 on the f32 matrix cores)
+export VPK_ALGORITHM=0 VPK_FUSION=1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_direct_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_direct_trace.log 2>&1
-export VPK_ALGORITHM=1
+export VPK_ALGORITHM=1 VPK_FUSION=1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_wino_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_wino_trace.log 2>&1
+unset VPK_ALGORITHM VPK_FUSION
 # CNN alone with conv2..5 on the bf16 matrix cores (vpk_cnn_set_precision(1)) and the bench with that path
 export VPK_PRECISION=1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_split_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_split_trace.log 2>&1
 unset VPK_PRECISION
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt --cnn-precision 1 --em-wgs 47 > $R/yud_split_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_split_trace -o t -- python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt --cnn-precision 1 > $R/yud_split_trace.log 2>&1
 # MFMA utilisation of the conv / dense kernels: CNN alone and inside the bench (beside the EM)
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $R/cnn_mfma -o t -- python3 scripts/time_cnn.py --passes 6 102 > $R/cnn_mfma.log 2>&1
@@ -33,6 +36,7 @@ python3 scripts/rocpd_stats.py $(find $R/stress_trace -name '*.db' | head -1) $R
 python3 scripts/rocpd_stats.py $(find $R/cnn_trace -name '*.db' | head -1) $R/summary/${N}_cnn_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_split_trace -name '*.db' | head -1) $R/summary/${N}_cnn_split_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_split_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_direct_trace -name '*.db' | head -1) $R/summary/${N}_cnn_direct_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_direct_top.txt
+python3 scripts/rocpd_stats.py $(find $R/cnn_wino_trace -name '*.db' | head -1) $R/summary/${N}_cnn_wino_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_wino_top.txt
 python3 scripts/rocpd_stats.py $(find $R/yud_split_trace -name '*.db' | head -1) $R/summary/${N}_yud_split_kernel_stats.csv > $R/summary/${N}_yud_split_top.txt
 python3 scripts/make_traffic_json.py $R $R/summary/${N}_pmc_traffic.json > /dev/null
 python3 scripts/make_mfma_json.py $R $R/summary/${N}_pmc_mfma.json > /dev/null
