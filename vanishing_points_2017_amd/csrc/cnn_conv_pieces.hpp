@@ -83,6 +83,25 @@ __device__ long long cp_dbg[2 * 256 * 8 * 8];
 template <int N>
 __device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// A 16-byte global load the COMPILER DOES NOT KNOW TO BE A LOAD (round 5).  hipcc keeps a scoreboard of the vector-memory operations it
+// has emitted and puts its own s_waitcnt in front of the first use of a loaded register; with LDS-DMA issued from inline asm in between
+// (which it cannot count) it falls back to `s_waitcnt vmcnt(0)` -- in front of every K16 step's first matrix instruction here, which turned
+// "weights two steps ahead" into "everything in flight must land now" (the ISA of the first version: `s_waitcnt vmcnt(0) lgkmcnt(11)`).
+// Issued from asm, completion is counted by hand (cp_wait_for below ties the wait to the registers it releases, so that no use can be
+// scheduled above it).  s_nop: the scalar base may have been written by v_readlane just before (VALU-writes-SGPR -> VMEM hazard).
+// The destination is a "+v" operand -- the load overwrites the register the variable already lives in -- so that the compiler has no
+// fresh value to copy into place (a copy issued before the data has landed would copy the old contents).
+__device__ __forceinline__ void cp_gload16(bf16x8& dst, const void* sbase, unsigned voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// (The wait must NOT take the registers as operands: hipcc then copies them into the asm's operand registers BEFORE the wait -- stale data.
+// A scheduling barrier behind the wait keeps the matrix instructions, the only readers, below it.)
+template <int N>
+__device__ __forceinline__ void cp_wait_for(bf16x8&, bf16x8&, bf16x8&) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // KH: kernel size (5: conv2; 3 is kept for measurements on the 3 x 3 layers).  A tile = 128 output channels x (4 rows x 32 columns).
 // Four waves, one per 32-row block of the output channels, each all 4 x 32 pixels (four 32 x 32 blocks).
 template <int KH, int NB>
@@ -146,17 +165,19 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
         };
         // ---- weights: this wave's three fragments (pieces) of a K16 step, 16 bytes per lane each, straight from L2 into registers ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
-                                    ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * 3 * 1024 + lane * 16;
+                                    ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * 3 * 1024;     // (wave-uniform)
         const size_t wstep = (size_t)d.mblocks * 3 * 1024;
         // B operand register sets.  With two, the next step's operands are requested BEFORE this step's matrix instructions: measured
         // (round 5) on the 2-block / three-workgroups-per-CU build, the only one with room for it: 1.36 ms against 1.29 -- not used
         constexpr int BSETS = 1;
         bf16x8 af[2][3], bfr[BSETS][NB][3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) af[q / 3][q % 3] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
         auto load_a = [&](int s, auto o_tag) {
             constexpr int o = decltype(o_tag)::value;
             const unsigned char* src = wgrp + (size_t)s * wstep;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[o][p] = *reinterpret_cast<const bf16x8*>(src + p * 1024);
+            for (int p = 0; p < 3; ++p) cp_gload16(af[o][p], src + p * 1024, (unsigned)lane * 16u);
         };
         const unsigned bbase = lds0 + (unsigned)(kh_ * PLANE + n31 * 16);
         int cg = 0, tap = 0, kh = 0, kw = 0;                 // position of the current step
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
             if (group_start) {
                 // own pieces of this group's patch (issued a whole group ago) and the weights of this step have landed; behind the
                 // barrier every wave's have -- and every wave has finished reading the other buffer
-                if (s_ + 1 < S) cp_wait<3>(); else cp_wait<0>();
+                if (s_ + 1 < S) cp_wait_for<3>(af[o][0], af[o][1], af[o][2]); else cp_wait_for<0>(af[o][0], af[o][1], af[o][2]);
 #ifndef CP_X_NOBAR
                 __builtin_amdgcn_s_barrier();
 #endif
@@ -204,9 +225,9 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
             } else {
                 // the weights of this step (younger: the next step's three loads -- and the patch, when it was issued a step ago)
 #if !defined(CP_X_NOA) && !defined(CP_X_NOPATCH)
-                if (s_ + 1 >= S) cp_wait<0>();
-                else if (tap == 1 && cg + 1 < d.Cg16) cp_wait<3 + NPW>();
-                else cp_wait<3>();
+                if (s_ + 1 >= S) cp_wait_for<0>(af[o][0], af[o][1], af[o][2]);
+                else if (tap == 1 && cg + 1 < d.Cg16) cp_wait_for<3 + NPW>(af[o][0], af[o][1], af[o][2]);
+                else cp_wait_for<3>(af[o][0], af[o][1], af[o][2]);
 #endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
