@@ -37,7 +37,6 @@ namespace {
 
 constexpr int CP_THREADS = 256;            // four waves; TWO workgroups per CU (one's prologue / epilogue under the other's products)
 constexpr int CP_TC = 32;                       // columns of a tile (its rows: the kernel's NB)
-constexpr int CP_NST = 4;                       // weight stages in LDS (stage s + 4 takes the slot of stage s, which is in registers by then)
 
 struct PieceDims {
     int B;                                      // images
@@ -48,23 +47,48 @@ struct PieceDims {
     int mtiles, rtiles, ctiles;                 // tiles per (image, conv group): output-channel tiles, row tiles, column tiles
     int relu;
     int OHp, OWp, opad;                         // f32 NCHW output planes
-    long long in_image;                         // bytes per image of the P6 input tensor
+    long long in_image;                         // bytes per image of the input tensor (planes of 16-byte words)
+    float oscale;                               // 1 / (weight scale x activation scale) of the fp16-pair operands (a power of two); 1 for bf16 pieces
 };
 
-// f32 NCHW planes (with their zero border) -> P6 planes.  One workgroup per (image, channel group, row): 16 channels x Wp
-// values in, 6 x Wp 16-byte words out.
-__global__ __launch_bounds__(256) void to_p6_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int Hp,
-                                                    int Wp) {
+// fp16 PAIRS (round 5): an f32 operand x is h0 + h1 with h0 = fp16(x), h1 = fp16(x - h0): 22 significand bits of its 24 (the
+// remainder is below 2^-23 |x|), and of the four partial products h_i h_j (each EXACT in f32: 11 x 11 bits) the three with
+// i + j <= 1 carry everything above 2^-24 of the product -- HALF the matrix instructions of the bf16 triples, for operands that are
+// a bit short of exact.  fp16's exponent range is what needs care: weights are scaled by a power of two per layer so that
+// the largest is in [2^13, 2^14) (every weight down to 2^-17 of the largest keeps a normal second piece), activations by
+// CP_ASCALE = 2^-3 (finite up to 5e5; below 1 the second piece becomes denormal -- the matrix cores multiply fp16 denormals, measured
+// with scripts/ubench/mfma_f16_pairs.hip -- and the absolute error stays below 2^-25 / CP_ASCALE); the epilogue multiplies by the
+// exact reciprocal.  Whether a layer may use this is decided by MEASUREMENT against the float64 net (tests/test_gpu_cnn.py: no
+// further from it than the f32 direct kernels, at every tap).
+constexpr float CP_ASCALE = 0.125f;
+
+__device__ __forceinline__ void split2h(float x, unsigned short& h0, unsigned short& h1) {
+    const _Float16 a = (_Float16)x;
+    const _Float16 b = (_Float16)(x - (float)a);
+    h0 = __builtin_bit_cast(unsigned short, a);
+    h1 = __builtin_bit_cast(unsigned short, b);
+}
+
+// f32 NCHW planes (with their zero border) -> piece planes: [image][channel group of 16][piece x k half (2 NP)][y][x] 16-byte words
+// (8 values = the B operand of one lane for one pixel).  NP = 3: bf16 triples; NP = 2: fp16 pairs of CP_ASCALE x.  One workgroup
+// per (image, channel group, row): 16 channels x Wp values in, 2 NP x Wp words out.
+template <int NP>
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int Hp,
+                                                        int Wp) {
     const int y = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
     const float* src = in + (((size_t)b * C + cg * 16) * Hp + y) * Wp;
-    u32x4* dst = reinterpret_cast<u32x4*>(out) + (((size_t)b * (C >> 4) + cg) * 6 * Hp + y) * Wp;
+    u32x4* dst = reinterpret_cast<u32x4*>(out) + (((size_t)b * (C >> 4) + cg) * (2 * NP) * Hp + y) * Wp;
     for (int idx = threadIdx.x; idx < 2 * Wp; idx += 256) {      // (k half, x)
         const int h = idx / Wp, x = idx - h * Wp;
         unsigned short p[3][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split3(src[(size_t)(8 * h + e) * Hp * Wp + x], p[0][e], p[1][e], p[2][e]);
+        for (int e = 0; e < 8; ++e) {
+            const float v = src[(size_t)(8 * h + e) * Hp * Wp + x];
+            if (NP == 3) split3(v, p[0][e], p[1][e], p[2][e]);
+            else split2h(v * CP_ASCALE, p[0][e], p[1][e]);
+        }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             u32x4 w4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) w4[e] = (unsigned)p[q][2 * e] | ((unsigned)p[q][2 * e + 1] << 16);
@@ -73,51 +97,55 @@ __global__ __launch_bounds__(256) void to_p6_kernel(const float* __restrict__ in
     }
 }
 
-#ifdef CP_TIME
-// development: shader-clock laps of the kernel's phases per wave (scripts/cp_phase_times.py; a build with -DCP_TIME)
-__device__ long long cp_dbg[2 * 256 * 8 * 8];
-#define CP_LAP(slot) do { const long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define CP_LAP(slot) do { } while (0)
-#endif
 template <int N>
-__device__ __forceinline__ void cp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void cp_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);           // (nothing that reads a loaded register moves above the wait)
+}
 
 // A 16-byte global load the COMPILER DOES NOT KNOW TO BE A LOAD (round 5).  hipcc keeps a scoreboard of the vector-memory operations it
 // has emitted and puts its own s_waitcnt in front of the first use of a loaded register; with LDS-DMA issued from inline asm in between
-// (which it cannot count) it falls back to `s_waitcnt vmcnt(0)` -- in front of every K16 step's first matrix instruction here, which turned
-// "weights two steps ahead" into "everything in flight must land now" (the ISA of the first version: `s_waitcnt vmcnt(0) lgkmcnt(11)`).
-// Issued from asm, completion is counted by hand (cp_wait_for below ties the wait to the registers it releases, so that no use can be
-// scheduled above it).  s_nop: the scalar base may have been written by v_readlane just before (VALU-writes-SGPR -> VMEM hazard).
-// The destination is a "+v" operand -- the load overwrites the register the variable already lives in -- so that the compiler has no
-// fresh value to copy into place (a copy issued before the data has landed would copy the old contents).
+// (which it cannot count) it falls back to `s_waitcnt vmcnt(0)` -- in front of every K16 step's first matrix instruction in the first
+// version, which turned "weights two steps ahead" into "everything in flight must land now".  Issued from asm, completion is counted
+// by hand (cp_wait: a bare s_waitcnt and a scheduling barrier; a wait that names the registers as "+v" operands makes hipcc COPY them
+// into the asm's operand registers BEFORE the wait -- stale data).  The destination is a "+v" operand -- the load overwrites the
+// register the variable already lives in -- so that the compiler has no fresh value to copy into place either.
+template <int OFF>
 __device__ __forceinline__ void cp_gload16(bf16x8& dst, const void* sbase, unsigned voff) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-// (The wait must NOT take the registers as operands: hipcc then copies them into the asm's operand registers BEFORE the wait -- stale data.
-// A scheduling barrier behind the wait keeps the matrix instructions, the only readers, below it.)
-template <int N>
-__device__ __forceinline__ void cp_wait_for(bf16x8&, bf16x8&, bf16x8&) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
-// KH: kernel size (5: conv2; 3 is kept for measurements on the 3 x 3 layers).  A tile = 128 output channels x (4 rows x 32 columns).
-// Four waves, one per 32-row block of the output channels, each all 4 x 32 pixels (four 32 x 32 blocks).
-template <int KH, int NB>
-__global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
+// KH: kernel size (5: conv2; 3 is kept for measurements on the 3 x 3 layers).  A tile = 128 output channels x (NB = 4 rows x 32
+// columns).  Four waves, one per 32-row block of the output channels, each all 4 x 32 pixels (four 32 x 32 blocks).
+//
+// THE LOOP IS WRITTEN FOR THE INSTRUCTION ISSUE, not only for the memory system (round 5, the counters of profiles/r05_pmc_conv2.txt):
+// the first version spent 2.5 scalar instructions, 0.45 branches and 1.2 other vector instructions per matrix instruction on
+// per-step bookkeeping (tap position, conditional waits, 64-bit addresses) -- ~130 instructions per step and wave beside its 24
+// matrix instructions, as long to issue as those take to execute -- and the two waves of a SIMD do not hide that for each other:
+// the arbiter alternates between them while both have matrix work, they finish a step together and then do their bookkeeping
+// together (pipe 62 % busy, whatever the memory schedule).  Here a BLOCK of FP steps (a kernel row of conv2; all nine taps of
+// a 3 x 3 layer) is straight-line code: tap offsets are immediates of the LDS reads, the weight pieces immediates of one
+// scalar pointer, waits are constants, and the only branches are per block.
+template <int KH, int NB, int NP>
+__global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
                                                                      const unsigned short* __restrict__ wfrag,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int* __restrict__ tile_counter, int total_tiles) {
     constexpr int MB = 4;                                    // 32-row blocks per tile
-    constexpr int CP_TR = NB;                                // rows of a tile = 32 x 32 blocks per wave
-    constexpr int PR = CP_TR + KH - 1, PC = CP_TC + KH - 1;  // patch rows / columns
-    constexpr int PRW = PR * PC;                             // 16-byte words per plane
-    constexpr int KPP = (PRW + 63) / 64;                     // DMA instructions per plane
-    constexpr int PLANE = KPP * 64 * 16;                     // bytes per plane in LDS (tail lanes write into the padding)
-    constexpr int PBUF = 6 * PLANE;                          // bytes per patch buffer
-    constexpr int NPW = (6 * KPP + 3) / 4;                   // patch DMA instructions per wave and channel group
-    constexpr int FP = KH == 5 ? 5 : 9;                      // K16 steps per block sum (a kernel row of conv2, all taps of a 3 x 3 layer)
+    constexpr int H = NB / 2;                                // rows per half (the halves' B operands are fetched half a step apart)
+    constexpr int PR = NB + KH - 1, PC = CP_TC + KH - 1;     // patch rows / columns
+    constexpr int KPP = (PC + 7) / 8;                        // DMA instructions per plane: 8 rows x 8 columns each
+    constexpr int GST = 1024 + 128;                          // bytes between column groups: 8 rows x 128 bytes, + 128 so that the two or three
+                                                             // groups a 16-lane quarter of a ds_read_b128 touches fall on different banks
+    constexpr int PLANE = KPP * GST;                         // bytes per plane in LDS: [column group of 8][row (8)][column] 16-byte words
+    constexpr int NPL = 2 * NP;                              // planes per channel group: piece x k half
+    constexpr int PBUF = NPL * PLANE;                        // bytes per patch buffer
+    constexpr int NPW = (NPL * KPP + 3) / 4;                 // patch DMA instructions per wave and channel group
+    constexpr int NPR = NP == 3 ? 6 : 3;                     // products per K16 step and 32 x 32 block
+    constexpr int KHB = KH == 5 ? 5 : 1;                     // blocks per channel group
+    constexpr int FP = KH == 5 ? 5 : 9;                      // K16 steps per block = per block sum (a kernel row of conv2, all taps of a 3 x 3 layer)
+    constexpr int NPWB = (NPW + KHB - 1) / KHB;              // patch DMA instructions per wave and block
+    static_assert(PR <= 8 && NB % 2 == 0 && KH * KH == KHB * FP && (NP == 2 || NP == 3), "8 row slots per DMA instruction; two halves");
     __shared__ __attribute__((aligned(16))) unsigned char cp_lds[2 * PBUF];
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,11 +154,15 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
     const int n31 = lane & 31, kh_ = lane >> 5;
     const unsigned lds0 = lds_addr(cp_lds);
     typedef __attribute__((address_space(3))) const bf16x8 lds_cbf8;
+    // a lane's B operand for pixel column n31 + kw: word ((column / 8) * 64 + row * 8 + column % 8) of plane (piece, k half = lane / 32)
+    unsigned vb[KH];
+#pragma unroll
+    for (int kw = 0; kw < KH; ++kw) {
+        const unsigned c = (unsigned)(n31 + kw);
+        vb[kw] = lds0 + (unsigned)(kh_ * PLANE) + (c >> 3) * (unsigned)GST + (c & 7u) * 16u;
+    }
+    const unsigned voff_a = (unsigned)lane * 16u;
     int parity = 0;
-#ifdef CP_TIME
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = __builtin_readcyclecounter();
-#endif
     for (int tile = blockIdx.x; tile < total_tiles;) {
         int nx = 0;
         if (tid == 0)
@@ -141,191 +173,212 @@ __global__ __launch_bounds__(CP_THREADS, NB == 4 ? 2 : 3) void conv_pieces_kerne
         const int rt = t % d.rtiles; t /= d.rtiles;
         const int b = t % d.B;
         const int g = t / d.B;
-        const int y0 = rt * CP_TR, x0 = ct * CP_TC;
-        // ---- patch loader: instruction q = wave * NPW + k of a channel group brings 64 words of plane q / KPP; a lane's word
-        //      (row, column) of the patch is recomputed per channel group (a few integer operations per 25 / 9 steps) rather than
-        //      kept in registers ----
+        const int y0 = rt * NB, x0 = ct * CP_TC;
+        // ---- patch loader: a DMA instruction brings 8 rows x 8 columns of one plane (lane = row * 8 + column); the lane part of
+        //      its address is the same for all of them (rows past the plane repeat the last one; columns past the row read on into
+        //      the next row or plane -- finite data for output pixels that are never stored) ----
         const unsigned char* in_g = reinterpret_cast<const unsigned char*>(act) + (size_t)b * d.in_image +
-                                    (size_t)g * d.Cg16 * 6 * d.Hp * d.Wp * 16;
+                                    (size_t)g * d.Cg16 * NPL * d.Hp * d.Wp * 16;
         const size_t plane_bytes = (size_t)d.Hp * d.Wp * 16;
-        auto issue_patch = [&](int cg, int buf) {
-            const unsigned char* src = in_g + (size_t)cg * 6 * plane_bytes;
-#pragma unroll
-            for (int k = 0; k < NPW; ++k) {
-                int q = wave * NPW + k;
-                q = q < 6 * KPP ? q : 6 * KPP - 1;           // (surplus instructions repeat the last one)
-                const int pl = q / KPP, kk = q - pl * KPP;   // wave-uniform
-                int i = kk * 64 + lane;
-                i = i < PRW ? i : PRW - 1;
-                const int r = i / PC, c = i - r * PC;
-                const int yy = y0 + r < d.Hp ? y0 + r : d.Hp - 1, xx = x0 + c < d.Wp ? x0 + c : d.Wp - 1;   // overhang: clamped (finite data)
-                dma16((unsigned)(yy * d.Wp + xx) * 16u, src + (size_t)pl * plane_bytes,
-                      __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * PBUF + pl * PLANE + kk * 1024)));
-            }
+        const int yr = y0 + (lane >> 3) < d.Hp ? y0 + (lane >> 3) : d.Hp - 1;
+        const unsigned voff_p = (unsigned)(yr * d.Wp + x0 + (lane & 7)) * 16u;
+        auto issue_dma = [&](int cg, int k) __attribute__((always_inline)) {   // this wave's k-th instruction of channel group cg
+            int q = wave * NPW + k;
+            q = q < NPL * KPP ? q : NPL * KPP - 1;           // (surplus instructions repeat the last one)
+            const int pl = q / KPP, kk = q - pl * KPP;       // wave-uniform
+            dma16(voff_p, in_g + ((size_t)cg * NPL + pl) * plane_bytes + (size_t)kk * 128,
+                  __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((cg & 1) * PBUF + pl * PLANE + kk * GST)));
         };
         // ---- weights: this wave's three fragments (pieces) of a K16 step, 16 bytes per lane each, straight from L2 into registers ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
-                                    ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * 3 * 1024;     // (wave-uniform)
-        const size_t wstep = (size_t)d.mblocks * 3 * 1024;
-        // B operand register sets.  With two, the next step's operands are requested BEFORE this step's matrix instructions: measured
-        // (round 5) on the 2-block / three-workgroups-per-CU build, the only one with room for it: 1.36 ms against 1.29 -- not used
-        constexpr int BSETS = 1;
-        bf16x8 af[2][3], bfr[BSETS][NB][3];
+                                    ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * NP * 1024;    // (wave-uniform)
+        const unsigned wstep = (unsigned)d.mblocks * NP * 1024;
+        bf16x8 af[2][NP], bfr[NB][NP];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) af[q / 3][q % 3] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-        auto load_a = [&](int s, auto o_tag) {
+        for (int q = 0; q < 2 * NP; ++q) af[q / NP][q % NP] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+        auto load_a = [&](const unsigned char* src, auto o_tag) __attribute__((always_inline)) {
             constexpr int o = decltype(o_tag)::value;
-            const unsigned char* src = wgrp + (size_t)s * wstep;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) cp_gload16(af[o][p], src + p * 1024, (unsigned)lane * 16u);
+            cp_gload16<0>(af[o][0], src, voff_a);
+            cp_gload16<1024>(af[o][1], src, voff_a);
+            if constexpr (NP == 3) cp_gload16<2048>(af[o][2], src, voff_a);
         };
-        const unsigned bbase = lds0 + (unsigned)(kh_ * PLANE + n31 * 16);
-        int cg = 0, tap = 0, kh = 0, kw = 0;                 // position of the current step
-        auto fetch_b = [&](auto set_tag, int cg_, int kh__, int kw__) {   // the B operands of the step at that position -> bfr[set]
-            constexpr int st = decltype(set_tag)::value;
-            const unsigned bt = bbase + (unsigned)((cg_ & 1) * PBUF + (kh__ * PC + kw__) * 16);
+        // B operands of one half's rows for tap k of a block whose scalar LDS offset is sb (buffer, kernel row): bfr[rows of the half]
+        auto fetch_b = [&](auto half_tag, auto k_tag, unsigned sb) __attribute__((always_inline)) {
+            constexpr int h = decltype(half_tag)::value, k = decltype(k_tag)::value;
+            constexpr int dkh = KH == 5 ? 0 : k / KH, kw = KH == 5 ? k : k % KH;
+            const unsigned va = vb[kw] + sb;
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
+            for (int j = h * H; j < (h + 1) * H; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bfr[st][j][p] = *(lds_cbf8*)(bt + (unsigned)(j * PC * 16 + p * 2 * PLANE));
+                for (int p = 0; p < NP; ++p) bfr[j][p] = *(lds_cbf8*)(va + (unsigned)((j + dkh) * 128 + p * 2 * PLANE));
         };
-        f32x16 acc[NB], tq[NB];
+        // The accumulators are register PAIRS that only inline asm adds to (cp_fold): left to the compiler, the sum of accumulator and
+        // block sum lands in the block sum's registers, the accumulators wander between two homes over the unrolled blocks and
+        // ~30 of them are spilled (and every scratch reload is a `s_waitcnt vmcnt(0)` on the weights in flight).
+        f32x2v acc[NB][8];
+        f32x16 tq[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+        for (int j = 0; j < NB; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; tq[j][e] = 0.f; }
+            for (int e = 0; e < 8; ++e) acc[j][e] = f32x2v{0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tq[j][e] = 0.f;
+        }
         const int S = d.ksteps;
         __builtin_amdgcn_s_barrier();                        // (every wave has left the previous tile's patches)
-        issue_patch(0, 0);
-        load_a(0, std::integral_constant<int, 0>());
-        load_a(1, std::integral_constant<int, 1>());
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) issue_dma(0, k);
+        asm volatile("s_nop 4" ::: "memory");                // (the weight pointer may come from v_readfirstlane: VALU-writes-SGPR -> VMEM)
+        load_a(wgrp, std::integral_constant<int, 0>());
+        load_a(wgrp + wstep, std::integral_constant<int, 1>());
+        const unsigned char* anext = wgrp + (size_t)2 * wstep;   // the next weights to request (step s + 2 behind step s; none behind the last two)
         cp_wait<0>();
         if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // patch 0 is complete for every wave
-        fetch_b(std::integral_constant<int, 0>(), 0, 0, 0);
-        CP_LAP(7);
-        int fold = 0;
-        // One K16 step.  The waves of a workgroup are NOT in lockstep: weights come per wave from L2 (two steps ahead, two register
-        // sets), the B operands from the shared patch (a step ahead), and the only barrier is at a channel group's first step --
-        // while one wave of a SIMD waits for memory or LDS, the other one's matrix instructions keep the pipe busy.
-        auto step = [&](auto o_tag, int s_) {
-            constexpr int o = decltype(o_tag)::value;
-            const bool group_start = tap == 0 && s_ > 0;
-            if (group_start) {
-                // own pieces of this group's patch (issued a whole group ago) and the weights of this step have landed; behind the
-                // barrier every wave's have -- and every wave has finished reading the other buffer
-                if (s_ + 1 < S) cp_wait_for<3>(af[o][0], af[o][1], af[o][2]); else cp_wait_for<0>(af[o][0], af[o][1], af[o][2]);
-#ifndef CP_X_NOBAR
-                __builtin_amdgcn_s_barrier();
-#endif
-#ifndef CP_X_NOFETCH
-                fetch_b(std::integral_constant<int, BSETS == 2 ? o : 0>(), cg, 0, 0);
-#endif
-            } else {
-                // the weights of this step (younger: the next step's three loads -- and the patch, when it was issued a step ago)
-#if !defined(CP_X_NOA) && !defined(CP_X_NOPATCH)
-                if (s_ + 1 >= S) cp_wait_for<0>(af[o][0], af[o][1], af[o][2]);
-                else if (tap == 1 && cg + 1 < d.Cg16) cp_wait_for<3 + NPW>(af[o][0], af[o][1], af[o][2]);
-                else cp_wait_for<3>(af[o][0], af[o][1], af[o][2]);
-#endif
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            CP_LAP(4);
-            // the next step's position
-            int n_kw = kw + 1, n_kh = kh, n_tap = tap + 1, n_cg = cg;
-            if (n_kw == d.KW) { n_kw = 0; ++n_kh; }
-            if (n_tap == d.ntaps) { n_tap = 0; n_kh = 0; ++n_cg; }
-#ifndef CP_X_NOFETCH
-            if (BSETS == 2 && n_tap != 0 && s_ + 1 < S) fetch_b(std::integral_constant<int, BSETS == 2 ? (o ^ 1) : 0>(), n_cg, n_kh, n_kw);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int bs = BSETS == 2 ? o : 0;
-#ifndef CP_X_NOMFMA
-            // six products per block into the block sums, the five small ones first
+        fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), 0u);
+        fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), 0u);
+        // The matrix instructions of one half (H rows x six products, the five small ones first) into the block sums.  FIRST: the step
+        // opens a block -- the first product starts from zero (C = 0: no register clearing).
+        auto products = [&](auto o_tag, auto half_tag, auto first_tag) __attribute__((always_inline)) {
+            constexpr int o = decltype(o_tag)::value, h = decltype(half_tag)::value;
+            constexpr bool first = decltype(first_tag)::value;
+            constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][2], bfr[bs][j][0], tq[j], 0, 0, 0);
+            for (int p = 0; p < NPR; ++p)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[bs][j][1], tq[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][2], tq[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][1], bfr[bs][j][0], tq[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][1], tq[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][0], bfr[bs][j][0], tq[j], 0, 0, 0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            CP_LAP(0);
-            // behind the matrix instructions (their operands are read at issue): the next group's patch at a group's first step
-            // (every wave is past the barrier: nobody reads that buffer any more), the weights two steps ahead into the set just
-            // used, the next step's B operands (unless that step starts a group: then after its barrier)
-#ifndef CP_X_NOPATCH
-            if (tap == 0 && cg + 1 < d.Cg16) issue_patch(cg + 1, (cg + 1) & 1);
-#endif
-#ifndef CP_X_NOA
-            if (s_ + 2 < S) load_a(s_ + 2, o_tag);
-#endif
-            kw = n_kw; kh = n_kh; tap = n_tap; cg = n_cg;
-#ifndef CP_X_NOFETCH
-            if (BSETS == 1 && tap != 0 && s_ + 1 < S) fetch_b(std::integral_constant<int, 0>(), cg, kh, kw);
-#endif
-            CP_LAP(3);
-#ifdef CP_X_NOFOLD
-            if (s_ + 1 == S)
-#else
-            if (++fold == FP)
-#endif
-            {                                                // the block sums join the accumulators: ONE rounding per FP steps
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    acc[j] += tq[j];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) tq[j][e] = 0.f;
+                for (int j = h * H; j < (h + 1) * H; ++j) {
+                    if constexpr (NP == 3)
+                        tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][PA[p]], bfr[j][PB[p]], first && p == 0 ? zero : tq[j], 0, 0, 0);
+                    else
+                        tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[o][PA[p]]), __builtin_bit_cast(f16x8, bfr[j][PB[p]]),
+                                                                       first && p == 0 ? zero : tq[j], 0, 0, 0);
                 }
-                fold = 0;
-            }
-            CP_LAP(2);
         };
-        int s2 = 0;
-        for (; s2 + 1 < S; s2 += 2) {
-            step(std::integral_constant<int, 0>(), s2);
-            step(std::integral_constant<int, 1>(), s2 + 1);
+        int kb = 0, cg = 0;                                  // block of the channel group (kernel row of conv2); channel group
+        // One K16 step (tap k of the block).  The waves of a workgroup are NOT in lockstep: weights come per wave from L2 (two steps
+        // ahead, two register sets), the B operands from the shared patch, and the only barrier is at a channel group's first step.
+        // The B operands of the next step's first half are requested between the halves (that half's registers are free once its
+        // matrix instructions have issued: operands are read at issue), the second half's behind the step: each request has half
+        // a step (12 matrix instructions) to land, without a second register set.
+        // Vector-memory queue (in order): at the top of a step [weights s][weights s + 1]; behind step 0 of a block with patch work
+        // [weights s + 2][NPWB patch instructions] join it -- steps 1 and 2 leave those in flight, step 3 waits for them.
+        // TAIL: the tile's last block -- nothing is requested behind its last two steps (a load in flight into registers the
+        // compiler considers dead would land in whatever the epilogue keeps there), and the last step's weights are the queue's last.
+        auto step = [&](auto o_tag, auto k_tag, bool gs, bool dma_block, bool more_blocks, bool tail, unsigned sb) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            if (k == 1 || k == 2) { if (dma_block) cp_wait<NP + NPWB>(); else cp_wait<NP>(); }
+            else if (k == FP - 1) { if (tail) cp_wait<0>(); else cp_wait<NP>(); }
+            else cp_wait<NP>();
+            if (k == 0 && gs) {
+                // own pieces of this group's patch (issued a whole group ago: older than any weights) have landed; behind the
+                // barrier every wave's have -- and every wave has finished reading the other buffer
+                __builtin_amdgcn_s_barrier();
+                fetch_b(std::integral_constant<int, 0>(), k_tag, sb);
+                fetch_b(std::integral_constant<int, 1>(), k_tag, sb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            products(o_tag, std::integral_constant<int, 0>(), std::integral_constant<bool, k == 0>());
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (k + 1 < FP) fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, k + 1>(), sb);
+            else if (more_blocks) fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), sb + 128u);
+            __builtin_amdgcn_sched_barrier(0);
+            products(o_tag, std::integral_constant<int, 1>(), std::integral_constant<bool, k == 0>());
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < FP - 2 || !tail) { load_a(anext, o_tag); anext += wstep; }   // into the set just used
+            if (k == 0 && dma_block) {
+#pragma unroll
+                for (int i = 0; i < NPWB; ++i) issue_dma(cg + 1, kb * NPWB + i < NPW ? kb * NPWB + i : NPW - 1);
+            }
+            if constexpr (k + 1 < FP) fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, k + 1>(), sb);
+            else if (more_blocks) fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), sb + 128u);
+            if constexpr (k + 1 == FP) {                     // the block sums join the accumulators: ONE rounding per FP steps
+                // (matrix-instruction result -> VALU read needs up to 18 wait states that the compiler does not count for asm)
+                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x2v t2 = {tq[j][2 * e], tq[j][2 * e + 1]};
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[j][e]) : "v"(t2));
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // FP steps make a block, written out: the weight register set alternates per step, so two blocks make a period when FP is odd.
+        auto block = [&](auto a_tag) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_tag)::value;
+            constexpr std::integral_constant<int, a> sa{};
+            constexpr std::integral_constant<int, a ^ 1> sb_{};
+            const bool gs = kb == 0 && cg > 0;
+            const bool dma_block = cg + 1 < d.Cg16 && kb * NPWB < NPW;
+            const bool more = kb + 1 < KHB;                  // (the next block continues this channel group: its first operands can be requested)
+            const unsigned sb = (unsigned)((cg & 1) * PBUF + kb * 128);
+            const bool tail = !more && cg + 1 == d.Cg16;
+            static_assert(FP == 5 || FP == 9, "the steps of a block are written out for 5 and 9");
+#define CP_K(n) std::integral_constant<int, n>()
+            step(sa, CP_K(0), gs, dma_block, more, tail, sb); step(sb_, CP_K(1), gs, dma_block, more, tail, sb); step(sa, CP_K(2), gs, dma_block, more, tail, sb);
+            step(sb_, CP_K(3), gs, dma_block, more, tail, sb); step(sa, CP_K(4), gs, dma_block, more, tail, sb);
+            if constexpr (FP == 9) {
+                step(sb_, CP_K(5), gs, dma_block, more, tail, sb); step(sa, CP_K(6), gs, dma_block, more, tail, sb);
+                step(sb_, CP_K(7), gs, dma_block, more, tail, sb); step(sa, CP_K(8), gs, dma_block, more, tail, sb);
+            }
+#undef CP_K
+            if (++kb == KHB) { kb = 0; ++cg; }
+        };
+        const int nblocks = S / FP;
+        int bi = 0;
+        for (; bi + 2 <= nblocks; bi += 2) {
+            block(std::integral_constant<int, 0>());
+            block(std::integral_constant<int, FP & 1>());
         }
-        if (s2 < S) step(std::integral_constant<int, 0>(), s2);
-        // ---- epilogue: bias + ReLU -> f32 NCHW planes; accumulator register 4 q + e = row 8 q + 4 (lane / 32) + e of the block ----
-        const int ow = x0 + n31;
-        const int m_blk = (mt * MB + wmq) * 32;
+        if (bi < nblocks) block(std::integral_constant<int, 0>());
+        // ---- epilogue: bias + ReLU -> f32 NCHW planes; accumulator register 4 q + e = row 8 q + 4 (lane / 32) + e of the block.
+        //      The tile's coordinates are derived AGAIN from the (laundered) tile index and lane offset: kept from the top of the
+        //      tile they would be a dozen registers live through the loop, which has none to spare ----
+        {
+            int te = tile;
+            unsigned le = voff_a;
+            asm volatile("" : "+s"(te), "+v"(le));
+            const int e_mt = te % d.mtiles; te /= d.mtiles;
+            const int e_ct = te % d.ctiles; te /= d.ctiles;
+            const int e_rt = te % d.rtiles; te /= d.rtiles;
+            const int e_b = te % d.B, e_g = te / d.B;
+            const int e_n31 = (int)(le >> 4) & 31, e_kh = (int)(le >> 9);
+            const int ow = e_ct * CP_TC + e_n31;
+            const int m_blk = (e_mt * MB + wmq) * 32;
+            // one scalar base per stored plane, one 32-bit lane offset per row of the tile (64 stores per lane: address arithmetic per
+            // store -- 64-bit multiplies in the first version -- was a tenth of the kernel's VALU time)
+            const unsigned plane = (unsigned)(d.OHp * d.OWp);
+            const unsigned char* obase = reinterpret_cast<const unsigned char*>(out + ((size_t)e_b * d.groups + e_g) * d.OC * plane);
+            const unsigned vo0 = ((unsigned)(4 * e_kh) * plane + (unsigned)((e_rt * NB + d.opad) * d.OWp + ow + d.opad)) * 4u;
+            f32x4v bl[4];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int oh = y0 + j;
-            if (oh >= d.OH || ow >= d.OW) continue;
-            float* ocol = out + ((size_t)b * d.groups + g) * d.OC * d.OHp * d.OWp + (size_t)(oh + d.opad) * d.OWp + ow + d.opad;
+            for (int q = 0; q < 4; ++q) {                    // this lane's 4 rows of each 8-row slice (the packed weights' padding rows: clamped)
+                const int m0 = m_blk + 8 * q < d.OC ? m_blk + 8 * q : d.OC - 8;
+                bl[q] = *reinterpret_cast<const f32x4v*>(bias + e_g * d.OC + m0 + 4 * e_kh);
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m0 = __builtin_amdgcn_readfirstlane(m_blk + 8 * q);
-                if (m0 >= d.OC) continue;
-                const f32x4v bl = *reinterpret_cast<const f32x4v*>(bias + g * d.OC + m0 + 4 * kh_);   // this lane's 4 rows
+            for (int j = 0; j < NB; ++j) {
+                if (ow >= d.OW || e_rt * NB + j >= d.OH) continue;       // (one exec-mask region per row of the tile)
+                const unsigned vo = vo0 + (unsigned)(j * d.OWp) * 4u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[j][4 * q + e] + bl[e];
-                    if (d.relu) v = v > 0.f ? v : 0.f;
-#ifdef CP_X_NOSTORE
-                    if (v == 12345.678f)
-#endif
-                    ocol[(size_t)(m0 + 4 * kh_ + e) * d.OHp * d.OWp] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int m0 = __builtin_amdgcn_readfirstlane(m_blk + 8 * q);
+                    if (m0 >= d.OC) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[j][2 * q + e / 2][e % 2] * d.oscale + bl[q][e];
+                        if (d.relu) v = v > 0.f ? v : 0.f;
+                        *reinterpret_cast<float*>(const_cast<unsigned char*>(obase) + (vo + (unsigned)(m0 + e) * plane * 4u)) = v;
+                    }
                 }
             }
         }
         tile = __builtin_amdgcn_readfirstlane(s_next[parity]);
         parity ^= 1;
-        CP_LAP(7);
     }
-#ifdef CP_TIME
-    if (lane == 0 && blockIdx.x < 256)
-        for (int i = 0; i < 8; ++i) cp_dbg[(((KH == 5 ? 0 : 1) * 256 + blockIdx.x) * 8 + wave) * 8 + i] = tacc[i];
-#endif
 }
 
 }  // namespace

@@ -29,6 +29,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct SplitDims {
     int B, Cg, Ctot, Hp, Wp;        // input: channels per group / in total; padded plane

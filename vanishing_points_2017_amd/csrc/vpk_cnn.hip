@@ -965,6 +965,8 @@ struct Layer {
     float* bias = nullptr;
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
+    unsigned short* whalf = nullptr;    // conv2..5: weights as scaled fp16 pairs in the same order (cnn_conv_pieces.hpp, NP = 2)
+    PieceDims pdh;                      //            and the layer's dimensions for that path (own block padding, output scale)
     SplitDims sd;
     float* wino = nullptr;      // conv2..5: G g G^T in the chunk order of the Winograd kernels (cnn_winograd.hpp)
     unsigned short* c1frag = nullptr;   // conv1: three bf16 pieces of every weight in MFMA fragment order (cnn_conv1_pieces.hpp)
@@ -997,7 +999,6 @@ struct vpk_cnn_state {
     int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
                              // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
     int conv1_group = 4;     // images per work item of conv1_pieces_kernel (VPK_CONV1_GROUP: development knob)
-    int pieces_rows = 4;     // rows per tile of conv_pieces_kernel (VPK_PIECES_ROWS: development knob)
     bool profiling = false;
     static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
     hipEvent_t ev[EV_RING][14] = {};
@@ -1013,6 +1014,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.bias) (void)hipFree(l.bias);
         if (l.ktab) (void)hipFree(l.ktab);
         if (l.wsplit) (void)hipFree(l.wsplit);
+        if (l.whalf) (void)hipFree(l.whalf);
         if (l.wino) (void)hipFree(l.wino);
         if (l.c1frag) (void)hipFree(l.c1frag);
         if (l.c1map) (void)hipFree(l.c1map);
@@ -1238,21 +1240,24 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     const bool wino = S->precision == 0 && S->algorithm >= 1;      // Winograd for the layers that are not on pieces
     const bool pieces = S->precision == 0 && S->algorithm >= 2;     // conv2 (mode 3, measurements: conv3 and conv5 too) on exact bf16 pieces
     // conv2..5 as direct convolutions on exact bf16 pieces (cnn_conv_pieces.hpp): the layer's input as P6 planes
+    const bool halves = S->precision == 0 && S->algorithm == 4;     // conv2..5 on scaled fp16 pairs (three products per step)
     auto to_p6 = [&](const float* src, unsigned short* dst, int C, int Hp, int Wp) {
-        hipLaunchKernelGGL(to_p6_kernel, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
+        if (halves) hipLaunchKernelGGL(to_planes_kernel<2>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
+        else hipLaunchKernelGGL(to_planes_kernel<3>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
     };
     auto conv_pieces = [&](int li, const unsigned short* src6, float* dst) {
-        PieceDims pd = S->L[li].pd;
+        PieceDims pd = halves ? S->L[li].pdh : S->L[li].pd;
         pd.B = batch;
-        const int nb = S->pieces_rows;                                     // rows of a tile: 4 (two workgroups per CU) or 2 (three)
+        constexpr int nb = 4;                                               // rows of a tile
         pd.rtiles = (pd.OH + nb - 1) / nb;
         const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
-        const unsigned blocks = (unsigned)std::min(total, (nb == 4 ? 2 : 3) * h->num_cu);
+        const unsigned blocks = (unsigned)std::min(total, 2 * h->num_cu);   // two workgroups per CU (LDS: two patch buffers each)
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, S->L[li].wsplit, S->L[li].bias, dst, ctr + li, total);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, halves ? S->L[li].whalf : S->L[li].wsplit, S->L[li].bias,
+                               dst, ctr + li, total);
         };
-        if (li == 1) { if (nb == 4) go(conv_pieces_kernel<5, 4>); else go(conv_pieces_kernel<5, 2>); }
-        else { if (nb == 4) go(conv_pieces_kernel<3, 4>); else go(conv_pieces_kernel<3, 2>); }
+        if (halves) { if (li == 1) go(conv_pieces_kernel<5, nb, 2>); else go(conv_pieces_kernel<3, nb, 2>); }
+        else { if (li == 1) go(conv_pieces_kernel<5, nb, 3>); else go(conv_pieces_kernel<3, nb, 3>); }
     };
     unsigned short* p6_2 = reinterpret_cast<unsigned short*>(R[R_P6_2]);
     unsigned short* p6_3 = reinterpret_cast<unsigned short*>(R[R_P6_3]);
@@ -1289,18 +1294,19 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     unsigned short* s4 = reinterpret_cast<unsigned short*>(R[R_SPLIT4]);
     unsigned short* s5 = reinterpret_cast<unsigned short*>(R[R_SPLIT5]);
     // (pieces: conv3 -> conv4 -> conv5 hand over P6 planes; a tapped f32 blob is converted for the next layer instead)
-    if (pieces && S->algorithm == 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3]); }
+    if (pieces && S->algorithm >= 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3]); }
     else if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
     else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    if (chain) conv_split(3, nullptr, s4, s5, true);
+    if (halves) { to_p6(R[R_CONV3], p6_5, 384, 32, 32); conv_pieces(3, p6_5, R[R_CONV4]); }
+    else if (chain) conv_split(3, nullptr, s4, s5, true);
     else if (S->precision == 1) conv_split(3, R[R_CONV3], nullptr, R[R_CONV4], false);
     else if (wino) conv_wino(3, R[R_CONV3], R[R_CONV4]);
     else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    if (pieces && S->algorithm == 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
+    if (pieces && S->algorithm >= 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
     else if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
     else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
@@ -1372,9 +1378,6 @@ int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     return VPK_OK;
 }
 
-#ifdef CP_TIME
-int vpk_dbg_cp(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cp_dbg), sizeof(long long) * 2 * 256 * 8 * 8); }
-#endif
 #ifdef W5_TIME
 int vpk_dbg_w5(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w5_dbg), sizeof(long long) * 256 * 12 * 8); }
 int vpk_dbg_w3(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w3_dbg), sizeof(long long) * 256 * 8 * 8); }
@@ -1382,7 +1385,7 @@ int vpk_dbg_w3(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL
 
 int vpk_cnn_set_algorithm(vpk_handle* h, int mode) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_algorithm before vpk_cnn_load");
-    if (mode < 0 || mode > 3) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 .. 3");
+    if (mode < 0 || mode > 4) return vpk_fail(h, VPK_ERR_ARG, "vpk_cnn_set_algorithm: mode must be 0 .. 4");
     h->cnn->algorithm = mode;
     return VPK_OK;
 }
@@ -1510,6 +1513,40 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             pd.mtiles = sd.mblocks / blk; pd.rtiles = (t.OH + 3) / 4; pd.ctiles = (t.OW + CP_TC - 1) / CP_TC; pd.relu = 1;
             pd.OHp = d.OHp; pd.OWp = d.OWp; pd.opad = d.opad;
             pd.in_image = (long long)pd.CGtot * 6 * d.Hp * d.Wp * 16;
+            pd.oscale = 1.f;
+            // the same layer on fp16 pairs: weights x 2^k (the largest in [2^13, 2^14)), two pieces each; 32-row blocks padded to
+            // whole tiles of four (conv4: 6 -> 8)
+            PieceDims& ph = l.pdh;
+            ph = pd;
+            ph.mblocks = (t.OC / 32 + 3) / 4 * 4;
+            ph.mtiles = ph.mblocks / 4;
+            ph.in_image = (long long)ph.CGtot * 4 * d.Hp * d.Wp * 16;
+            float wmax = 0.f;
+            for (size_t i = 0; i < w_floats; ++i) wmax = std::max(wmax, std::fabs(wsrc[i]));
+            int kexp = 0;
+            if (wmax > 0.f) { int ex; (void)std::frexp(wmax, &ex); kexp = 14 - ex; }     // wmax = f * 2^ex, f in [0.5, 1): wmax * 2^kexp in [2^13, 2^14)
+            const float wscale = std::ldexp(1.f, kexp);
+            ph.oscale = 1.f / (wscale * CP_ASCALE);
+            std::vector<unsigned short> ph_pk((size_t)t.G * ph.ksteps * ph.mblocks * 2 * 512, 0);
+            for (int g = 0; g < t.G; ++g)
+                for (int s_ = 0; s_ < ph.ksteps; ++s_)
+                    for (int mb = 0; mb < ph.mblocks; ++mb)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int m = mb * 32 + (ln & 31);
+                                const int tap = s_ % ph.ntaps, c = (s_ / ph.ntaps) * 16 + 8 * (ln >> 5) + e;
+                                float w = 0.f;
+                                if (m < t.OC) w = wsrc[((size_t)(g * t.OC + m) * t.IC + c) * t.KH * t.KH + tap] * wscale;
+                                const _Float16 h0 = (_Float16)w;
+                                const _Float16 h1 = (_Float16)(w - (float)h0);
+                                unsigned short u0, u1;
+                                memcpy(&u0, &h0, 2); memcpy(&u1, &h1, 2);
+                                const size_t base = ((((size_t)g * ph.ksteps + s_) * ph.mblocks + mb) * 2) * 512 + (size_t)ln * 8 + e;
+                                ph_pk[base] = u0;
+                                ph_pk[base + 512] = u1;
+                            }
+            VPK_HIP(h, hipMalloc((void**)&l.whalf, ph_pk.size() * sizeof(unsigned short)));
+            VPK_HIP(h, hipMemcpy(l.whalf, ph_pk.data(), ph_pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         }
         if (li == 0) {              // conv1 on the bf16 matrix cores: weight pieces in fragment order, bias - conv1(mean)
             std::vector<unsigned short> fr;
@@ -1521,7 +1558,6 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             VPK_HIP(h, hipMalloc((void**)&l.c1map, cm.size() * sizeof(float)));
             VPK_HIP(h, hipMemcpy(l.c1map, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
             if (const char* e = getenv("VPK_CONV1_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) S->conv1_group = v; }
-            if (const char* e = getenv("VPK_PIECES_ROWS")) { const int v = atoi(e); if (v == 2 || v == 4) S->pieces_rows = v; }
         }
         if (li == 1) {              // conv2: G g G^T of every 5 x 5 filter (F(2 x 2, 5 x 5))
             std::vector<float> u;
