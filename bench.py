@@ -49,7 +49,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak (--cnn-precision 1 only)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 / fp16 MFMA dense peak
+# measured on this pool with operands that change between instructions (random bits; scripts/ubench/mfma_f16_pairs.hip): power-limited
+MFMA_SUSTAINED_TFLOPS = {"bf16": 1770.0, "f16": 1675.0}
 
 
 def parse():
@@ -66,7 +68,7 @@ def parse():
                          "holds --em-wgs CUs for at most --em-slice-ms, images unfinished by then are parked and resumed by the "
                          "next launch, so no launch waits for a 99-iteration straggler; serial: ONE stream, CNN(k) then a sliced EM "
                          "launch on all CUs; lanes: round 1's scheme, whole EM batches on --em-lanes streams beside the CNN stream")
-    ap.add_argument("--em-slice-ms", type=float, default=-1.0, help="time budget of one sliced EM launch (default 4 slice / 1.6 serial)")
+    ap.add_argument("--em-slice-ms", type=float, default=-1.0, help="time budget of one sliced EM launch (default 2.5 slice / 1.6 serial)")
     ap.add_argument("--em-lanes", type=int, default=3,
                     help="EM batches in flight (HIP streams); the EM of a YUD-size batch fills <half of the CUs")
     ap.add_argument("--em-wgs", type=int, default=-1,
@@ -75,9 +77,10 @@ def parse():
     ap.add_argument("--cnn-precision", type=int, default=0, choices=[0, 1],
                     help="0: native f32 matrix instructions (default); 1: conv2..5 as six bf16 matrix products per f32 "
                          "product (vpk_cnn_set_precision, same error class; reported as its own dtype)")
-    ap.add_argument("--cnn-algorithm", type=int, default=2, choices=[0, 1, 2, 3],
-                    help="conv2..5: 2 = conv2 direct on exact bf16 pieces + conv3..5 Winograd F(2x2,3x3) on the f32 matrix cores (default, the "
-                         "library's default), 1 = Winograd everywhere (conv2: F(2x2,5x5)), 0 = direct implicit GEMM on the f32 matrix cores "
+    ap.add_argument("--cnn-algorithm", type=int, default=4, choices=[0, 1, 2, 3, 4],
+                    help="conv2..5 / fc6: 4 = direct on scaled fp16 pairs of the f32 operands, three exact products per f32 product (default, "
+                         "the library's default); 2 = conv2 / fc6 on exact bf16 triples (six products) + conv3..5 Winograd F(2x2,3x3) on the "
+                         "f32 matrix cores; 1 = Winograd everywhere (conv2: F(2x2,5x5)); 0 = direct implicit GEMM on the f32 matrix cores "
                          "(vpk_cnn_set_algorithm)")
     ap.add_argument("--cnn-fusion", type=int, default=3, choices=[0, 1, 2, 3],
                     help="conv1 + norm1 + pool1: 3 = direct convolution on the bf16 matrix cores with exact operands (uint8 raster = one "
@@ -433,14 +436,15 @@ def hlw_pass(local_rank, n_batches=10, em_wgs=128):
 def hlw_cnn_roofline(net, images, cnn_s):
     """Whole-net figure of the HLW pass's forward (library defaults): the time the matrix pipes would need at their peaks for what
     the kernels execute / the forward's wall time -- a fraction of a bound, never above 1; the algorithmic rate beside it."""
-    pipe_s, ex = 0.0, {"f32": 0.0, "bf16": 0.0}
+    pipe_s, ex = 0.0, {"f32": 0.0, "bf16": 0.0, "f16": 0.0}
     for lname in net.LAYER_FLOP:
         f_, p_ = net.executed_flop(lname, batch=101)           # (the forward runs in chunks of ~100 images)
         ex[p_] += f_ * images / 1e12
         pipe_s += f_ * images / ((MFMA_F32_PEAK_TFLOPS if p_ == "f32" else MFMA_BF16_PEAK_TFLOPS) * 1e12)
     return {"bound": "mfma", "frac": pipe_s / cnn_s, "executed_tflop_f32_mfma": ex["f32"], "executed_tflop_bf16_mfma": ex["bf16"],
+            "executed_tflop_f16_mfma": ex["f16"],
             "direct_equivalent_tflops": sum(net.LAYER_FLOP.values()) * images / cnn_s / 1e12, "unit": "TFLOP/s",
-            "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF) / the forward's wall time, nothing "
+            "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16- and fp16-MFMA flops / 2500 TF) / the forward's wall time, nothing "
                     "beside it; direct_equivalent_tflops = 6.73 GFLOP per image (SURVEY 8d) x images / the same time"}
 
 
@@ -477,31 +481,44 @@ def extra_workloads(args, local_rank):
 def cnn_algorithm_text(args):
     c1 = {3: "conv1: direct on the bf16 matrix cores, exact operands (uint8 raster = 1 bf16 piece, weights = 3 pieces: 3 products per f32 product)",
           1: "conv1: direct on v_mfma_f32", 2: "conv1: implicit GEMM on v_mfma_f32", 0: "conv1: implicit GEMM on v_mfma_f32, separate LRN / pool"}[args.cnn_fusion]
+    fc = "fc6-8: v_mfma_f32"
     if args.cnn_precision == 1:
         rest = "conv2-5: implicit GEMM on exact bf16 pieces (6 bf16 products per f32 product)"
+    elif args.cnn_algorithm == 4:
+        rest = ("conv2-5: direct on scaled fp16 PAIRS of the f32 operands (h0 = fp16(s x), h1 = fp16(s x - h0): 22 of 24 significand bits; 3 "
+                "exact fp16 products per f32 product; s a power of two per layer; block sums rounded once per kernel row x 16 channels)")
+        fc = "fc6: the same pairs, weights split in registers from the f32 stream; fc7-8: v_mfma_f32"
     elif args.cnn_algorithm >= 2:
         rest = ("conv2: direct on exact bf16 pieces (3 + 3 pieces, 6 bf16 products per f32 product, block sums rounded once per kernel row x 16 "
                 "channels); conv3-5: Winograd F(2x2,3x3) on v_mfma_f32")
+        fc = "fc6: exact bf16 pieces (6 products); fc7-8: v_mfma_f32"
     elif args.cnn_algorithm == 1:
         rest = "conv2: Winograd F(2x2,5x5), conv3-5: Winograd F(2x2,3x3), on v_mfma_f32"
     else:
         rest = "conv2-5: implicit GEMM on v_mfma_f32"
-    return c1 + "; " + rest + "; fc6-8: v_mfma_f32; f32 operands, f32 accumulation and f32 results throughout"
+    return c1 + "; " + rest + "; " + fc + "; f32 operands, f32 accumulation and f32 results throughout"
 
 
 def dtype_text(args):
-    bf = []
+    bf, hf = [], []
     if args.cnn_fusion == 3:
         bf.append("conv1")
     if args.cnn_precision == 1:
         bf.append("conv2-5")
+    elif args.cnn_algorithm == 4:
+        hf.append("conv2-5 and fc6")
     elif args.cnn_algorithm >= 2:
-        bf.append("conv2")
-    if not bf:
+        bf.append("conv2 and fc6")
+    if not bf and not hf:
         return "f32 (CNN, MFMA) + f64 (EM)"
-    return ("f32 (CNN: f32 operands / accumulation / results; %s multiply EXACT bf16 pieces of the f32 operands on the bf16 matrix cores -- "
-            "error against float64 no larger than the f32-input kernels' at any tap, tests/test_gpu_cnn.py; the other layers on v_mfma_f32) "
-            "+ f64 (EM)" % " and ".join(bf))
+    parts = []
+    if bf:
+        parts.append("%s multiply EXACT bf16 pieces of the f32 operands (three per operand) on the bf16 matrix cores" % " and ".join(bf))
+    if hf:
+        parts.append("%s multiply scaled fp16 PAIRS of the f32 operands (22 of 24 significand bits, three exact products per f32 product) on "
+                     "the fp16 matrix cores" % " and ".join(hf))
+    return ("f32 (CNN: f32 operands / accumulation / results; %s -- error against the float64 net no larger than the f32-input direct "
+            "kernels' at any tap, measured 2-4 x smaller, tests/test_gpu_cnn.py; the other layers on v_mfma_f32) + f64 (EM)" % "; ".join(parts))
 
 
 _NETS = {}
@@ -534,8 +551,8 @@ def run_workload(args, dist, rank, local_rank, world):
         serial = args.em_mode == "serial"
         # (round 5, CNN at 3.9 ms alone: 96 workgroups x 4 ms 16.4-16.5 k images/s, 128 x 3 16.6 k, 112 x 4 16.2 k, 72 x 5 15.1 k;
         #  whole-batch launches on three lanes 15.6 k -- each lane is held for its slowest image, ~17 ms)
-        em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else max(8, (count * 16) // 17))
-        slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 4.0)
+        em_wgs = 0 if serial else (args.em_wgs if args.em_wgs > 0 else max(8, (count * 27) // 17))   # 160 of 102 (scripts/knobs_r5c.sh)
+        slice_ms = args.em_slice_ms if args.em_slice_ms > 0 else (1.6 if serial else 2.5)
         rt = get_runtime(local_rank, "main" if serial else "em")
         rt_cnn = rt if serial else get_runtime(local_rank, "cnn")
         rt.handle.em_set_workgroups(em_wgs)
@@ -859,7 +876,7 @@ def run_workload(args, dist, rank, local_rank, world):
         #      never above 1; the layer's algorithmic rate (2 x MACs of the direct convolution) is `direct_equivalent_tflops`
         name = max(cnn.Net.LAYER_FLOP, key=lambda k: cnn.Net.LAYER_FLOP[k])
         setting = dict(fusion=args.cnn_fusion, precision=args.cnn_precision, algorithm=args.cnn_algorithm, batch=count)
-        peak_of = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS}
+        peak_of = {"f32": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_BF16_PEAK_TFLOPS, "f16": MFMA_BF16_PEAK_TFLOPS}
         ex_flop, pipe = cnn.Net.executed_flop(name, **setting)
         if args.cnn_precision == 1:
             kname, klabel = "conv_gemm_split_kernel", "conv_gemm_split_kernel(conv2)"
@@ -869,7 +886,9 @@ def run_workload(args, dist, rank, local_rank, world):
             kname, klabel = "conv5x5_winograd_kernel", "conv5x5_winograd_kernel(conv2)"
         else:
             kname, klabel = "conv_gemm_dma_kernelILi2ELi2ELi2ELi2ELb0", "conv_gemm_dma_kernel<2,2,2,2>(conv2)"
-        roof_cnn = {"kernel": klabel, "bound": "mfma", "matrix_instruction": "v_mfma_f32_32x32x16_bf16" if pipe == "bf16" else "v_mfma_f32_32x32x2_f32",
+        roof_cnn = {"kernel": klabel, "bound": "mfma",
+                    "matrix_instruction": {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16", "f32": "v_mfma_f32_32x32x2_f32"}[pipe],
+                    "sustained_peak_with_changing_operands": MFMA_SUSTAINED_TFLOPS.get(pipe),
                     "achieved": ex_flop * count / (layer_ms[name] * 1e-3) / 1e12, "peak": peak_of[pipe], "unit": "TFLOP/s", "traffic": None,
                     "direct_equivalent_tflops": cnn.Net.LAYER_FLOP[name] * count / (layer_ms[name] * 1e-3) / 1e12,
                     "executed_gflop_per_launch": ex_flop * count / 1e9,
@@ -877,7 +896,11 @@ def run_workload(args, dist, rank, local_rank, world):
                             "over the timed steps (HIP events on the CNN stream, %d passes; includes the layer's input conversion kernel), "
                             "i.e. with whatever ran beside it; peak = dense peak of that instruction type; direct_equivalent_tflops = the "
                             "layer's algorithmic flops (2 x MACs of the direct f32 convolution, SURVEY 8d) over the same time"
-                            % ("6 bf16 products per f32 product on 4 x 32-pixel tiles" if pipe == "bf16" else "f32 products", layer_passes)}
+                            "; sustained_peak_with_changing_operands = what the matrix cores hold with operands that change between "
+                            "instructions (scripts/ubench/mfma_f16_pairs.hip, profiles/r05_mfma_sustained.txt: the chip drops to ~1.6-1.7 GHz under "
+                            "that load) -- the kernel's practical ceiling, reported beside the nominal peak that `frac` is priced against"
+                            % ({"bf16": "6 bf16 products per f32 product on 4 x 32-pixel tiles", "f16": "3 fp16 products per f32 product on 4 x 32-pixel tiles",
+                                "f32": "f32 products"}[pipe], layer_passes)}
         roof_cnn["frac"] = roof_cnn["achieved"] / roof_cnn["peak"]
         tc = traffic.get(key + "_conv2") if key else None        # HBM bytes per launch of THIS kernel (--pmc FETCH_SIZE / WRITE_SIZE passes)
         if tc and tc.get("kernel", "") in klabel:
@@ -909,14 +932,14 @@ def run_workload(args, dist, rank, local_rank, world):
                                                        "the CNN alone (dispatches serialised)"}
         # the whole CNN stream: time the matrix pipes would need at their peaks for what the net executes, against the stream's period
         pipe_ms = 0.0
-        ex_tf = {"f32": 0.0, "bf16": 0.0}
+        ex_tf = {"f32": 0.0, "bf16": 0.0, "f16": 0.0}
         for lname in cnn.Net.LAYER_FLOP:
             f_, p_ = cnn.Net.executed_flop(lname, **setting)
             ex_tf[p_] += f_ * count / 1e12
             pipe_ms += f_ * count / (peak_of[p_] * 1e12) * 1e3
         cnn_stream = {"period_ms": cnn_ms, "executed_tflop_f32_mfma": ex_tf["f32"], "executed_tflop_bf16_mfma": ex_tf["bf16"],
-                      "matrix_pipe_ms_at_peak": pipe_ms, "frac": pipe_ms / cnn_ms,
-                      "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16-MFMA flops / 2500 TF) / the CNN stream's period per step "
+                      "executed_tflop_f16_mfma": ex_tf["f16"], "matrix_pipe_ms_at_peak": pipe_ms, "frac": pipe_ms / cnn_ms,
+                      "note": "frac = (executed f32-MFMA flops / 157.3 TF + executed bf16- and fp16-MFMA flops / 2500 TF) / the CNN stream's period per step "
                               "(HIP events around the forward on its stream, beside the EM): the share of the period the matrix pipes would be "
                               "busy at their peak rates"}
         # dominant = the kernel on the stream that bounds the step: the CNN stream runs one forward per step, each EM

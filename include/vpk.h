@@ -148,7 +148,7 @@ int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* 
 
 /* How the net's layers are computed.  The reference runs Caffe in fp32 (deploy.prototxt, evaluation.py:20: cuDNN's pick of
  * algorithm per layer); every setting below keeps f32 operands, f32 accumulation and f32 results -- what changes is which matrix
- * instruction multiplies and where the sums are rounded.  Each setting's error against the SAME net evaluated in float64 is
+ * instruction multiplies, in how many pieces the operands reach it, and where the sums are rounded.  Each setting's error against the SAME net evaluated in float64 is
  * measured by tests/test_gpu_cnn.py; the defaults are, at every tap, no further from it than the f32-input direct kernels.
  *
  * conv1 + relu1 + norm1 + pool1 (deploy.prototxt:9-55):
@@ -164,11 +164,18 @@ int vpk_cnn_set_fusion(vpk_handle* h, int mode);
  *   1            every f32 operand as the exact sum of three bf16 pieces, six bf16 matrix products per f32 product
  *                (everything above 2^-24 of the product), f32 accumulation, implicit GEMM (csrc/cnn_split_gemm.hpp) */
 int vpk_cnn_set_precision(vpk_handle* h, int mode);
-/* Algorithm of conv2..conv5 (precision 0):
- *   2  (default) conv2 (5 x 5, 2 x 48 -> 128 channels) as a DIRECT convolution on the bf16 matrix cores with exact operands --
- *      three bf16 pieces per operand, six products per f32 product, the products of a kernel row x 16 channels summed from zero
- *      and added to the accumulator with ONE rounding (csrc/cnn_conv_pieces.hpp; error against float64 0.2e-6 of the blob's
- *      scale, the f32 direct kernel's is 1.0e-6) --; conv3..conv5 as in 1
+/* Algorithm of conv2..conv5 and fc6 (precision 0):
+ *   4  (default) DIRECT convolutions (and fc6's weight stream) on the fp16 matrix cores, every f32 operand as a SCALED PAIR of fp16
+ *      numbers h0 = fp16(s x), h1 = fp16(s x - h0) -- 22 of its 24 significand bits, the remainder below 2^-23 |x| -- and THREE exact
+ *      products per f32 product (h0 h0', h0 h1', h1 h0'; the fourth is below 2^-24 of the product).  s is a power of two: per layer
+ *      for the weights (the largest lands in [2^13, 2^14)), 2^-3 for activations; the epilogue multiplies by the exact reciprocal.
+ *      Sums as in 2: the products of a kernel row x 16 channels (all taps of a 3 x 3 layer) accumulate from zero and join the f32
+ *      accumulator with ONE rounding.  Half the matrix instructions of 2 -- which matters because the matrix cores are
+ *      power-limited with real operands (1.7 PFLOP/s sustained against the 2.5 dense peak, scripts/ubench/mfma_f16_pairs.hip).
+ *      Error against the float64 net (B = 3, scale of each blob): conv2 0.25e-6, conv3..5 0.4-0.5e-6, fc6 0.4e-6 -- at every tap
+ *      below 2's and 2-4 x below the f32 direct kernels' (csrc/cnn_conv_pieces.hpp, csrc/cnn_dense_pieces.hpp)
+ *   2  conv2 (5 x 5, 2 x 48 -> 128 channels) and fc6 on the bf16 matrix cores with EXACT operands -- three bf16 pieces per operand,
+ *      six products per f32 product, block sums as in 4 (error 0.2e-6; the f32 direct kernel's is 1.0e-6) --; conv3..conv5 as in 1
  *   1  Winograd's minimal filtering on the f32-input matrix instructions: conv2 by F(2 x 2, 5 x 5) (36 instead of 100 products per
  *      2 x 2 outputs and input channel), conv3..conv5 by F(2 x 2, 3 x 3) (16 instead of 36); input / output transforms in f32.
  *      Same arithmetic type and accumulation width as the direct form; the rounding differs (products of transformed

@@ -9,7 +9,7 @@ net.set_profiling(True)
 import os
 net.set_fusion(int(os.environ.get("VPK_FUSION", "3")))
 net.set_precision(int(os.environ.get("VPK_PRECISION", "0")))
-net.set_algorithm(int(os.environ.get("VPK_ALGORITHM", "2")))
+net.set_algorithm(int(os.environ.get("VPK_ALGORITHM", "4")))
 args = sys.argv[1:]
 passes = 3
 if "--passes" in args:

@@ -148,7 +148,7 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_f32_matrix_path():
             assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
         net.set_precision(0)
-        net.set_algorithm(2)
+        net.set_algorithm(4)
 
 
 def test_split_path_beyond_4_gib_of_activations():
@@ -204,11 +204,12 @@ def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_
 
 
 def test_default_path_is_no_further_from_the_float64_net_than_the_f32_direct_kernels():
-    """The rule for moving a layer onto bf16 pieces (or onto another algorithm): against the SAME net evaluated in float64 its
-    error must not exceed, at any tap, that of the f32-input DIRECT kernels (vpk_cnn_set_fusion(1), vpk_cnn_set_algorithm(0):
-    one f32 FMA chain per output) -- factor 1, plus 2^-24 of the blob's scale for ties.  The defaults: conv1 on exact bf16
-    pieces (cnn_conv1_pieces.hpp), conv2 direct on exact bf16 pieces with block sums (cnn_conv_pieces.hpp), conv3..5 Winograd
-    F(2 x 2, 3 x 3) on the f32 matrix cores, fc6..8 f32.  B = 3 and an odd batch of 7."""
+    """The rule for moving a layer onto pieces (or onto another algorithm): against the SAME net evaluated in float64 its error
+    must not exceed, at any tap, that of the f32-input DIRECT kernels (vpk_cnn_set_fusion(1), vpk_cnn_set_algorithm(0): one f32
+    FMA chain per output) -- factor 1, plus 2^-24 of the blob's scale for ties.  Checked for the defaults -- conv1 on exact bf16
+    pieces (cnn_conv1_pieces.hpp), conv2..5 and fc6 on scaled fp16 PAIRS with block sums (algorithm 4: cnn_conv_pieces.hpp,
+    cnn_dense_pieces.hpp), fc7 / fc8 f32 -- and for round 5's first default (algorithm 2: conv2 and fc6 on exact bf16 triples,
+    conv3..5 Winograd).  B = 3 and an odd batch of 7."""
     from oracle import cnn_torch
     from vanishing_points_2017_amd import cnn, sphere_mapping, synth
     w = cnn.synthetic_weights(0)
@@ -223,18 +224,19 @@ def test_default_path_is_no_further_from_the_float64_net_than_the_f32_direct_ker
                 want = taps[cnn_torch.TAPS[tap]]
                 scale = float(np.abs(want).max())
                 err = {}
-                for name, (fusion, algorithm) in (("direct_f32", (1, 0)), ("default", (3, 2))):
+                for name, (fusion, algorithm) in (("direct_f32", (1, 0)), ("default", (3, 4)), ("triples", (3, 2))):
                     net.set_fusion(fusion)
                     net.set_algorithm(algorithm)
                     out, got = net.forward(sphere, tap=tap)
                     err[name] = (float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(out - ref).max()))
                 report[(batch, cnn_torch.TAPS[tap])] = (err, scale)
-                assert err["default"][0] <= err["direct_f32"][0] + 6e-8 * scale, (batch, cnn_torch.TAPS[tap], err, scale)
-                assert err["default"][1] <= err["direct_f32"][1] + 6e-8, (batch, cnn_torch.TAPS[tap], err)
-                assert err["default"][1] <= 2e-5
+                for name in ("default", "triples"):
+                    assert err[name][0] <= err["direct_f32"][0] + 6e-8 * scale, (name, batch, cnn_torch.TAPS[tap], err, scale)
+                    assert err[name][1] <= err["direct_f32"][1] + 6e-8, (name, batch, cnn_torch.TAPS[tap], err)
+                    assert err[name][1] <= 2e-5
     finally:
         net.set_fusion(3)
-        net.set_algorithm(2)
+        net.set_algorithm(4)
     print({k: {n: round(e[0] / v[1], 9) for n, e in v[0].items()} for k, v in report.items()})
 
 
@@ -267,5 +269,5 @@ def test_winograd_convolutions_against_the_float64_net():
                 assert err[1][0] <= 6.0 * err[0][0] + 1e-7 * scale, (batch, cnn_torch.TAPS[tap], err)
                 assert err[1][1] <= 2e-5 and err[0][1] <= 2e-5
     finally:
-        net.set_algorithm(2)                                       # the library's default
+        net.set_algorithm(4)                                       # the library's default
     print({k: ([round(e[0] / v[1], 9) for e in v[0]]) for k, v in report.items()})

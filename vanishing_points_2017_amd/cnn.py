@@ -81,9 +81,10 @@ class Net(object):
                   "fc7": 2 * 4096 * 4096, "fc8": 2 * 4096 * 400}
 
     @classmethod
-    def executed_flop(cls, layer, fusion=3, precision=0, algorithm=2, batch=102):
+    def executed_flop(cls, layer, fusion=3, precision=0, algorithm=4, batch=102):
         """(matrix-core flops the kernels EXECUTE for `layer` per image, which pipe: "f32" or "bf16") under a setting -- tile padding,
-        Winograd's product count and the six (conv1: three) bf16 products per f32 product included; the roofline's numerator."""
+        Winograd's product count and the six (conv1: three) bf16 products -- or three fp16 products, algorithm 4 -- per f32 product
+        included; the roofline's numerator.  Pipes: "f32", "bf16", "f16" (the last two: the same dense peak)."""
         alg = cls.LAYER_FLOP[layer]
         if layer == "conv1":
             if fusion == 3:      # 168 tiles x 12 waves x 72 v_mfma_f32_16x16x32_bf16 (cnn_conv1_pieces.hpp)
@@ -94,12 +95,18 @@ class Net(object):
         if layer in ("conv2", "conv3", "conv4", "conv5"):
             if precision == 1:
                 return 6.0 * alg, "bf16"
+            if algorithm == 4:      # fp16 pairs: tiles of 128 channels x 4 rows x 32 columns, 4 waves x 12 v_mfma_f32_32x32x16_f16 per K16 step
+                tiles, steps = {"conv2": (2 * 16 * 2 * 1, 75), "conv3": (1 * 8 * 1 * 3, 16 * 9), "conv4": (2 * 8 * 1 * 2, 12 * 9),
+                                "conv5": (2 * 8 * 1 * 1, 12 * 9)}[layer]       # (groups x row tiles x column tiles x channel tiles, K16 steps)
+                return tiles * steps * 4 * 12 * 2.0 * 32 * 32 * 16, "f16"
             if layer == "conv2" and algorithm >= 2:      # 64 tiles x 4 waves x 75 steps x 24 v_mfma_f32_32x32x16_bf16
                 return 64 * 4 * 75 * 24 * 2.0 * 32 * 32 * 16, "bf16"
             if algorithm >= 1:
                 return alg * (36.0 / 100.0 if layer == "conv2" else 16.0 / 36.0), "f32"
             return alg, "f32"
         pad = (-(-batch // 128) * 128) / float(batch)     # dense layers: 128-column tiles
+        if layer == "fc6" and algorithm >= 2 and precision == 0:      # cnn_dense_pieces.hpp: six bf16 / three fp16 products per f32 product
+            return alg * pad * (3.0 if algorithm == 4 else 6.0), "f16" if algorithm == 4 else "bf16"
         return alg * pad, "f32"
 
     def set_fusion(self, on=3):
@@ -108,8 +115,10 @@ class Net(object):
         self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
     def set_algorithm(self, mode):
-        """conv2..5: 2 (default) = conv2 direct on exact bf16 pieces + conv3..5 Winograd F(2 x 2, 3 x 3) on the f32 matrix cores,
-        1 = Winograd everywhere (conv2: F(2 x 2, 5 x 5)), 0 = direct implicit GEMM on the f32 matrix cores (include/vpk.h)."""
+        """conv2..5 and fc6: 4 (default) = direct convolutions / weight stream on SCALED fp16 PAIRS of the f32 operands (three exact
+        products per f32 product), 2 = conv2 and fc6 on exact bf16 triples (six products) + conv3..5 Winograd F(2 x 2, 3 x 3) on the
+        f32 matrix cores (round 5's first default), 3 = as 2 with conv3 and conv5 on triples too, 1 = Winograd everywhere
+        (conv2: F(2 x 2, 5 x 5)), 0 = direct implicit GEMM on the f32 matrix cores (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_algorithm(self.rt.h, int(mode)))
 
     def set_precision(self, mode):

@@ -48,6 +48,7 @@ struct PieceDims {
     int relu;
     int OHp, OWp, opad;                         // f32 NCHW output planes
     long long in_image;                         // bytes per image of the input tensor (planes of 16-byte words)
+    int o_cgtot, o_Hp, o_Wp, o_pad;             // the NEXT layer's piece planes (written instead of the f32 planes when the kernel gets them)
     float oscale;                               // 1 / (weight scale x activation scale) of the fp16-pair operands (a power of two); 1 for bf16 pieces
 };
 
@@ -130,6 +131,7 @@ template <int KH, int NB, int NP>
 __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
                                                                      const unsigned short* __restrict__ wfrag,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                                     unsigned short* __restrict__ out_planes,
                                                                      int* __restrict__ tile_counter, int total_tiles) {
     constexpr int MB = 4;                                    // 32-row blocks per tile
     constexpr int H = NB / 2;                                // rows per half (the halves' B operands are fetched half a step apart)
@@ -359,6 +361,34 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                 const int m0 = m_blk + 8 * q < d.OC ? m_blk + 8 * q : d.OC - 8;
                 bl[q] = *reinterpret_cast<const f32x4v*>(bias + e_g * d.OC + m0 + 4 * e_kh);
             }
+            if (NP == 2 && out_planes) {
+                // the NEXT layer's input: fp16 pairs of CP_ASCALE x (ReLU(result)) in its piece planes (interior only: the border is the
+                // arena's zeros).  A lane holds 4 consecutive channels of an 8-channel word, lane + 32 the other 4: 8-byte stores that
+                // the two halves of the wave complete to whole words.
+                unsigned char* pbase = reinterpret_cast<unsigned char*>(out_planes) + (size_t)e_b * d.o_cgtot * 4 * d.o_Hp * d.o_Wp * 16;
+                const unsigned wplane = (unsigned)(d.o_Hp * d.o_Wp) * 16u;
+                const unsigned vo_p = (unsigned)((e_rt * NB + d.o_pad) * d.o_Wp + ow + d.o_pad) * 16u + 8u * (unsigned)e_kh;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (ow >= d.OW || e_rt * NB + j >= d.OH) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m0 = __builtin_amdgcn_readfirstlane(m_blk + 8 * q);
+                        if (m0 >= d.OC) continue;
+                        const int c0 = e_g * d.OC + m0;                                  // first channel of the 8-channel word (wave-uniform)
+                        unsigned short h0[4], h1[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[j][2 * q + e / 2][e % 2] * d.oscale + bl[q][e];
+                            if (d.relu) v = v > 0.f ? v : 0.f;
+                            split2h(v * CP_ASCALE, h0[e], h1[e]);
+                        }
+                        const unsigned w0 = ((unsigned)(c0 >> 4) * 4u + (unsigned)((c0 >> 3) & 1)) * wplane + vo_p + (unsigned)(j * d.o_Wp) * 16u;
+                        *reinterpret_cast<u32x2*>(pbase + w0) = u32x2{(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
+                        *reinterpret_cast<u32x2*>(pbase + (w0 + 2u * wplane)) = u32x2{(unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16)};
+                    }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (ow >= d.OW || e_rt * NB + j >= d.OH) continue;       // (one exec-mask region per row of the tile)

@@ -24,7 +24,7 @@ namespace {
 constexpr int DP_THREADS = 512;
 constexpr int DP_BM = 256, DP_BN = 128;         // rows (outputs) x columns (images) of a tile
 constexpr int DP_CHUNK = 32;                    // k per chunk = two K16 steps
-constexpr int DP_STAGE = 3 * 2 * 4 * 1024;      // bytes of one chunk's B fragments: [piece][step][column block][lane][8 bf16]
+template <int NP> constexpr int DP_STAGE = NP * 2 * 4 * 1024;   // bytes of one chunk's B fragments: [piece][step][column block][lane][8]
 constexpr int DP_NST = 3;
 constexpr int DP_FOLD = 8;                      // chunks per block sum
 
@@ -32,9 +32,12 @@ struct DenseDims {
     int N, K, OC;                               // images, inputs, outputs
     int chunks, kparts, cpp;                    // K / 32; split-K parts; chunks per part
     int mtiles, ntiles;
+    float wscale, oscale;                       // fp16 pairs (NP = 2): weights x wscale before the split; partials x oscale (powers of two)
 };
 
-// X f32 [N][K] -> B fragments [column tile][chunk][piece][step][column block][lane][8] bf16 (columns >= N: zeros)
+// X f32 [N][K] -> B fragments [column tile][chunk][piece][step][column block][lane][8] (columns >= N: zeros): NP = 3 bf16 triples,
+// NP = 2 fp16 pairs of CP_ASCALE x (cnn_conv_pieces.hpp)
+template <int NP>
 __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int N, int K,
                                                           int chunks) {
     const int c = blockIdx.x, nt = blockIdx.y;
@@ -54,10 +57,13 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restric
     }
     unsigned short p[3][16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
-    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)nt * chunks + c) * (DP_STAGE / 2));
+    for (int e = 0; e < 16; ++e) {
+        if (NP == 3) split3(v[e], p[0][e], p[1][e], p[2][e]);
+        else split2h(v[e] * CP_ASCALE, p[0][e], p[1][e]);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)nt * chunks + c) * (DP_STAGE<NP> / 2));
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             u32x4 w4;
@@ -67,10 +73,28 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restric
         }
 }
 
+// Caffe's (out, in) weight matrix -> tile order [row tile of 256][chunk of 32 k][row][k] (rows past OC: zeros), once at load: the
+// kernel then streams each tile's K range as one contiguous run (in Caffe's layout a wave's 32 rows are 32 separate 128-byte
+// pieces 230 KB apart: 3.0 TB/s; in tile order see DESIGN.md)
+__global__ void dense_tile_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int OC, int K, int chunks, long long total4) {
+    const long long o4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o4 >= total4) return;
+    const int kk4 = (int)(o4 % (DP_CHUNK / 4));
+    const int r = (int)((o4 / (DP_CHUNK / 4)) % DP_BM);
+    const long long tc = o4 / ((DP_CHUNK / 4) * DP_BM);
+    const int c = (int)(tc % chunks);
+    const int mt = (int)(tc / chunks);
+    const int row = mt * DP_BM + r;
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if (row < OC) v = *reinterpret_cast<const f32x4v*>(w + (size_t)row * K + (size_t)c * DP_CHUNK + 4 * kk4);
+    reinterpret_cast<f32x4v*>(out)[o4] = v;
+}
+
+template <int NP>
 __global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d, const float* __restrict__ w,
                                                                      const unsigned short* __restrict__ xfrag, float* __restrict__ part,
                                                                      int* __restrict__ item_counter, int total_items) {
-    __shared__ __attribute__((aligned(16))) unsigned char dp_lds[DP_NST * DP_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char dp_lds[DP_NST * DP_STAGE<NP>];
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,20 +113,21 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d
         const int c0 = ks * d.cpp, c1 = c0 + d.cpp < d.chunks ? c0 + d.cpp : d.chunks;
         const int row = mt * DP_BM + 32 * wave + r31;
         const bool row_ok = row < d.OC;
-        const f32x4v* wrow = reinterpret_cast<const f32x4v*>(w + (size_t)(row_ok ? row : d.OC - 1) * d.K + 16 * h);
-        const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(xfrag) + (size_t)nt * d.chunks * DP_STAGE;
+        // (weights in TILE order, dense_tile_weights_kernel: a chunk of a tile is 32 KB contiguous, a wave's 32 rows 4 KB of it)
+        const f32x4v* wrow = reinterpret_cast<const f32x4v*>(w + ((size_t)mt * d.chunks * DP_BM + 32 * wave + r31) * DP_CHUNK + 16 * h);
+        const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(xfrag) + (size_t)nt * d.chunks * DP_STAGE<NP>;
         f32x4v araw[2][4];                                   // the 16 weights of this lane for chunks c and c + 1 (two register sets)
         auto load_a = [&](int c, auto o_tag) {
             constexpr int o = decltype(o_tag)::value;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) araw[o][q] = wrow[(size_t)c * (DP_CHUNK / 4) + q];
+            for (int q = 0; q < 4; ++q) araw[o][q] = wrow[(size_t)c * (DP_BM * DP_CHUNK / 4) + q];
         };
-        auto issue_b = [&](int c) {                           // 24 fragments of 1 KB: wave w brings 3 w .. 3 w + 2
-            const unsigned char* src = xsrc + (size_t)c * DP_STAGE;
-            const unsigned dst = lds0 + (unsigned)((c % DP_NST) * DP_STAGE);
+        auto issue_b = [&](int c) {                           // 8 NP fragments of 1 KB: wave w brings NP w .. NP w + NP - 1
+            const unsigned char* src = xsrc + (size_t)c * DP_STAGE<NP>;
+            const unsigned dst = lds0 + (unsigned)((c % DP_NST) * DP_STAGE<NP>);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int f = 3 * wave + k;
+            for (int k = 0; k < NP; ++k) {
+                const int f = NP * wave + k;
                 dma16((unsigned)(f * 1024 + lane * 16), src, __builtin_amdgcn_readfirstlane(dst + (unsigned)f * 1024u));
             }
         };
@@ -121,19 +146,23 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d
         // for its own LDS reads.)
         auto chunk = [&](auto o_tag, int c) {
             constexpr int o = decltype(o_tag)::value;
-            // chunk c's weights and B fragments (own pieces) have landed; younger: chunk c + 1's 4 + 3 requests
-            if (c + 1 < c1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk c's weights and B fragments (own pieces) have landed; younger: chunk c + 1's 4 + NP requests
+            if (c + 1 < c1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (c == c0 && tid == 0) { asm volatile("" : "+v"(nx)); s_next[parity] = nx + (int)gridDim.x; }
             __builtin_amdgcn_s_barrier();                    // ... for every wave; and every wave is done with chunk c - 1's stage
             // split this lane's 16 weights: step A = values 0..7, step B = values 8..15
-            bf16x8 af[2][3];
+            bf16x8 af[2][NP];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 unsigned short p[3][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split3(row_ok ? araw[o][2 * s + (e >> 2)][e & 3] : 0.f, p[0][e], p[1][e], p[2][e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float wv = row_ok ? araw[o][2 * s + (e >> 2)][e & 3] : 0.f;
+                    if (NP == 3) split3(wv, p[0][e], p[1][e], p[2][e]);
+                    else split2h(wv * d.wscale, p[0][e], p[1][e]);
+                }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NP; ++q) {
                     u32x4 w4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w4[e] = (unsigned)p[q][2 * e] | ((unsigned)p[q][2 * e + 1] << 16);
@@ -141,26 +170,23 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d
                 }
             }
             if (c + 2 < c1) { load_a(c + 2, o_tag); issue_b(c + 2); }   // (stage (c + 2) % 3 held chunk c - 1)
-            const unsigned stage = lds0 + (unsigned)((c % DP_NST) * DP_STAGE + lane * 16);
+            const unsigned stage = lds0 + (unsigned)((c % DP_NST) * DP_STAGE<NP> + lane * 16);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 bfr[4][3];
+                bf16x8 bfr[4][NP];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) bfr[j][q] = *(lds_cbf8*)(stage + (unsigned)((((q * 2 + s) * 4) + j) * 1024));
+                    for (int q = 0; q < NP; ++q) bfr[j][q] = *(lds_cbf8*)(stage + (unsigned)((((q * 2 + s) * 4) + j) * 1024));
+                constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};   // (small products first)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2], bfr[j][0], tq[j], 0, 0, 0);
+                for (int pr = 0; pr < (NP == 3 ? 6 : 3); ++pr)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bfr[j][1], tq[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][2], tq[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bfr[j][0], tq[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][1], tq[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bfr[j][0], tq[j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (NP == 3) tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][PA[pr]], bfr[j][PB[pr]], tq[j], 0, 0, 0);
+                        else tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[s][PA[pr]]),
+                                                                            __builtin_bit_cast(f16x8, bfr[j][PB[pr]]), tq[j], 0, 0, 0);
+                    }
             }
             if (++fold == DP_FOLD || c + 1 == c1) {
 #pragma unroll
@@ -187,7 +213,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dense_pieces_kernel(DenseDims d
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (mt * DP_BM + 32 * wave + 8 * q >= d.OC) continue;
-                f32x4v v4 = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                f32x4v v4 = {acc[j][4 * q] * d.oscale, acc[j][4 * q + 1] * d.oscale, acc[j][4 * q + 2] * d.oscale, acc[j][4 * q + 3] * d.oscale};
                 *reinterpret_cast<f32x4v*>(prow + 8 * q) = v4;
             }
         }

@@ -965,6 +965,7 @@ struct Layer {
     float* bias = nullptr;
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
+    float hscale = 1.f;                 // fc6: the power of two its weights are multiplied by before the fp16 split (largest in [2^13, 2^14))
     unsigned short* whalf = nullptr;    // conv2..5: weights as scaled fp16 pairs in the same order (cnn_conv_pieces.hpp, NP = 2)
     PieceDims pdh;                      //            and the layer's dimensions for that path (own block padding, output scale)
     SplitDims sd;
@@ -974,7 +975,7 @@ struct Layer {
     WinoDims wd;
     Wino5Dims wd5;
     PieceDims pd;               // conv2..5 on exact bf16 pieces from an LDS-resident patch (cnn_conv_pieces.hpp)
-    float* wraw = nullptr;      // fc6: the weights in Caffe's own (out, in) layout, read by dense_pieces_kernel (cnn_dense_pieces.hpp)
+    float* wraw = nullptr;      // fc6: the f32 weights in tile order (dense_tile_weights_kernel), streamed by dense_pieces_kernel (cnn_dense_pieces.hpp)
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -994,7 +995,7 @@ struct vpk_cnn_state {
     // optional per-layer timing (HIP events on the handle's stream)
     int split_variant = 0;   // (development) tiling of the split GEMM
     int precision = 0;       // vpk_cnn_set_precision: 0 = native f32 MFMA, 1 = conv2..5 on the bf16 matrix cores (3-piece split)
-    int algorithm = 2;       // vpk_cnn_set_algorithm: 0 = direct f32, 1 = Winograd on the f32 matrix cores, 2 (default) = conv2..5 as
+    int algorithm = 4;       // vpk_cnn_set_algorithm: 4 = conv2..5 / fc6 on scaled fp16 pairs (default), 2 = conv2 / fc6 on bf16 triples + Winograd, ...
                              // direct convolutions on exact bf16 pieces (cnn_conv_pieces.hpp)
     int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
                              // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
@@ -1245,16 +1246,18 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         if (halves) hipLaunchKernelGGL(to_planes_kernel<2>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
         else hipLaunchKernelGGL(to_planes_kernel<3>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
     };
-    auto conv_pieces = [&](int li, const unsigned short* src6, float* dst) {
+    // (planes_next: the next layer's input planes, written by the epilogue instead of the f32 blob -- fp16 pairs only)
+    auto conv_pieces = [&](int li, const unsigned short* src6, float* dst, unsigned short* planes_next = nullptr) {
         PieceDims pd = halves ? S->L[li].pdh : S->L[li].pd;
         pd.B = batch;
+        if (planes_next) { const PieceDims& nx = S->L[li + 1].pdh; pd.o_cgtot = nx.CGtot; pd.o_Hp = nx.Hp; pd.o_Wp = nx.Wp; pd.o_pad = 1; }
         constexpr int nb = 4;                                               // rows of a tile
         pd.rtiles = (pd.OH + nb - 1) / nb;
         const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
         const unsigned blocks = (unsigned)std::min(total, 2 * h->num_cu);   // two workgroups per CU (LDS: two patch buffers each)
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, halves ? S->L[li].whalf : S->L[li].wsplit, S->L[li].bias,
-                               dst, ctr + li, total);
+                               dst, planes_next, ctr + li, total);
         };
         if (halves) { if (li == 1) go(conv_pieces_kernel<5, nb, 2>); else go(conv_pieces_kernel<3, nb, 2>); }
         else { if (li == 1) go(conv_pieces_kernel<5, nb, 3>); else go(conv_pieces_kernel<3, nb, 3>); }
@@ -1294,19 +1297,23 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     unsigned short* s4 = reinterpret_cast<unsigned short*>(R[R_SPLIT4]);
     unsigned short* s5 = reinterpret_cast<unsigned short*>(R[R_SPLIT5]);
     // (pieces: conv3 -> conv4 -> conv5 hand over P6 planes; a tapped f32 blob is converted for the next layer instead)
-    if (pieces && S->algorithm >= 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3]); }
+    // (fp16 pairs: conv3 -> conv4 -> conv5 hand over piece planes -- conv3's epilogue writes conv4's input into p6_5, conv4's writes
+    //  conv5's into p6_3, which conv3 has finished reading; a tapped f32 blob is written as such and converted for the next layer)
+    const bool hand3 = halves && tap != 4, hand4 = halves && tap != 5;
+    if (pieces && S->algorithm >= 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3], hand3 ? p6_5 : nullptr); }
     else if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
     else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    if (halves) { to_p6(R[R_CONV3], p6_5, 384, 32, 32); conv_pieces(3, p6_5, R[R_CONV4]); }
+    if (halves) { if (!hand3) to_p6(R[R_CONV3], p6_5, 384, 32, 32); conv_pieces(3, p6_5, R[R_CONV4], hand4 ? p6_3 : nullptr); }
     else if (chain) conv_split(3, nullptr, s4, s5, true);
     else if (S->precision == 1) conv_split(3, R[R_CONV3], nullptr, R[R_CONV4], false);
     else if (wino) conv_wino(3, R[R_CONV3], R[R_CONV4]);
     else launch_dma(h, conv_gemm_dma_kernel<1, 4, 3, 1, false>, dims(3), 96, R[R_CONV3], S->L[3], R[R_CONV4], 1, ctr + 3);
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
-    if (pieces && S->algorithm >= 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
+    if (hand4) conv_pieces(4, p6_3, R[R_CONV5]);
+    else if (pieces && S->algorithm >= 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
     else if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
     else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
@@ -1321,17 +1328,27 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
         if (li == 5 && pieces) {
-            // fc6 on exact bf16 pieces: the input split into B fragments, the weights streamed as they are (cnn_dense_pieces.hpp)
+            // fc6 on pieces: the input split into B fragments, the weights streamed as they are and split in registers
+            // (cnn_dense_pieces.hpp): exact bf16 triples, or scaled fp16 pairs under vpk_cnn_set_algorithm(4)
             DenseDims dd;
             dd.N = batch; dd.K = d.K; dd.OC = d.OC; dd.chunks = d.K / DP_CHUNK; dd.kparts = 45; dd.cpp = dd.chunks / dd.kparts;
             dd.mtiles = (d.OC + DP_BM - 1) / DP_BM; dd.ntiles = (batch + DP_BN - 1) / DP_BN;
-            const size_t need = (size_t)dd.ntiles * dd.chunks * DP_STAGE;
+            dd.wscale = halves ? S->L[5].hscale : 1.f;
+            dd.oscale = halves ? 1.f / (S->L[5].hscale * CP_ASCALE) : 1.f;
+            const size_t need = (size_t)dd.ntiles * dd.chunks * DP_STAGE<3>;
             if ((rc = vpk_reserve(h, (void**)&S->xfrag, &S->xfrag_bytes, need, "hipMalloc(fc6 input fragments)"))) return rc;
-            hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch, d.K,
-                               dd.chunks);
             const int total = dd.mtiles * dd.ntiles * dd.kparts;
-            hipLaunchKernelGGL(dense_pieces_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
-                               S->xfrag, R[R_PART], ctr + li, total);
+            if (halves) {
+                hipLaunchKernelGGL(dense_split_kernel<2>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
+                                   d.K, dd.chunks);
+                hipLaunchKernelGGL(dense_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
+                                   S->xfrag, R[R_PART], ctr + li, total);
+            } else {
+                hipLaunchKernelGGL(dense_split_kernel<3>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
+                                   d.K, dd.chunks);
+                hipLaunchKernelGGL(dense_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
+                                   S->xfrag, R[R_PART], ctr + li, total);
+            }
             d.ksplit = dd.kparts;
         } else
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, true>, d, 128, fc_in, S->L[li], R[R_PART], 1, ctr + li);
@@ -1459,7 +1476,20 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((p_floats + 255) / 256)), dim3(256), 0, h->stream, raw,
                            l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
         VPK_HIP(h, hipStreamSynchronize(h->stream));
-        if (li == 5) l.wraw = raw;      // fc6: also read in its own layout (cnn_dense_pieces.hpp)
+        if (li == 5) {                  // fc6: also read in its own layout (cnn_dense_pieces.hpp)
+            const int chunks = d.K / DP_CHUNK, mtiles = (t.OC + DP_BM - 1) / DP_BM;
+            const long long total4 = (long long)mtiles * chunks * DP_BM * (DP_CHUNK / 4);
+            VPK_HIP(h, hipMalloc((void**)&l.wraw, (size_t)total4 * 16));
+            hipLaunchKernelGGL(dense_tile_weights_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, h->stream, raw, l.wraw, t.OC, d.K,
+                               chunks, total4);
+            VPK_HIP(h, hipStreamSynchronize(h->stream));
+            VPK_HIP(h, hipFree(raw));
+            float wmax = 0.f;
+            for (size_t i = 0; i < w_floats; ++i) wmax = std::max(wmax, std::fabs(blobs[2 * li][i]));
+            int ex = 0;
+            if (wmax > 0.f) (void)std::frexp(wmax, &ex);
+            l.hscale = std::ldexp(1.f, wmax > 0.f ? 14 - ex : 0);
+        }
         else VPK_HIP(h, hipFree(raw));
         if (li < 5) {   // convolution: byte offset of tap k from the patch origin, in the bordered planes;
                         // the K padding (conv1: 121 -> 128) points at offset 0 and meets zero weights
