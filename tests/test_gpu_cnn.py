@@ -240,6 +240,39 @@ def test_default_path_is_no_further_from_the_float64_net_than_the_f32_direct_ker
     print({k: {n: round(e[0] / v[1], 9) for n, e in v[0].items()} for k, v in report.items()})
 
 
+def test_fp16_pairs_over_the_operand_range():
+    """The fp16 pairs of vpk_cnn_set_algorithm(4) live in fp16's exponent range: weights are brought there by a power of two per layer,
+    activations by a fixed 2^-3 (cnn_conv_pieces.hpp).  Nets whose blobs are 128 x larger / smaller than the synthetic net's -- conv2's
+    weights and bias x 2^7, conv3's weights x 2^-7 (and the other way round: small activations fall into fp16's denormals, which the
+    matrix cores multiply) -- must still be no further from the float64 net than the f32 direct kernels, at every tap behind conv2."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, sphere_mapping, synth
+    base = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=3, start=20)])
+    report = {}
+    for f2 in (128.0, 1.0 / 128.0):
+        w = {k: (np.array(v[0], copy=True), np.array(v[1], copy=True)) for k, v in base.items()}
+        w["conv2"] = (w["conv2"][0] * np.float32(f2), w["conv2"][1] * np.float32(f2))
+        w["conv3"] = (w["conv3"][0] * np.float32(1.0 / f2), w["conv3"][1])
+        ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
+        net = cnn.Net(w, mean)
+        for tap in (2, 3, 4, 5, 6, 8):                             # conv2, pool2, conv3, conv4, conv5, fc6
+            want = taps[cnn_torch.TAPS[tap]]
+            scale = float(np.abs(want).max())
+            err = {}
+            for name, (fusion, algorithm) in (("direct_f32", (1, 0)), ("pairs", (3, 4))):
+                net.set_fusion(fusion)
+                net.set_algorithm(algorithm)
+                out, got = net.forward(sphere, tap=tap)
+                assert np.isfinite(got).all() and np.isfinite(out).all()
+                err[name] = (float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(out - ref).max()))
+            report[(f2, cnn_torch.TAPS[tap])] = {n: round(e[0] / scale, 9) for n, e in err.items()}
+            assert err["pairs"][0] <= err["direct_f32"][0] + 6e-8 * scale, (f2, cnn_torch.TAPS[tap], err, scale)
+            assert err["pairs"][1] <= err["direct_f32"][1] + 6e-8, (f2, cnn_torch.TAPS[tap], err)
+    print(report)
+
+
 def test_winograd_convolutions_against_the_float64_net():
     """vpk_cnn_set_algorithm(1): conv2 by Winograd F(2 x 2, 5 x 5) and conv3..5 by F(2 x 2, 3 x 3) on the f32 matrix
     cores (cnn_winograd.hpp).  Direct and Winograd paths are measured against the SAME net evaluated in float64 (B = 3 and

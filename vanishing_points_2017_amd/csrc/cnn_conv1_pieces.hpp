@@ -38,8 +38,9 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
 
 // [m tile 6][K step 6][piece 3][lane 64][8] bf16: the A operand of v_mfma_f32_16x16x32_bf16 for output channels
 // 16 mt + lane % 16, k = 8 (lane / 16) + e -> kernel row 2 s + (lane / 32), tap 8 ((lane / 16) % 2) + e (zero beyond 10)
-inline void conv1_pieces_weights(const float* w, std::vector<unsigned short>& out) {
-    out.assign((size_t)6 * C1B_STEPS * 3 * 64 * 8, 0);
+// np = 2: scaled fp16 pairs instead (cnn_conv_pieces.hpp; the raster's integers are exact fp16 numbers too): x scale, two pieces
+inline void conv1_pieces_weights(const float* w, std::vector<unsigned short>& out, int np = 3, float scale = 1.f) {
+    out.assign((size_t)6 * C1B_STEPS * np * 64 * 8, 0);
     auto rne = [](float x) { unsigned b; memcpy(&b, &x, 4); return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u; };
     for (int mt = 0; mt < 6; ++mt)
         for (int s = 0; s < C1B_STEPS; ++s)
@@ -48,6 +49,15 @@ inline void conv1_pieces_weights(const float* w, std::vector<unsigned short>& ou
                     const int q = ln >> 4, kh = 2 * s + (q >> 1), kw = 8 * (q & 1) + e, oc = 16 * mt + (ln & 15);
                     if (kh > 10 || kw > 10) continue;
                     const float x = w[(size_t)oc * 121 + kh * 11 + kw];
+                    if (np == 2) {
+                        const float xs = x * scale;
+                        const _Float16 h0 = (_Float16)xs;
+                        const _Float16 h1 = (_Float16)(xs - (float)h0);
+                        const size_t at2 = ((((size_t)mt * C1B_STEPS + s) * 2) * 64 + ln) * 8 + e;
+                        memcpy(&out[at2], &h0, 2);
+                        memcpy(&out[at2 + 512], &h1, 2);
+                        continue;
+                    }
                     const unsigned b0 = rne(x);                    // the three pieces of split3() (cnn_split_gemm.hpp)
                     float f0; memcpy(&f0, &b0, 4);
                     const float r1 = x - f0;
@@ -83,10 +93,11 @@ inline void conv1_pieces_cmap(const float* w, const float* bias, const float* me
         }
 }
 
+template <int NP>
 __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsigned char* __restrict__ sphere,
                                                                       const unsigned short* __restrict__ wfrag,
                                                                       const float* __restrict__ cmap, float* __restrict__ out,
-                                                                      int OHp, int OWp, int opad, int batch, int group,
+                                                                      int OHp, int OWp, int opad, int batch, int group, float oscale,
                                                                       int* __restrict__ item_counter, int total_items) {
     __shared__ __attribute__((aligned(16))) unsigned short Xs[2][C1B_XS];
     __shared__ __attribute__((aligned(16))) float Cs[96 + 4][C1D_LD];     // channel c in row c + 2; rows 0, 1, 98, 99 stay 0 (LRN halo)
@@ -97,12 +108,12 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
     const int q = lane >> 4, c16 = lane & 15;
     if (tid < C1D_LD) Cs[0][tid] = Cs[1][tid] = Cs[98][tid] = Cs[99][tid] = 0.f;
     // ---- this wave's weight fragments: 18 x 16 bytes per lane, for the lifetime of the workgroup ----
-    bf16x8 A[C1B_STEPS][3];
+    bf16x8 A[C1B_STEPS][NP];
 #pragma unroll
     for (int s = 0; s < C1B_STEPS; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            A[s][p] = *reinterpret_cast<const bf16x8*>(wfrag + ((((size_t)mtile * C1B_STEPS + s) * 3 + p) * 64 + lane) * 8);
+        for (int p = 0; p < NP; ++p)
+            A[s][p] = *reinterpret_cast<const bf16x8*>(wfrag + ((((size_t)mtile * C1B_STEPS + s) * NP + p) * 64 + lane) * 8);
     // ---- B operands: column of the patch this lane feeds in N tile j, and where its eight pixels of K step 0 start ----
     lds_cu32x2* bp[4];
 #pragma unroll
@@ -119,11 +130,17 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         const int y = 4 * (C1_PR - 1) * pr + p_row, x = 4 * (C1_PC - 1) * pc + 4 * p_q;   //  (it only meets zero weights and
         return (y < 500 ? y : 499) * 500 + (x < 496 ? x : 496);         //   conv outputs outside the blob, which are zeroed)
     };
-    auto patch_store = [&](unsigned v, int buf) {                        // uint8 -> bf16: exact, the high half of the f32
+    auto patch_store = [&](unsigned v, int buf) {                        // uint8 -> bf16: exact, the high half of the f32 (fp16: exact too)
         if (p_on) {
             u32x2 w2;
-            w2[0] = (__float_as_uint((float)(v & 255u)) >> 16) | (__float_as_uint((float)((v >> 8) & 255u)) & 0xffff0000u);
-            w2[1] = (__float_as_uint((float)((v >> 16) & 255u)) >> 16) | (__float_as_uint((float)(v >> 24)) & 0xffff0000u);
+            if (NP == 3) {
+                w2[0] = (__float_as_uint((float)(v & 255u)) >> 16) | (__float_as_uint((float)((v >> 8) & 255u)) & 0xffff0000u);
+                w2[1] = (__float_as_uint((float)((v >> 16) & 255u)) >> 16) | (__float_as_uint((float)(v >> 24)) & 0xffff0000u);
+            } else {
+                auto h = [](unsigned x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)x); };
+                w2[0] = h(v & 255u) | (h((v >> 8) & 255u) << 16);
+                w2[1] = h((v >> 16) & 255u) | (h(v >> 24) << 16);
+            }
             *reinterpret_cast<u32x2*>(&Xs[buf][p_row * C1B_PCOLS + 4 * p_q]) = w2;
         }
     };
@@ -187,9 +204,12 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
                 bf[j] = __builtin_bit_cast(bf16x8, t4);
             }
 #pragma unroll
-            for (int p = 2; p >= 0; --p)
+            for (int p = NP - 1; p >= 0; --p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][p], bf[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (NP == 3) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][p], bf[j], acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[s][p]), __builtin_bit_cast(f16x8, bf[j]), acc[j], 0, 0, 0);
+                }
         }
         lds_barrier();                                                   // (the previous tile's pooling has read Cs)
         // ---- what comes next: the same item's next image, or the next item's first (its index was stored before at
@@ -215,7 +235,8 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
             const int col = 64 * chalf + 16 * j + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r)                                  // accumulator register r holds row 4 (lane / 16) + r
-                Cs[16 * mtile + 4 * q + r + 2][col] = __builtin_amdgcn_fmed3f(acc[j][r] + cin[j][r], 0.f, cap[j]);
+                Cs[16 * mtile + 4 * q + r + 2][col] = __builtin_amdgcn_fmed3f(NP == 3 ? acc[j][r] + cin[j][r] : __builtin_fmaf(acc[j][r], oscale, cin[j][r]),
+                                                                              0.f, cap[j]);
         }
         lds_barrier();
         // ---- LRN across channels (deploy.prototxt:34-44): out = v (1 + alpha / 5 sum of the 5 squares)^-0.75; this thread:

@@ -134,7 +134,6 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                                                                      unsigned short* __restrict__ out_planes,
                                                                      int* __restrict__ tile_counter, int total_tiles) {
     constexpr int MB = 4;                                    // 32-row blocks per tile
-    constexpr int H = NB / 2;                                // rows per half (the halves' B operands are fetched half a step apart)
     constexpr int PR = NB + KH - 1, PC = CP_TC + KH - 1;     // patch rows / columns
     constexpr int KPP = (PC + 7) / 8;                        // DMA instructions per plane: 8 rows x 8 columns each
     constexpr int GST = 1024 + 128;                          // bytes between column groups: 8 rows x 128 bytes, + 128 so that the two or three
@@ -144,10 +143,17 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
     constexpr int PBUF = NPL * PLANE;                        // bytes per patch buffer
     constexpr int NPW = (NPL * KPP + 3) / 4;                 // patch DMA instructions per wave and channel group
     constexpr int NPR = NP == 3 ? 6 : 3;                     // products per K16 step and 32 x 32 block
+    // weight register sets = how many steps ahead the weights are requested.  fp16 pairs (8 registers a set): one per step of a
+    // kernel row (5) / three for the nine taps -- the set is a function of the step's place in the block, every block is the same
+    // code, and a request has 5 (3) steps to come back from L2 (with two sets the pairs' steps, half as long as the triples',
+    // waited for their weights 29 % of the time: SQ_WAIT_ANY).  bf16 triples (12 registers a set): two sets alternating per step,
+    // two blocks make a period when FP is odd.
+    constexpr int NSETS = NP == 3 ? 2 : (KH == 5 ? 5 : 3);
+    constexpr int D = NSETS;                                 // steps between a weight request and its use
     constexpr int KHB = KH == 5 ? 5 : 1;                     // blocks per channel group
     constexpr int FP = KH == 5 ? 5 : 9;                      // K16 steps per block = per block sum (a kernel row of conv2, all taps of a 3 x 3 layer)
     constexpr int NPWB = (NPW + KHB - 1) / KHB;              // patch DMA instructions per wave and block
-    static_assert(PR <= 8 && NB % 2 == 0 && KH * KH == KHB * FP && (NP == 2 || NP == 3), "8 row slots per DMA instruction; two halves");
+    static_assert(PR <= 8 && NB == 4 && KH * KH == KHB * FP && (NP == 2 || NP == 3), "8 row slots per DMA instruction; two halves");
     __shared__ __attribute__((aligned(16))) unsigned char cp_lds[2 * PBUF];
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -195,24 +201,30 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
                                     ((size_t)g * d.ksteps * d.mblocks + (size_t)mt * MB + wmq) * NP * 1024;    // (wave-uniform)
         const unsigned wstep = (unsigned)d.mblocks * NP * 1024;
-        bf16x8 af[2][NP], bfr[NB][NP];
+        bf16x8 af[NSETS][NP], bfr[NB][NP];
 #pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) af[q / NP][q % NP] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+        for (int q = 0; q < NSETS * NP; ++q) af[q / NP][q % NP] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
         auto load_a = [&](const unsigned char* src, auto o_tag) __attribute__((always_inline)) {
             constexpr int o = decltype(o_tag)::value;
             cp_gload16<0>(af[o][0], src, voff_a);
             cp_gload16<1024>(af[o][1], src, voff_a);
             if constexpr (NP == 3) cp_gload16<2048>(af[o][2], src, voff_a);
         };
-        // B operands of one half's rows for tap k of a block whose scalar LDS offset is sb (buffer, kernel row): bfr[rows of the half]
-        auto fetch_b = [&](auto half_tag, auto k_tag, unsigned sb) __attribute__((always_inline)) {
-            constexpr int h = decltype(half_tag)::value, k = decltype(k_tag)::value;
-            constexpr int dkh = KH == 5 ? 0 : k / KH, kw = KH == 5 ? k : k % KH;
-            const unsigned va = vb[kw] + sb;
+        // B operands of tile row j for tap k of a block whose scalar LDS offset is sb (buffer, kernel row)
+        auto fetch_b = [&](auto row_tag, auto k_tag, unsigned va) __attribute__((always_inline)) {   // va = tap_address(k, sb)
+            constexpr int j = decltype(row_tag)::value, k = decltype(k_tag)::value;
+            constexpr int dkh = KH == 5 ? 0 : k / KH;
 #pragma unroll
-            for (int j = h * H; j < (h + 1) * H; ++j)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) bfr[j][p] = *(lds_cbf8*)(va + (unsigned)((j + dkh) * 128 + p * 2 * PLANE));
+            for (int p = 0; p < NP; ++p) bfr[j][p] = *(lds_cbf8*)(va + (unsigned)((j + dkh) * 128 + p * 2 * PLANE));
+        };
+        auto tap_address = [&](auto k_tag, unsigned sb) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            return vb[KH == 5 ? k : k % KH] + sb;
+        };
+        auto fetch_all = [&](auto k_tag, unsigned sb) __attribute__((always_inline)) {
+            const unsigned va = tap_address(k_tag, sb);
+            fetch_b(std::integral_constant<int, 0>(), k_tag, va); fetch_b(std::integral_constant<int, 1>(), k_tag, va);
+            fetch_b(std::integral_constant<int, 2>(), k_tag, va); fetch_b(std::integral_constant<int, 3>(), k_tag, va);
         };
         // The accumulators are register PAIRS that only inline asm adds to (cp_fold): left to the compiler, the sum of accumulator and
         // block sum lands in the block sum's registers, the accumulators wander between two homes over the unrolled blocks and
@@ -233,109 +245,122 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         asm volatile("s_nop 4" ::: "memory");                // (the weight pointer may come from v_readfirstlane: VALU-writes-SGPR -> VMEM)
         load_a(wgrp, std::integral_constant<int, 0>());
         load_a(wgrp + wstep, std::integral_constant<int, 1>());
-        const unsigned char* anext = wgrp + (size_t)2 * wstep;   // the next weights to request (step s + 2 behind step s; none behind the last two)
+        if constexpr (NSETS > 2) load_a(wgrp + 2 * wstep, std::integral_constant<int, 2>());
+        if constexpr (NSETS > 3) { load_a(wgrp + 3 * wstep, std::integral_constant<int, 3>()); load_a(wgrp + 4 * wstep, std::integral_constant<int, 4>()); }
+        const unsigned char* anext = wgrp + (size_t)D * wstep;   // the next weights to request (step s + D behind step s; none behind the last D)
         cp_wait<0>();
         if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // patch 0 is complete for every wave
-        fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), 0u);
-        fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), 0u);
-        // The matrix instructions of one half (H rows x six products, the five small ones first) into the block sums.  FIRST: the step
-        // opens a block -- the first product starts from zero (C = 0: no register clearing).
-        auto products = [&](auto o_tag, auto half_tag, auto first_tag) __attribute__((always_inline)) {
-            constexpr int o = decltype(o_tag)::value, h = decltype(half_tag)::value;
+        fetch_all(std::integral_constant<int, 0>(), 0u);
+        // The matrix instructions of one tile row (the products of a K16 step, the small ones first) into its block sum.  FIRST: the step
+        // opens a block -- the first product starts from zero (C = 0: no register clearing).  (A row's instructions form a dependent
+        // chain; the matrix pipe forwards the accumulator, scripts/ubench/mfma_bf16_chain.hip.)
+        auto products = [&](auto o_tag, auto row_tag, auto first_tag) __attribute__((always_inline)) {
+            constexpr int o = decltype(o_tag)::value, j = decltype(row_tag)::value;
             constexpr bool first = decltype(first_tag)::value;
             constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < NPR; ++p)
+            for (int p = 0; p < NPR; ++p) {
+                if constexpr (NP == 3)
+                    tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][PA[p]], bfr[j][PB[p]], first && p == 0 ? zero : tq[j], 0, 0, 0);
+                else
+                    tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[o][PA[p]]), __builtin_bit_cast(f16x8, bfr[j][PB[p]]),
+                                                                   first && p == 0 ? zero : tq[j], 0, 0, 0);
+            }
+        };
+        // a row's finished block sum joins its accumulators: ONE rounding per FP steps (asm: see the accumulators' comment; the
+        // matrix-instruction result -> VALU read hazard is not counted by the compiler for asm: s_nop; where the fold of row j - 1
+        // follows the products of row j the result is ~100 cycles old anyway)
+        auto fold_row = [&](auto row_tag) __attribute__((always_inline)) {
+            constexpr int j = decltype(row_tag)::value;
+            asm volatile("s_nop 7" ::: "memory");
 #pragma unroll
-                for (int j = h * H; j < (h + 1) * H; ++j) {
-                    if constexpr (NP == 3)
-                        tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o][PA[p]], bfr[j][PB[p]], first && p == 0 ? zero : tq[j], 0, 0, 0);
-                    else
-                        tq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[o][PA[p]]), __builtin_bit_cast(f16x8, bfr[j][PB[p]]),
-                                                                       first && p == 0 ? zero : tq[j], 0, 0, 0);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const f32x2v t2 = {tq[j][2 * e], tq[j][2 * e + 1]};
+                f32x2v& a2 = acc[j][e];                      // (a plain use: an asm operand alone does not make the lambda capture `acc`)
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
+            }
         };
         int kb = 0, cg = 0;                                  // block of the channel group (kernel row of conv2); channel group
-        // One K16 step (tap k of the block).  The waves of a workgroup are NOT in lockstep: weights come per wave from L2 (two steps
-        // ahead, two register sets), the B operands from the shared patch, and the only barrier is at a channel group's first step.
-        // The B operands of the next step's first half are requested between the halves (that half's registers are free once its
-        // matrix instructions have issued: operands are read at issue), the second half's behind the step: each request has half
-        // a step (12 matrix instructions) to land, without a second register set.
+        // One K16 step (tap k of the block), ROW BY ROW: [a row's matrix instructions][the same row's B operands of the NEXT step] --
+        // the row's operand registers are free once its instructions have issued (operands are read at issue), the requests go out
+        // in the shadow of the row's last matrix instruction and have three rows' instructions to land: no second register set, and
+        // almost nothing of a step's bookkeeping is issued while the matrix pipe has nothing of this wave's to do.  The waves of a
+        // workgroup are NOT in lockstep: weights come per wave from L2 (two steps ahead, two register sets), the B operands from
+        // the shared patch, and the only barrier is at a channel group's first step.  In a block's last step a row's fold follows the
+        // NEXT row's matrix instructions (VALU beside the matrix pipe).
         // Vector-memory queue (in order): at the top of a step [weights s][weights s + 1]; behind step 0 of a block with patch work
         // [weights s + 2][NPWB patch instructions] join it -- steps 1 and 2 leave those in flight, step 3 waits for them.
         // TAIL: the tile's last block -- nothing is requested behind its last two steps (a load in flight into registers the
         // compiler considers dead would land in whatever the epilogue keeps there), and the last step's weights are the queue's last.
-        auto step = [&](auto o_tag, auto k_tag, bool gs, bool dma_block, bool more_blocks, bool tail, unsigned sb) __attribute__((always_inline)) {
+        auto step = [&](auto o_tag, auto k_tag, bool gs, bool dma_block, bool dma_prev, bool more_blocks, bool tail, unsigned sb) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value;
-            if (k == 1 || k == 2) { if (dma_block) cp_wait<NP + NPWB>(); else cp_wait<NP>(); }
-            else if (k == FP - 1) { if (tail) cp_wait<0>(); else cp_wait<NP>(); }
-            else cp_wait<NP>();
+            constexpr bool last = k + 1 == FP;
+            // this step's weights have landed; younger in the queue: the next D - 1 steps' (fewer at the tile's end), and the patch
+            // instructions issued behind step 0 of this block (of the previous one at step 0 when D = FP) for D steps
+            constexpr int AHEAD = NP * (D - 1), AHEAD_TAIL = NP * (FP - 1 - k < D - 1 ? FP - 1 - k : D - 1);
+            const bool dma_out = (k >= 1 && k <= D) ? dma_block : (k == 0 && D == FP ? dma_prev : false);
+            if (tail) cp_wait<AHEAD_TAIL>();
+            else if (dma_out) cp_wait<AHEAD + NPWB>();
+            else cp_wait<AHEAD>();
             if (k == 0 && gs) {
-                // own pieces of this group's patch (issued a whole group ago: older than any weights) have landed; behind the
-                // barrier every wave's have -- and every wave has finished reading the other buffer
+                // own pieces of this group's patch (issued at least a block ago) have landed; behind the barrier every wave's have --
+                // and every wave has finished reading the other buffer
                 __builtin_amdgcn_s_barrier();
-                fetch_b(std::integral_constant<int, 0>(), k_tag, sb);
-                fetch_b(std::integral_constant<int, 1>(), k_tag, sb);
+                fetch_all(k_tag, sb);
             }
+            const unsigned va_next = k + 1 < FP ? tap_address(std::integral_constant<int, (k + 1 < FP ? k + 1 : 0)>(), sb)
+                                                : tap_address(std::integral_constant<int, 0>(), sb + 128u);
+#define CP_ROW(J)                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            products(o_tag, std::integral_constant<int, J>(), std::integral_constant<bool, k == 0>());                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            if constexpr (k + 1 < FP) fetch_b(std::integral_constant<int, J>(), std::integral_constant<int, k + 1>(), va_next); \
+            else if (more_blocks) fetch_b(std::integral_constant<int, J>(), std::integral_constant<int, 0>(), va_next);    \
+            if constexpr (last && J > 0) fold_row(std::integral_constant<int, (J > 0 ? J - 1 : 0)>());                     \
             __builtin_amdgcn_sched_barrier(0);
-            products(o_tag, std::integral_constant<int, 0>(), std::integral_constant<bool, k == 0>());
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (k + 1 < FP) fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, k + 1>(), sb);
-            else if (more_blocks) fetch_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), sb + 128u);
-            __builtin_amdgcn_sched_barrier(0);
-            products(o_tag, std::integral_constant<int, 1>(), std::integral_constant<bool, k == 0>());
-            __builtin_amdgcn_sched_barrier(0);
-            if (k < FP - 2 || !tail) { load_a(anext, o_tag); anext += wstep; }   // into the set just used
+            CP_ROW(0) CP_ROW(1) CP_ROW(2) CP_ROW(3)
+#undef CP_ROW
+            if (k < FP - D || !tail) { load_a(anext, o_tag); anext += wstep; }   // into the set just used
             if (k == 0 && dma_block) {
 #pragma unroll
                 for (int i = 0; i < NPWB; ++i) issue_dma(cg + 1, kb * NPWB + i < NPW ? kb * NPWB + i : NPW - 1);
             }
-            if constexpr (k + 1 < FP) fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, k + 1>(), sb);
-            else if (more_blocks) fetch_b(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), sb + 128u);
-            if constexpr (k + 1 == FP) {                     // the block sums join the accumulators: ONE rounding per FP steps
-                // (matrix-instruction result -> VALU read needs up to 18 wait states that the compiler does not count for asm)
-                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const f32x2v t2 = {tq[j][2 * e], tq[j][2 * e + 1]};
-                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[j][e]) : "v"(t2));
-                    }
-            }
+            if constexpr (last) { asm volatile("s_nop 15" ::: "memory"); fold_row(std::integral_constant<int, NB - 1>()); }
             __builtin_amdgcn_sched_barrier(0);
         };
-        // FP steps make a block, written out: the weight register set alternates per step, so two blocks make a period when FP is odd.
+        // FP steps make a block, written out.  fp16 pairs: every block is the same code (set = step % NSETS, NSETS divides FP);
+        // bf16 triples: the set alternates per step, so two blocks make a period when FP is odd.
+        bool dma_prev = false;
         auto block = [&](auto a_tag) __attribute__((always_inline)) {
             constexpr int a = decltype(a_tag)::value;
-            constexpr std::integral_constant<int, a> sa{};
-            constexpr std::integral_constant<int, a ^ 1> sb_{};
             const bool gs = kb == 0 && cg > 0;
             const bool dma_block = cg + 1 < d.Cg16 && kb * NPWB < NPW;
             const bool more = kb + 1 < KHB;                  // (the next block continues this channel group: its first operands can be requested)
             const unsigned sb = (unsigned)((cg & 1) * PBUF + kb * 128);
             const bool tail = !more && cg + 1 == d.Cg16;
             static_assert(FP == 5 || FP == 9, "the steps of a block are written out for 5 and 9");
-#define CP_K(n) std::integral_constant<int, n>()
-            step(sa, CP_K(0), gs, dma_block, more, tail, sb); step(sb_, CP_K(1), gs, dma_block, more, tail, sb); step(sa, CP_K(2), gs, dma_block, more, tail, sb);
-            step(sb_, CP_K(3), gs, dma_block, more, tail, sb); step(sa, CP_K(4), gs, dma_block, more, tail, sb);
-            if constexpr (FP == 9) {
-                step(sb_, CP_K(5), gs, dma_block, more, tail, sb); step(sa, CP_K(6), gs, dma_block, more, tail, sb);
-                step(sb_, CP_K(7), gs, dma_block, more, tail, sb); step(sa, CP_K(8), gs, dma_block, more, tail, sb);
-            }
-#undef CP_K
+            static_assert(NP == 3 || FP % NSETS == 0, "a block must be a whole number of set rotations");
+#define CP_STEP(n) step(std::integral_constant<int, (NP == 3 ? (a + n) & 1 : n % NSETS)>(), std::integral_constant<int, n>(), gs, dma_block, dma_prev, more, tail, sb);
+            CP_STEP(0) CP_STEP(1) CP_STEP(2) CP_STEP(3) CP_STEP(4)
+            if constexpr (FP == 9) { CP_STEP(5) CP_STEP(6) CP_STEP(7) CP_STEP(8) }
+#undef CP_STEP
+            dma_prev = dma_block;
             if (++kb == KHB) { kb = 0; ++cg; }
         };
         const int nblocks = S / FP;
-        int bi = 0;
-        for (; bi + 2 <= nblocks; bi += 2) {
-            block(std::integral_constant<int, 0>());
-            block(std::integral_constant<int, FP & 1>());
+        if constexpr (NP == 3) {
+            int bi = 0;
+            for (; bi + 2 <= nblocks; bi += 2) {
+                block(std::integral_constant<int, 0>());
+                block(std::integral_constant<int, FP & 1>());
+            }
+            if (bi < nblocks) block(std::integral_constant<int, 0>());
+        } else {
+            for (int bi = 0; bi < nblocks; ++bi) block(std::integral_constant<int, 0>());
         }
-        if (bi < nblocks) block(std::integral_constant<int, 0>());
         // ---- epilogue: bias + ReLU -> f32 NCHW planes; accumulator register 4 q + e = row 8 q + 4 (lane / 32) + e of the block.
         //      The tile's coordinates are derived AGAIN from the (laundered) tile index and lane offset: kept from the top of the
         //      tile they would be a dozen registers live through the loop, which has none to spare ----

@@ -971,6 +971,8 @@ struct Layer {
     SplitDims sd;
     float* wino = nullptr;      // conv2..5: G g G^T in the chunk order of the Winograd kernels (cnn_winograd.hpp)
     unsigned short* c1frag = nullptr;   // conv1: three bf16 pieces of every weight in MFMA fragment order (cnn_conv1_pieces.hpp)
+    unsigned short* c1half = nullptr;   // conv1: scaled fp16 pairs in the same order (c1scale: the power of two)
+    float c1scale = 1.f;
     float* c1map = nullptr;     // conv1: bias - conv1(mean), 123 x 123 x 96
     WinoDims wd;
     Wino5Dims wd5;
@@ -1018,6 +1020,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.whalf) (void)hipFree(l.whalf);
         if (l.wino) (void)hipFree(l.wino);
         if (l.c1frag) (void)hipFree(l.c1frag);
+        if (l.c1half) (void)hipFree(l.c1half);
         if (l.c1map) (void)hipFree(l.c1map);
         if (l.wraw) (void)hipFree(l.wraw);
     }
@@ -1174,11 +1177,15 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     } else {
         // conv1 + relu1 + norm1 + pool1 in one kernel: 21 x 8 patches of 7 x 17 conv outputs per image, straight into
         // pool1's planes (with conv2's border of 2); the conv1 blob only exists when a caller taps it
-        if (S->fuse_conv1 == 3) {                         // exact bf16 pieces on the bf16 matrix cores (cnn_conv1_pieces.hpp)
+        if (S->fuse_conv1 >= 3) {                         // exact bf16 pieces (3) / scaled fp16 pairs (4) on the matrix cores (cnn_conv1_pieces.hpp)
             const int group = S->conv1_group;
             const int total = C1B_PATCHES * ((batch + group - 1) / group);
-            hipLaunchKernelGGL(conv1_pieces_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
-                               S->L[0].c1frag, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, ctr + 0, total);
+            if (S->fuse_conv1 == 4)
+                hipLaunchKernelGGL(conv1_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
+                                   S->L[0].c1half, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f / S->L[0].c1scale, ctr + 0, total);
+            else
+                hipLaunchKernelGGL(conv1_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
+                                   S->L[0].c1frag, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f, ctr + 0, total);
         } else if (S->fuse_conv1 == 2) {                  // the implicit-GEMM kernel with the fused epilogue (kept for comparison)
             ConvDims df = dims(0);
             df.N = batch * C1_TR * C1_TC * 128;           // one 128-column tile per patch
@@ -1391,7 +1398,7 @@ int vpk_cnn_set_profiling(vpk_handle* h, int on) {
 
 int vpk_cnn_set_fusion(vpk_handle* h, int on) {
     if (!h || !h->cnn) return vpk_fail(h, VPK_ERR_STATE, "vpk_cnn_set_fusion before vpk_cnn_load");
-    h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 3 ? 3 : on);
+    h->cnn->fuse_conv1 = on < 0 ? 0 : (on > 4 ? 4 : on);
     return VPK_OK;
 }
 
@@ -1583,6 +1590,16 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             conv1_pieces_weights(blobs[0], fr);
             VPK_HIP(h, hipMalloc((void**)&l.c1frag, fr.size() * sizeof(unsigned short)));
             VPK_HIP(h, hipMemcpy(l.c1frag, fr.data(), fr.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            {
+                float wmax = 0.f;
+                for (int i = 0; i < 96 * 121; ++i) wmax = std::max(wmax, std::fabs(blobs[0][i]));
+                int ex = 0;
+                if (wmax > 0.f) (void)std::frexp(wmax, &ex);
+                l.c1scale = std::ldexp(1.f, wmax > 0.f ? 14 - ex : 0);
+                conv1_pieces_weights(blobs[0], fr, 2, l.c1scale);
+                VPK_HIP(h, hipMalloc((void**)&l.c1half, fr.size() * sizeof(unsigned short)));
+                VPK_HIP(h, hipMemcpy(l.c1half, fr.data(), fr.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            }
             std::vector<float> cm;
             conv1_pieces_cmap(blobs[0], blobs[1], mean, cm);
             VPK_HIP(h, hipMalloc((void**)&l.c1map, cm.size() * sizeof(float)));
