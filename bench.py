@@ -487,7 +487,7 @@ def cnn_algorithm_text(args):
     elif args.cnn_algorithm == 4:
         rest = ("conv2-5: direct on scaled fp16 PAIRS of the f32 operands (h0 = fp16(s x), h1 = fp16(s x - h0): 22 of 24 significand bits; 3 "
                 "exact fp16 products per f32 product; s a power of two per layer; block sums rounded once per kernel row x 16 channels)")
-        fc = "fc6: the same pairs, weights split in registers from the f32 stream; fc7-8: v_mfma_f32"
+        fc = "fc6, fc7: the same pairs, weights split in registers from the f32 stream; fc8: v_mfma_f32"
     elif args.cnn_algorithm >= 2:
         rest = ("conv2: direct on exact bf16 pieces (3 + 3 pieces, 6 bf16 products per f32 product, block sums rounded once per kernel row x 16 "
                 "channels); conv3-5: Winograd F(2x2,3x3) on v_mfma_f32")
@@ -506,7 +506,7 @@ def dtype_text(args):
     if args.cnn_precision == 1:
         bf.append("conv2-5")
     elif args.cnn_algorithm == 4:
-        hf.append("conv2-5 and fc6")
+        hf.append("conv2-5, fc6 and fc7")
     elif args.cnn_algorithm >= 2:
         bf.append("conv2 and fc6")
     if not bf and not hf:

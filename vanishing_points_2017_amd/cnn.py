@@ -105,8 +105,8 @@ class Net(object):
                 return alg * (36.0 / 100.0 if layer == "conv2" else 16.0 / 36.0), "f32"
             return alg, "f32"
         pad = (-(-batch // 128) * 128) / float(batch)     # dense layers: 128-column tiles
-        if layer == "fc6" and algorithm >= 2 and precision == 0:      # cnn_dense_pieces.hpp: six bf16 / three fp16 products per f32 product
-            return alg * pad * (3.0 if algorithm == 4 else 6.0), "f16" if algorithm == 4 else "bf16"
+        if precision == 0 and ((layer == "fc6" and algorithm >= 2) or (layer == "fc7" and algorithm == 4)):
+            return alg * pad * (3.0 if algorithm == 4 else 6.0), "f16" if algorithm == 4 else "bf16"      # cnn_dense_pieces.hpp
         return alg * pad, "f32"
 
     def set_fusion(self, on=3):

@@ -965,7 +965,7 @@ struct Layer {
     float* bias = nullptr;
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
-    float hscale = 1.f;                 // fc6: the power of two its weights are multiplied by before the fp16 split (largest in [2^13, 2^14))
+    float hscale = 1.f;                 // fc6, fc7: the power of two its weights are multiplied by before the fp16 split (largest in [2^13, 2^14))
     unsigned short* whalf = nullptr;    // conv2..5: weights as scaled fp16 pairs in the same order (cnn_conv_pieces.hpp, NP = 2)
     PieceDims pdh;                      //            and the layer's dimensions for that path (own block padding, output scale)
     SplitDims sd;
@@ -977,7 +977,7 @@ struct Layer {
     WinoDims wd;
     Wino5Dims wd5;
     PieceDims pd;               // conv2..5 on exact bf16 pieces from an LDS-resident patch (cnn_conv_pieces.hpp)
-    float* wraw = nullptr;      // fc6: the f32 weights in tile order (dense_tile_weights_kernel), streamed by dense_pieces_kernel (cnn_dense_pieces.hpp)
+    float* wraw = nullptr;      // fc6, fc7: the f32 weights in tile order (dense_tile_weights_kernel), streamed by dense_pieces_kernel (cnn_dense_pieces.hpp)
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -1334,26 +1334,28 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     float* fc_out = R[R_FCA];
     for (int li = 5; li < 8; ++li) {
         ConvDims d = dims(li);
-        if (li == 5 && pieces) {
-            // fc6 on pieces: the input split into B fragments, the weights streamed as they are and split in registers
-            // (cnn_dense_pieces.hpp): exact bf16 triples, or scaled fp16 pairs under vpk_cnn_set_algorithm(4)
+        if ((li == 5 && pieces) || (halves && li == 6)) {
+            // fc6 (fp16 pairs: fc7 too; fc8's 400 outputs are two row tiles: 0.038 ms against 0.030 on the f32 path) on pieces: the input split into B fragments, the weights streamed as f32 in tile order
+            // and split in registers (cnn_dense_pieces.hpp): exact bf16 triples, or scaled fp16 pairs under vpk_cnn_set_algorithm(4)
             DenseDims dd;
-            dd.N = batch; dd.K = d.K; dd.OC = d.OC; dd.chunks = d.K / DP_CHUNK; dd.kparts = 45; dd.cpp = dd.chunks / dd.kparts;
+            dd.N = batch; dd.K = d.K; dd.OC = d.OC; dd.chunks = d.K / DP_CHUNK;
+            dd.kparts = li == 5 ? 45 : 16;                        // work items: 16 x 45 / 16 x 16 row tiles x K parts
+            dd.cpp = dd.chunks / dd.kparts;
             dd.mtiles = (d.OC + DP_BM - 1) / DP_BM; dd.ntiles = (batch + DP_BN - 1) / DP_BN;
-            dd.wscale = halves ? S->L[5].hscale : 1.f;
-            dd.oscale = halves ? 1.f / (S->L[5].hscale * CP_ASCALE) : 1.f;
-            const size_t need = (size_t)dd.ntiles * dd.chunks * DP_STAGE<3>;
-            if ((rc = vpk_reserve(h, (void**)&S->xfrag, &S->xfrag_bytes, need, "hipMalloc(fc6 input fragments)"))) return rc;
+            dd.wscale = halves ? S->L[li].hscale : 1.f;
+            dd.oscale = halves ? 1.f / (S->L[li].hscale * CP_ASCALE) : 1.f;
+            const size_t need = (size_t)dd.ntiles * (TOPO[5].IC / DP_CHUNK) * DP_STAGE<3>;
+            if ((rc = vpk_reserve(h, (void**)&S->xfrag, &S->xfrag_bytes, need, "hipMalloc(dense input fragments)"))) return rc;
             const int total = dd.mtiles * dd.ntiles * dd.kparts;
             if (halves) {
                 hipLaunchKernelGGL(dense_split_kernel<2>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
                                    d.K, dd.chunks);
-                hipLaunchKernelGGL(dense_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
+                hipLaunchKernelGGL(dense_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wraw,
                                    S->xfrag, R[R_PART], ctr + li, total);
             } else {
                 hipLaunchKernelGGL(dense_split_kernel<3>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
                                    d.K, dd.chunks);
-                hipLaunchKernelGGL(dense_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[5].wraw,
+                hipLaunchKernelGGL(dense_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wraw,
                                    S->xfrag, R[R_PART], ctr + li, total);
             }
             d.ksplit = dd.kparts;
@@ -1483,7 +1485,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((p_floats + 255) / 256)), dim3(256), 0, h->stream, raw,
                            l.wp, t.G, t.OC, d.K, d.Kp, d.Mp);
         VPK_HIP(h, hipStreamSynchronize(h->stream));
-        if (li == 5) {                  // fc6: also read in its own layout (cnn_dense_pieces.hpp)
+        if (li == 5 || li == 6) {       // fc6, fc7: also as f32 in tile order for the pieces path (cnn_dense_pieces.hpp)
             const int chunks = d.K / DP_CHUNK, mtiles = (t.OC + DP_BM - 1) / DP_BM;
             const long long total4 = (long long)mtiles * chunks * DP_BM * (DP_CHUNK / 4);
             VPK_HIP(h, hipMalloc((void**)&l.wraw, (size_t)total4 * 16));
