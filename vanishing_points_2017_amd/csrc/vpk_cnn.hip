@@ -956,6 +956,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 #include "cnn_split_gemm.hpp"
 #include "cnn_conv1_pieces.hpp"
 #include "cnn_conv_pieces.hpp"
+#include "cnn_norm_pool_planes.hpp"
 #include "cnn_dense_pieces.hpp"
 #include "cnn_winograd.hpp"
 
@@ -1293,6 +1294,12 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // (13 rows x 61 columns = 793 pixels per channel and workgroup <= 4 x 256 thread slots; 5 row tiles per image)
     // (13 rows x 61 columns = 793 pixels per channel and workgroup <= 4 x 256 thread slots; 5 row tiles x 8 channel ranges
     //  of 32 channels per image; measured at B = 102: 0.177 ms against 0.235 ms for lrn5_pool3s2_tiled_kernel<6, 15>)
+    // fp16 pairs: conv3's input planes straight from the pooling stage (cnn_norm_pool_planes.hpp), unless pool2 is tapped
+    const bool hand2 = S->precision == 0 && S->algorithm == 4 && tap != 3;
+    if (S->precision == 0 && S->algorithm == 4)
+        hipLaunchKernelGGL((lrn5_pool3s2_planes_kernel<6>), dim3((unsigned)(batch * 5 * 8)), dim3(256), 0, st, R[R_CONV2], R[R_POOL2],
+                           hand2 ? reinterpret_cast<unsigned short*>(R[R_P6_3]) : nullptr, 256, 61, 61, 30, 30, 1e-4f, 32, 32, 1, 8);
+    else
     hipLaunchKernelGGL((lrn5_pool3s2_stream_kernel<6, 4>), dim3((unsigned)(batch * 5 * 8)), dim3(256), 0, st, R[R_CONV2], R[R_POOL2],
                        256, 61, 61, 30, 30, 1e-4f, 0.75f, 32, 32, 1, 8);
     mark();
@@ -1307,7 +1314,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // (fp16 pairs: conv3 -> conv4 -> conv5 hand over piece planes -- conv3's epilogue writes conv4's input into p6_5, conv4's writes
     //  conv5's into p6_3, which conv3 has finished reading; a tapped f32 blob is written as such and converted for the next layer)
     const bool hand3 = halves && tap != 4, hand4 = halves && tap != 5;
-    if (pieces && S->algorithm >= 3) { to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3], hand3 ? p6_5 : nullptr); }
+    if (pieces && S->algorithm >= 3) { if (!hand2) to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3], hand3 ? p6_5 : nullptr); }
     else if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
     else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
