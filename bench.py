@@ -30,6 +30,16 @@ EM's results on these rasters (with the generator's response maps, which is what
 reference's stored results, outside the timed region.  "value" feeds the EM the random-weight CNN's own response maps
 (the reference's data flow); "value_fixture_prior" repeats the same K steps -- CNN executed all the same -- with the EM
 fed the response maps the parity object uses, i.e. the workload whose parity the line quotes.
+
+How a step is scheduled (--em-mode slice, the default): the CNN of step k runs on its stream; the EM launch of step k (a second
+stream, waiting for that forward on the device) holds --em-wgs CUs for at most --em-slice-ms, parks the images it has not finished
+and resumes them in the next launch; the last step is followed by a flush that finishes the parked images -- the flush is inside
+the timed region (the job is not done before it), so the run's tail (~12 ms: the slowest image of the last batches) is part of
+`ms_per_step`.  --em-mode lanes is the round-1..4 scheme (three whole-batch EM launches in flight).
+
+CNN arithmetic (--cnn-algorithm 4, the library's default): f32 operands, f32 accumulation and results; conv2..5, fc6 and fc7 multiply
+scaled fp16 PAIRS of the operands (three exact products per f32 product), conv1 exact bf16 pieces -- `dtype` spells it out, and the rule
+behind it (error against the float64 net no larger than the f32 direct kernels' at every tap) is tests/test_gpu_cnn.py.
 """
 import argparse
 import json

@@ -15,6 +15,10 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/yud_fetch -o t -- py
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/yud_write -o t -- python3 bench.py --workload yud --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/yud_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/stress_fetch -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/stress_write -o t -- python3 bench.py --workload stress --steps 2 --warmup 1 --no-cpu-baseline > $R/stress_write.log 2>&1
+# round 5's first default (conv2 / fc6 on exact bf16 triples, conv3..5 Winograd on the f32 cores)
+export VPK_ALGORITHM=2
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/cnn_triples_trace -o t -- python3 scripts/time_cnn.py --passes 14 102 > $R/cnn_triples_trace.log 2>&1
+unset VPK_ALGORITHM
 # CNN alone with the f32 direct kernels everywhere (vpk_cnn_set_fusion(1), vpk_cnn_set_algorithm(0): rounds 1-3's default) and with
 # round 4's defaults (f32 direct conv1, Winograd conv2..5 on the f32 matrix cores)
 export VPK_ALGORITHM=0 VPK_FUSION=1
@@ -38,9 +42,17 @@ python3 scripts/rocpd_stats.py $(find $R/cnn_split_trace -name '*.db' | head -1)
 python3 scripts/rocpd_stats.py $(find $R/cnn_direct_trace -name '*.db' | head -1) $R/summary/${N}_cnn_direct_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_direct_top.txt
 python3 scripts/rocpd_stats.py $(find $R/cnn_wino_trace -name '*.db' | head -1) $R/summary/${N}_cnn_wino_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_wino_top.txt
 python3 scripts/rocpd_stats.py $(find $R/yud_split_trace -name '*.db' | head -1) $R/summary/${N}_yud_split_kernel_stats.csv > $R/summary/${N}_yud_split_top.txt
+python3 scripts/rocpd_stats.py $(find $R/cnn_triples_trace -name '*.db' | head -1) $R/summary/${N}_cnn_triples_kernel_stats.csv --skip-passes 2 --passes 14 > $R/summary/${N}_cnn_triples_top.txt
 python3 scripts/make_traffic_json.py $R $R/summary/${N}_pmc_traffic.json > /dev/null
 python3 scripts/make_mfma_json.py $R $R/summary/${N}_pmc_mfma.json > /dev/null
 grep -h '"metric"' $R/yud_trace.log $R/stress_trace.log | cut -c1-400
 head -8 $R/summary/${N}_yud_top.txt; head -8 $R/summary/${N}_cnn_top.txt; cat $R/summary/${N}_pmc_mfma.json | head -60
+python3 scripts/rocpd_timeline.py $(find $R/yud_trace -name '*.db' | head -1) > $R/summary/${N}_yud_timeline.txt
 find $R -name '*.db' -delete
+# where the conv2 kernel's wave-cycles go (SQ counters, four passes), the fp16-pair kernel and the bf16-triple one
+bash scripts/pmc_kernel.sh conv_pieces_kernelILi5 > $R/summary/${N}_pmc_conv2_issue.txt 2>&1
+VPK_ALGORITHM=2 bash scripts/pmc_kernel.sh conv_pieces_kernelILi5 >> $R/summary/${N}_pmc_conv2_issue.txt 2>&1
+bash scripts/pmc_kernel.sh conv1_pieces > $R/summary/${N}_pmc_conv1_issue.txt 2>&1
+# what the matrix cores sustain with operands that change between instructions
+./scripts/ubench/mfma_f16_pairs > $R/summary/${N}_mfma_sustained.txt 2>&1
 du -sh $R

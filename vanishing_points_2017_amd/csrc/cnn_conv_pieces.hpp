@@ -1,35 +1,40 @@
-// cnn_conv_pieces.hpp -- conv2 of cnn/deploy.prototxt (:56-75: 5 x 5, stride 1, pad 2, two groups of 48 -> 128 channels) as a DIRECT
-// convolution on the bf16 matrix cores with exact operands.  Included by vpk_cnn.hip (after cnn_split_gemm.hpp: bf16x8, split3, dma16).
+// cnn_conv_pieces.hpp -- conv2..conv5 of cnn/deploy.prototxt (:56-174) as DIRECT convolutions on the matrix cores with the f32
+// operands cut into 16-bit pieces whose products are exact.  Included by vpk_cnn.hip (after cnn_split_gemm.hpp: bf16x8, split3, dma16).
 //
-// Arithmetic (as cnn_split_gemm.hpp): every f32 operand is exactly the sum of three bf16 pieces, a product of two pieces is
-// exact in f32, and of the nine partial products the six with i + j <= 4 carry everything above 2^-24 of the product.  What
-// is new here is where the sums are rounded: the products of FP consecutive K16 steps (a kernel row of conv2: 5 taps x 16
-// channels) accumulate in a BLOCK SUM that starts from zero -- per step the five small products first, the large one last --
-// and the block sum joins the running accumulator with one f32 addition.  The accumulator is rounded once per kernel row and
-// 16 channels (15 times per output) instead of six times per step (450 times), and what is rounded inside a block is a
-// twentieth of the final magnitude.  Measured against the float64 net (round 5, scripts/cnn_accuracy.py, error of conv2's blob
-// relative to its largest value): 0.21e-6 -- f32-input direct kernel 1.02e-6, Winograd F(2 x 2, 5 x 5) on the f32 cores 0.59e-6,
-// six chained roundings per step (cnn_split_gemm.hpp as it was) 1.06e-6.
+// Arithmetic.  Two ways to cut an f32 number (template parameter NP):
+//   NP = 3  three bf16 pieces, EXACT (8 + 8 + 8 significand bits); of the nine partial products the six with i + j <= 2 carry
+//           everything above 2^-24 of the product -- six v_mfma_f32_32x32x16_bf16 per K16 step and 32 x 32 block;
+//   NP = 2  two fp16 pieces of the number times a power of two (split2h below): 22 of 24 significand bits, THREE
+//           v_mfma_f32_32x32x16_f16 per step -- the default (vpk_cnn_set_algorithm(4)), because the matrix cores are POWER-limited with
+//           operands that change between instructions (1.7 PFLOP/s sustained, scripts/ubench/mfma_f16_pairs.hip, against the 2.5
+//           dense peak): the six-product kernel ran at 83 % of that ceiling and could only get faster by executing less.
+// Every product of two pieces is exact in f32; what is rounded is the accumulation, and that is organised in BLOCK SUMS: the
+// products of FP consecutive K16 steps (a kernel row of conv2: 5 taps x 16 channels; all nine taps of a 3 x 3 layer) accumulate
+// from zero -- per step the small products first -- and the block sum joins the running accumulator with one f32 addition.
+// Error against the float64 net (scripts/cnn_accuracy.py, B = 3, relative to each blob's largest value): conv2 0.21e-6 (NP = 3) /
+// 0.25e-6 (NP = 2); conv3..5 0.4-0.5e-6 (NP = 2); the f32-input direct kernels 1.0-2.0e-6, Winograd on the f32 cores 0.5-0.7e-6.
 //
 // Data movement:
-//   * activations as "P6" planes: [image][channel group of 16][piece x k half = 6][y][x] -> 16 bytes (8 bf16 = the B operand of
-//     one lane for one pixel), with the convolution's zero border (to_p6_kernel).  A tile = 128 output channels x 4 rows x 32
-//     columns; per channel group its RAW input patch ((4 + KH - 1) x (32 + KW - 1) pixels x 6 planes, 30 KB) comes ONCE by
-//     LDS-DMA, a channel group ahead, and every tap reads it at a shifted address: a lane's operand for tap (kh, kw) is the 16
-//     bytes at (pixel + kh * row + kw) -- consecutive lanes, consecutive words, no bank conflicts, no im2col (the gather of
-//     cnn_split_gemm.hpp fetches every pixel 25 times; its waves spent as long issuing it as multiplying);
-//   * weights: the A-fragment stream of cnn_split_gemm.hpp ([group][K16 step][32-row block][piece][lane][8]; 1.8 MB, L2-resident)
-//     goes per wave straight from L2 into registers, two steps ahead (two register sets): the waves of a workgroup share
-//     nothing but the patch, so the only barrier is at a channel group's first step (every 25 steps);
-//   * four waves per workgroup (one 32-row block of the output channels each, four 32 x 32 accumulator blocks), two workgroups
-//     per CU: one's prologue / epilogue runs under the other's matrix instructions.
-// Where it stands (round 5, B = 102): 1.2 ms against 1.46 ms for the Winograd kernel; the matrix pipes are 60 % busy (0.72 ms of
-// matrix instructions at the 2.05 GHz the kernel holds).  Ablations on the GPU (scripts/cp_experiments.sh: the loop with the
-// weight loads, the LDS operand reads, the patch DMA, the barrier, the block-sum additions and the stores removed one by one):
-// matrix instructions alone 0.83 ms; + operand reads 0.11, + weight loads 0.15, + additions / stores 0.05 -- these do NOT hide
-// under the other wave's matrix instructions, in any of the four schedules tried (operands at the top of a lockstep step: 1.22;
-// a ping-pong of the SIMD's two waves over two barriers per step: 1.48; lockstep with the next step's operands requested before
-// the products: 1.33; independent waves, this version: 1.21).
+//   * activations as piece planes: [image][channel group of 16][piece x k half = 2 NP][y][x] -> 16 bytes (8 values = the B operand of
+//     one lane for one pixel), with the convolution's zero border.  Written by to_planes_kernel, by this kernel's epilogue for the
+//     next convolution (conv3 -> conv4 -> conv5) and by cnn_norm_pool_planes.hpp (pool2 -> conv3).  A tile = 128 output channels
+//     x 4 rows x 32 columns; per channel group its RAW input patch ((4 + KH - 1) rows x 40 columns x 2 NP planes) comes once by
+//     LDS-DMA, a channel group ahead, spread over the group's blocks, and every tap reads it at a shifted address -- no im2col.
+//     LDS layout of a plane: [column group of 8][row (8)][column] 16-byte words, groups 1152 bytes apart: a DMA instruction writes
+//     8 rows x 8 columns with ONE lane-address register for the whole kernel, and the two or three groups a 16-lane quarter of a
+//     ds_read_b128 touches fall on different banks (at 1024 bytes: 2-way conflicts, measured);
+//   * weights: A fragments [group][K16 step][32-row block][piece][lane][8] (L2-resident) go per wave straight from L2 into
+//     registers, D steps ahead -- the waves of a workgroup share nothing but the patch, the only barrier is at a channel group's
+//     first step;
+//   * four waves per workgroup (one 32-row block of the output channels each, four 32 x 32 accumulator blocks), two workgroups per
+//     CU.
+// Instruction issue (round 5, SQ counters in profiles/r05_pmc_conv2_issue.txt): the first version spent ~130 scalar / branch / vector
+// instructions per step on bookkeeping beside 24 matrix instructions and kept the pipe 62 % busy whatever the memory schedule.
+// Now a block of FP steps is straight-line code (tap offsets are immediates, waits constants, branches per block), a step goes
+// row by row with the next step's operands requested behind each row, and the accumulators are touched only by inline asm
+// (so that the register allocator cannot move them): ~25 other instructions per 12 (24) matrix instructions, 0 spills.
+// Where it stands (B = 102, kernels alone): conv2 0.60-0.67 ms (was 1.20 on triples with the first loop, 1.46 Winograd), conv3 / 4 / 5
+// 0.40 / 0.36 / 0.21 ms (Winograd: 0.73 / 0.55 / 0.37): 1.3-1.5 PFLOP/s executed = 80-90 % of the sustained ceiling.
 #ifndef VPK_CNN_CONV_PIECES_HPP_
 #define VPK_CNN_CONV_PIECES_HPP_
 
@@ -49,19 +54,25 @@ struct PieceDims {
     int OHp, OWp, opad;                         // f32 NCHW output planes
     long long in_image;                         // bytes per image of the input tensor (planes of 16-byte words)
     int o_cgtot, o_Hp, o_Wp, o_pad;             // the NEXT layer's piece planes (written instead of the f32 planes when the kernel gets them)
+    float o_ascale;                             //   and its activation scale
     float oscale;                               // 1 / (weight scale x activation scale) of the fp16-pair operands (a power of two); 1 for bf16 pieces
 };
 
 // fp16 PAIRS (round 5): an f32 operand x is h0 + h1 with h0 = fp16(x), h1 = fp16(x - h0): 22 significand bits of its 24 (the
 // remainder is below 2^-23 |x|), and of the four partial products h_i h_j (each EXACT in f32: 11 x 11 bits) the three with
 // i + j <= 1 carry everything above 2^-24 of the product -- HALF the matrix instructions of the bf16 triples, for operands that are
-// a bit short of exact.  fp16's exponent range is what needs care: weights are scaled by a power of two per layer so that
-// the largest is in [2^13, 2^14) (every weight down to 2^-17 of the largest keeps a normal second piece), activations by
-// CP_ASCALE = 2^-3 (finite up to 5e5; below 1 the second piece becomes denormal -- the matrix cores multiply fp16 denormals, measured
-// with scripts/ubench/mfma_f16_pairs.hip -- and the absolute error stays below 2^-25 / CP_ASCALE); the epilogue multiplies by the
-// exact reciprocal.  Whether a layer may use this is decided by MEASUREMENT against the float64 net (tests/test_gpu_cnn.py: no
-// further from it than the f32 direct kernels, at every tap).
-constexpr float CP_ASCALE = 0.125f;
+// a bit short of exact.  fp16's exponent range is what needs care, and powers of two take care of it (exactly):
+//   * weights: x 2^k per layer, the largest in [2^13, 2^14): every weight down to 2^-17 of the largest keeps a normal second piece;
+//   * activations: x a power of two per CONSUMING layer, fixed at load by a calibration forward (vpk_cnn.hip: calibrate): the layer's
+//     input blob for a synthetic raster, computed by the f32 direct kernels, is brought to a maximum in [64, 128).  An activation
+//     keeps both pieces normal (full precision) from 2^-10 to 2^+9 of that calibration maximum; below, the second piece becomes
+//     denormal -- the matrix cores multiply fp16 denormals, measured with scripts/ubench/mfma_f16_pairs.hip -- and the ABSOLUTE
+//     error stays below 2^-25 / scale; 2^9 above it fp16 overflows (a net whose activations for real rasters are 500 x those of the
+//     calibration raster; CP_DEFAULT_ASCALE is the uncalibrated fallback);
+//   * the epilogue multiplies by the exact reciprocal of both.
+// Whether a layer may use this is decided by MEASUREMENT against the float64 net (tests/test_gpu_cnn.py: no further from it than the
+// f32 direct kernels, at every tap, also for nets whose blobs are 128 x larger / smaller than the synthetic net's).
+constexpr float CP_DEFAULT_ASCALE = 0.125f;
 
 __device__ __forceinline__ void split2h(float x, unsigned short& h0, unsigned short& h1) {
     const _Float16 a = (_Float16)x;
@@ -71,11 +82,11 @@ __device__ __forceinline__ void split2h(float x, unsigned short& h0, unsigned sh
 }
 
 // f32 NCHW planes (with their zero border) -> piece planes: [image][channel group of 16][piece x k half (2 NP)][y][x] 16-byte words
-// (8 values = the B operand of one lane for one pixel).  NP = 3: bf16 triples; NP = 2: fp16 pairs of CP_ASCALE x.  One workgroup
+// (8 values = the B operand of one lane for one pixel).  NP = 3: bf16 triples; NP = 2: fp16 pairs of ascale x.  One workgroup
 // per (image, channel group, row): 16 channels x Wp values in, 2 NP x Wp words out.
 template <int NP>
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int Hp,
-                                                        int Wp) {
+                                                        int Wp, float ascale) {
     const int y = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
     const float* src = in + (((size_t)b * C + cg * 16) * Hp + y) * Wp;
     u32x4* dst = reinterpret_cast<u32x4*>(out) + (((size_t)b * (C >> 4) + cg) * (2 * NP) * Hp + y) * Wp;
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
         for (int e = 0; e < 8; ++e) {
             const float v = src[(size_t)(8 * h + e) * Hp * Wp + x];
             if (NP == 3) split3(v, p[0][e], p[1][e], p[2][e]);
-            else split2h(v * CP_ASCALE, p[0][e], p[1][e]);
+            else split2h(v * ascale, p[0][e], p[1][e]);
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                 bl[q] = *reinterpret_cast<const f32x4v*>(bias + e_g * d.OC + m0 + 4 * e_kh);
             }
             if (NP == 2 && out_planes) {
-                // the NEXT layer's input: fp16 pairs of CP_ASCALE x (ReLU(result)) in its piece planes (interior only: the border is the
+                // the NEXT layer's input: fp16 pairs of o_ascale x (ReLU(result)) in its piece planes (interior only: the border is the
                 // arena's zeros).  A lane holds 4 consecutive channels of an 8-channel word, lane + 32 the other 4: 8-byte stores that
                 // the two halves of the wave complete to whole words.
                 unsigned char* pbase = reinterpret_cast<unsigned char*>(out_planes) + (size_t)e_b * d.o_cgtot * 4 * d.o_Hp * d.o_Wp * 16;
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                         for (int e = 0; e < 4; ++e) {
                             float v = acc[j][2 * q + e / 2][e % 2] * d.oscale + bl[q][e];
                             if (d.relu) v = v > 0.f ? v : 0.f;
-                            split2h(v * CP_ASCALE, h0[e], h1[e]);
+                            split2h(v * d.o_ascale, h0[e], h1[e]);
                         }
                         const unsigned w0 = ((unsigned)(c0 >> 4) * 4u + (unsigned)((c0 >> 3) & 1)) * wplane + vo_p + (unsigned)(j * d.o_Wp) * 16u;
                         *reinterpret_cast<u32x2*>(pbase + w0) = u32x2{(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};

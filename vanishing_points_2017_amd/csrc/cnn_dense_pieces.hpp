@@ -36,10 +36,10 @@ struct DenseDims {
 };
 
 // X f32 [N][K] -> B fragments [column tile][chunk][piece][step][column block][lane][8] (columns >= N: zeros): NP = 3 bf16 triples,
-// NP = 2 fp16 pairs of CP_ASCALE x (cnn_conv_pieces.hpp)
+// NP = 2 fp16 pairs of ascale x (cnn_conv_pieces.hpp)
 template <int NP>
 __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int N, int K,
-                                                          int chunks) {
+                                                          int chunks, float ascale) {
     const int c = blockIdx.x, nt = blockIdx.y;
     const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = nt * DP_BN + 32 * j + (lane & 31), h = lane >> 5;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         if (NP == 3) split3(v[e], p[0][e], p[1][e], p[2][e]);
-        else split2h(v[e] * CP_ASCALE, p[0][e], p[1][e]);
+        else split2h(v[e] * ascale, p[0][e], p[1][e]);
     }
     u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)nt * chunks + c) * (DP_STAGE<NP> / 2));
 #pragma unroll

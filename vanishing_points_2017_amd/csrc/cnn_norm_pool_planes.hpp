@@ -1,7 +1,7 @@
 // cnn_norm_pool_planes.hpp -- norm2 + pool2 (cnn/deploy.prototxt:82-103: LRN across 5 channels, alpha 1e-4, beta 0.75; MAX pool 3 x 3 /
 // stride 2) as a stream over the channels, writing conv3's input directly in the format conv_pieces_kernel reads: scaled fp16 pairs
 // in piece planes (cnn_conv_pieces.hpp) -- or the f32 planes when a caller taps pool2.  Included by vpk_cnn.hip after
-// cnn_conv_pieces.hpp (split2h, CP_ASCALE).
+// cnn_conv_pieces.hpp (split2h).
 //
 // Same walk as lrn5_pool3s2_stream_kernel (vpk_cnn.hip): a workgroup owns TPH pooled rows x the whole width of one image -- in an
 // unpadded NCHW plane one contiguous run of (2 TPH + 1) W floats per channel -- and a range of channels; a thread keeps the 5-deep
@@ -21,7 +21,7 @@ namespace {
 template <int TPH>
 __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
                                                                   unsigned short* __restrict__ out_planes, int C, int H, int W, int PH,
-                                                                  int PW, float alpha, int PHp, int PWp, int opad, int cgroups) {
+                                                                  int PW, float alpha, int PHp, int PWp, int opad, int cgroups, float ascale) {
     constexpr int CB = 8, TR = 2 * TPH + 1, SLOTS = 4, PMAX = 256 * SLOTS;
     __shared__ __attribute__((aligned(16))) float plane[2][CB][PMAX];
     const int tiles_h = (PH + TPH - 1) / TPH;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* _
             if (out_planes) {                            // conv3's input: word (channel group of 16, piece x k half, y, x)
                 unsigned short h0_[CB], h1_[CB];
 #pragma unroll
-                for (int k = 0; k < CB; ++k) split2h(m[k] * CP_ASCALE, h0_[k], h1_[k]);
+                for (int k = 0; k < CB; ++k) split2h(m[k] * ascale, h0_[k], h1_[k]);
                 u32x4 a, c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -966,7 +966,8 @@ struct Layer {
     float* bias = nullptr;
     unsigned* ktab = nullptr;   // im2col table (conv layers): byte offset of tap k inside the padded input planes
     unsigned short* wsplit = nullptr;   // conv2..5: weights as three bf16 pieces in MFMA fragment order (cnn_split_gemm.hpp)
-    float hscale = 1.f;                 // fc6, fc7: the power of two its weights are multiplied by before the fp16 split (largest in [2^13, 2^14))
+    float ascale = CP_DEFAULT_ASCALE;   // conv2..5, fc6, fc7 on fp16 pairs: the power of two the layer's INPUT is multiplied by (calibrate())
+    float hscale = 1.f;                 // conv2..5, fc6, fc7: the power of two the weights are multiplied by before the fp16 split (largest in [2^13, 2^14))
     unsigned short* whalf = nullptr;    // conv2..5: weights as scaled fp16 pairs in the same order (cnn_conv_pieces.hpp, NP = 2)
     PieceDims pdh;                      //            and the layer's dimensions for that path (own block padding, output scale)
     SplitDims sd;
@@ -1250,15 +1251,17 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     const bool pieces = S->precision == 0 && S->algorithm >= 2;     // conv2 (mode 3, measurements: conv3 and conv5 too) on exact bf16 pieces
     // conv2..5 as direct convolutions on exact bf16 pieces (cnn_conv_pieces.hpp): the layer's input as P6 planes
     const bool halves = S->precision == 0 && S->algorithm == 4;     // conv2..5 on scaled fp16 pairs (three products per step)
-    auto to_p6 = [&](const float* src, unsigned short* dst, int C, int Hp, int Wp) {
-        if (halves) hipLaunchKernelGGL(to_planes_kernel<2>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
-        else hipLaunchKernelGGL(to_planes_kernel<3>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp);
+    auto to_p6 = [&](const float* src, unsigned short* dst, int C, int Hp, int Wp, int li) {     // li: the layer that reads the planes
+        if (halves) hipLaunchKernelGGL(to_planes_kernel<2>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp,
+                                       S->L[li].ascale);
+        else hipLaunchKernelGGL(to_planes_kernel<3>, dim3((unsigned)Hp, (unsigned)(C / 16), (unsigned)batch), dim3(256), 0, st, src, dst, C, Hp, Wp, 1.f);
     };
     // (planes_next: the next layer's input planes, written by the epilogue instead of the f32 blob -- fp16 pairs only)
     auto conv_pieces = [&](int li, const unsigned short* src6, float* dst, unsigned short* planes_next = nullptr) {
         PieceDims pd = halves ? S->L[li].pdh : S->L[li].pd;
         pd.B = batch;
-        if (planes_next) { const PieceDims& nx = S->L[li + 1].pdh; pd.o_cgtot = nx.CGtot; pd.o_Hp = nx.Hp; pd.o_Wp = nx.Wp; pd.o_pad = 1; }
+        if (planes_next) { const PieceDims& nx = S->L[li + 1].pdh; pd.o_cgtot = nx.CGtot; pd.o_Hp = nx.Hp; pd.o_Wp = nx.Wp; pd.o_pad = 1; pd.o_ascale = S->L[li + 1].ascale; }
+        if (halves) pd.oscale = 1.f / (S->L[li].hscale * S->L[li].ascale);
         constexpr int nb = 4;                                               // rows of a tile
         pd.rtiles = (pd.OH + nb - 1) / nb;
         const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
@@ -1286,7 +1289,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
-    if (pieces) { to_p6(R[R_POOL1], p6_2, 96, 65, 65); conv_pieces(1, p6_2, R[R_CONV2]); }
+    if (pieces) { to_p6(R[R_POOL1], p6_2, 96, 65, 65, 1); conv_pieces(1, p6_2, R[R_CONV2]); }
     else conv_main(1, R[R_POOL1], R[R_CONV2]);
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
@@ -1298,7 +1301,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     const bool hand2 = S->precision == 0 && S->algorithm == 4 && tap != 3;
     if (S->precision == 0 && S->algorithm == 4)
         hipLaunchKernelGGL((lrn5_pool3s2_planes_kernel<6>), dim3((unsigned)(batch * 5 * 8)), dim3(256), 0, st, R[R_CONV2], R[R_POOL2],
-                           hand2 ? reinterpret_cast<unsigned short*>(R[R_P6_3]) : nullptr, 256, 61, 61, 30, 30, 1e-4f, 32, 32, 1, 8);
+                           hand2 ? reinterpret_cast<unsigned short*>(R[R_P6_3]) : nullptr, 256, 61, 61, 30, 30, 1e-4f, 32, 32, 1, 8,
+                           S->L[2].ascale);
     else
     hipLaunchKernelGGL((lrn5_pool3s2_stream_kernel<6, 4>), dim3((unsigned)(batch * 5 * 8)), dim3(256), 0, st, R[R_CONV2], R[R_POOL2],
                        256, 61, 61, 30, 30, 1e-4f, 0.75f, 32, 32, 1, 8);
@@ -1314,12 +1318,12 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     // (fp16 pairs: conv3 -> conv4 -> conv5 hand over piece planes -- conv3's epilogue writes conv4's input into p6_5, conv4's writes
     //  conv5's into p6_3, which conv3 has finished reading; a tapped f32 blob is written as such and converted for the next layer)
     const bool hand3 = halves && tap != 4, hand4 = halves && tap != 5;
-    if (pieces && S->algorithm >= 3) { if (!hand2) to_p6(R[R_POOL2], p6_3, 256, 32, 32); conv_pieces(2, p6_3, R[R_CONV3], hand3 ? p6_5 : nullptr); }
+    if (pieces && S->algorithm >= 3) { if (!hand2) to_p6(R[R_POOL2], p6_3, 256, 32, 32, 2); conv_pieces(2, p6_3, R[R_CONV3], hand3 ? p6_5 : nullptr); }
     else if (chain) conv_split(2, R[R_POOL2], nullptr, s4, true);
     else conv_main(2, R[R_POOL2], R[R_CONV3]);
     mark();
     tapunpad(4, R[R_CONV3], 384, 30, 30, 1);
-    if (halves) { if (!hand3) to_p6(R[R_CONV3], p6_5, 384, 32, 32); conv_pieces(3, p6_5, R[R_CONV4], hand4 ? p6_3 : nullptr); }
+    if (halves) { if (!hand3) to_p6(R[R_CONV3], p6_5, 384, 32, 32, 3); conv_pieces(3, p6_5, R[R_CONV4], hand4 ? p6_3 : nullptr); }
     else if (chain) conv_split(3, nullptr, s4, s5, true);
     else if (S->precision == 1) conv_split(3, R[R_CONV3], nullptr, R[R_CONV4], false);
     else if (wino) conv_wino(3, R[R_CONV3], R[R_CONV4]);
@@ -1327,7 +1331,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     mark();
     tapunpad(5, R[R_CONV4], 384, 30, 30, 1);
     if (hand4) conv_pieces(4, p6_3, R[R_CONV5]);
-    else if (pieces && S->algorithm >= 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32); conv_pieces(4, p6_5, R[R_CONV5]); }
+    else if (pieces && S->algorithm >= 3) { to_p6(R[R_CONV4], p6_5, 384, 32, 32, 4); conv_pieces(4, p6_5, R[R_CONV5]); }
     else if (chain) conv_split(4, nullptr, s5, R[R_CONV5], false);
     else conv_main(4, R[R_CONV4], R[R_CONV5]);
     mark();
@@ -1350,18 +1354,18 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
             dd.cpp = dd.chunks / dd.kparts;
             dd.mtiles = (d.OC + DP_BM - 1) / DP_BM; dd.ntiles = (batch + DP_BN - 1) / DP_BN;
             dd.wscale = halves ? S->L[li].hscale : 1.f;
-            dd.oscale = halves ? 1.f / (S->L[li].hscale * CP_ASCALE) : 1.f;
+            dd.oscale = halves ? 1.f / (S->L[li].hscale * S->L[li].ascale) : 1.f;
             const size_t need = (size_t)dd.ntiles * (TOPO[5].IC / DP_CHUNK) * DP_STAGE<3>;
             if ((rc = vpk_reserve(h, (void**)&S->xfrag, &S->xfrag_bytes, need, "hipMalloc(dense input fragments)"))) return rc;
             const int total = dd.mtiles * dd.ntiles * dd.kparts;
             if (halves) {
                 hipLaunchKernelGGL(dense_split_kernel<2>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
-                                   d.K, dd.chunks);
+                                   d.K, dd.chunks, S->L[li].ascale);
                 hipLaunchKernelGGL(dense_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wraw,
                                    S->xfrag, R[R_PART], ctr + li, total);
             } else {
                 hipLaunchKernelGGL(dense_split_kernel<3>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
-                                   d.K, dd.chunks);
+                                   d.K, dd.chunks, 1.f);
                 hipLaunchKernelGGL(dense_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wraw,
                                    S->xfrag, R[R_PART], ctr + li, total);
             }
@@ -1385,6 +1389,50 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     }
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
+}
+
+// Activation scales of the fp16-pair layers (cnn_conv_pieces.hpp): ONE forward per consuming layer of a fixed synthetic raster (sparse
+// random pixels 0..59, the value range of the sphere rasters), by the f32 direct kernels -- which do not depend on any scale --, tapped
+// at the layer's input blob; the scale is the power of two that brings that blob's maximum into [64, 128).  Fixed for the lifetime of
+// the loaded model: results never depend on earlier calls.
+int calibrate(vpk_handle* h) {
+    vpk_cnn_state* S = h->cnn;
+    std::vector<uint8_t> img(500 * 500);
+    unsigned x = 12345u;
+    for (auto& p : img) {
+        x = x * 1664525u + 1013904223u;
+        const unsigned r = x >> 8;
+        p = (r % 100u) < 15u ? (uint8_t)((r >> 8) % 60u) : 0;
+    }
+    uint8_t* d_img = nullptr;
+    float *d_out = nullptr, *d_tap = nullptr;
+    VPK_HIP(h, hipMalloc((void**)&d_img, img.size()));
+    VPK_HIP(h, hipMalloc((void**)&d_out, 400 * sizeof(float)));
+    VPK_HIP(h, hipMalloc((void**)&d_tap, A_POOL1 * sizeof(float)));        // (the largest tapped blob)
+    VPK_HIP(h, hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+    const int keep_alg = S->algorithm, keep_fuse = S->fuse_conv1, keep_prec = S->precision;
+    S->algorithm = 0; S->fuse_conv1 = 1; S->precision = 0;
+    const int layer_tap[6][2] = {{1, 1}, {2, 3}, {3, 4}, {4, 5}, {5, 7}, {6, 8}};       // (layer, tap of its input: pool1, pool2, conv3, conv4, pool5, fc6)
+    const size_t tap_size[6] = {A_POOL1, A_POOL2, A_CONV3, A_CONV4, A_POOL5, A_FC6};
+    std::vector<float> host(A_POOL1);
+    int rc = VPK_OK;
+    for (int i = 0; i < 6 && rc == VPK_OK; ++i) {
+        rc = run_forward(h, d_img, 1, d_out, layer_tap[i][1], d_tap);
+        if (rc != VPK_OK) break;
+        if (hipStreamSynchronize(h->stream) != hipSuccess ||
+            hipMemcpy(host.data(), d_tap, tap_size[i] * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = vpk_fail(h, VPK_ERR_HIP, "vpk_cnn_load: calibration forward failed");
+            break;
+        }
+        float m = 0.f;
+        for (size_t k = 0; k < tap_size[i]; ++k) m = std::max(m, std::fabs(host[k]));
+        float sc = CP_DEFAULT_ASCALE;
+        if (m > 0.f && std::isfinite(m)) { int ex; (void)std::frexp(m, &ex); sc = std::ldexp(1.f, 7 - ex); }   // m * sc in [64, 128)
+        S->L[layer_tap[i][0]].ascale = sc;
+    }
+    S->algorithm = keep_alg; S->fuse_conv1 = keep_fuse; S->precision = keep_prec;
+    (void)hipFree(d_img); (void)hipFree(d_out); (void)hipFree(d_tap);
+    return rc;
 }
 
 }  // namespace
@@ -1572,7 +1620,8 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             int kexp = 0;
             if (wmax > 0.f) { int ex; (void)std::frexp(wmax, &ex); kexp = 14 - ex; }     // wmax = f * 2^ex, f in [0.5, 1): wmax * 2^kexp in [2^13, 2^14)
             const float wscale = std::ldexp(1.f, kexp);
-            ph.oscale = 1.f / (wscale * CP_ASCALE);
+            l.hscale = wscale;
+            ph.oscale = 1.f / (wscale * l.ascale);               // (set again per forward: the activation scale is calibrated after the load)
             std::vector<unsigned short> ph_pk((size_t)t.G * ph.ksteps * ph.mblocks * 2 * 512, 0);
             for (int g = 0; g < t.G; ++g)
                 for (int s_ = 0; s_ < ph.ksteps; ++s_)
@@ -1637,7 +1686,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
         VPK_HIP(h, hipMemcpy(l.bias, blobs[2 * li + 1], (size_t)t.G * t.OC * sizeof(float), hipMemcpyHostToDevice));
     }
     S->loaded = true;
-    return VPK_OK;
+    return calibrate(h);
 }
 
 int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int tap, float* tap_out) {
