@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second timed run with --cnn-precision 1 (alt_precision)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timed legs (alt_exact_operands, fixture prior, from the lines)")
     ap.add_argument("--no-from-lines", action="store_true", help="skip the from_lines leg (raster -> CNN -> EM per step)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images timed on the CPU (default 6 yud / 1 stress)")
     return ap.parse_args()
@@ -728,13 +728,14 @@ def run_workload(args, dist, rank, local_rank, world):
         fixture = {"value": count * world * args.steps / fix_elapsed, "ms_per_step": fix_elapsed / args.steps * 1e3,
                    "iterations_mean": float(it_fix.mean()), "iterations_max": int(it_fix.max())}
         active["ring"] = ring
-    # The same K steps once more with conv2..5 on the bf16 matrix cores (vpk_cnn_set_precision(1): three bf16 pieces per f32
-    # operand, six products per f32 product -- f32-class accuracy, tests/test_gpu_cnn.py).  Reported beside the headline
-    # number, never as it: `value` is the native-f32 run above.
+    # The same K steps once more with EXACT-OPERAND arithmetic only (vpk_cnn_set_algorithm(2), round 5's first default: conv1, conv2
+    # and fc6 on exact bf16 triples -- six products per f32 product --, conv3..5 Winograd on the f32 matrix cores, fc7 / fc8 f32).
+    # Reported beside the headline number, never as it: `value` is the default run above (fp16 pairs, see `dtype`); a reader who only
+    # accepts operands that are represented exactly finds that number here.
     alt = None
-    if args.workload == "yud" and args.cnn_precision == 0 and not args.no_alt:
+    if args.workload == "yud" and args.cnn_precision == 0 and args.cnn_algorithm == 4 and not args.no_alt:
         alt_wgs = em_wgs if sliced else (args.em_wgs if args.em_wgs >= 0 else max(8, (count * 47) // 100))
-        net.set_precision(1)
+        net.set_algorithm(2)
         for r in lanes:
             r.handle.em_set_workgroups(alt_wgs)
         for k in range(max(args.warmup, n_lanes)):
@@ -749,15 +750,15 @@ def run_workload(args, dist, rank, local_rank, world):
             tmax = torch.tensor([alt_elapsed], dtype=torch.float64, device=rt.tdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             alt_elapsed = float(tmax.item())
-        alt = {"cnn": "conv2..conv5 as six bf16 matrix products per f32 product (three exact bf16 pieces per operand, f32 "
-                      "accumulation; vpk_cnn_set_precision(1), DESIGN.md section 8)",
+        alt = {"cnn": "vpk_cnn_set_algorithm(2): conv1, conv2, fc6 multiply EXACT bf16 pieces (three per f32 operand, six products per f32 "
+                      "product), conv3..5 Winograd F(2x2,3x3) on v_mfma_f32, fc7 / fc8 v_mfma_f32 -- every operand represented exactly",
                "value": count * world * args.steps / alt_elapsed, "unit": "images/s",
                "ms_per_step": alt_elapsed / args.steps * 1e3, "steps": args.steps,
                "host_submit_ms_per_step": alt_submit / args.steps * 1e3,
                "stage_ms": {"cnn": float(np.mean([e[0].elapsed_time(e[1]) for e in evs_alt])),
                             "em": float(np.mean([e[2].elapsed_time(e[3]) for e in evs_alt])), "em_workgroups": alt_wgs},
                "cnn_layer_ms": {k: round(v, 4) for k, v in net.last_layer_ms().items()}}
-        net.set_precision(0)
+        net.set_algorithm(args.cnn_algorithm)
         for r in lanes:
             r.handle.em_set_workgroups(em_wgs)
     # The same K steps once more STARTING FROM THE LINES: every step first rasterises its batch (vpk_sphere_raster on a stream
@@ -1026,7 +1027,7 @@ def run_workload(args, dist, rank, local_rank, world):
                               "every step whose buffers are alive); lanes mode: one per step on the EM lane's stream (sharding.gather_device)")
             line["gather"] = g_info
         if alt:
-            line["alt_precision"] = alt
+            line["alt_exact_operands"] = alt
         if from_lines is not None:
             line["from_lines"] = from_lines
         if args.workload == "yud":

@@ -138,9 +138,9 @@ def test_bench_modes_produce_a_valid_line(mode):
     assert line["em_stats"]["ok_images"] == 12
     assert line["parity"]["images"] == 12 and line["parity"]["all_criteria"] == 12
     assert line["roofline"]["bound"] in ("mfma", "hbm") and 0 < line["roofline"]["frac"] < 1
-    assert line["dtype"].startswith("f32 (CNN")      # the headline run uses the native f32 matrix path ...
-    if mode == "lanes":                                      # ... and the split-precision path is reported beside it
-        alt = line["alt_precision"]
+    assert line["dtype"].startswith("f32 (CNN") and "fp16 PAIRS" in line["dtype"]      # the line says what multiplies ...
+    if mode == "lanes":                                      # ... and the exact-operand configuration is reported beside it
+        alt = line["alt_exact_operands"]
         assert alt["value"] > 0 and alt["steps"] == 3 and "bf16" in alt["cnn"]
         fl = line["from_lines"]                              # ... and the same steps starting from the line sets:
         assert fl["value"] > 0 and fl["steps"] == 3          # raster (own stream) -> CNN -> EM, pipelined, gives what the
@@ -237,7 +237,7 @@ def test_bench_on_the_rccl_backend_one_rank():
     from vanishing_points_2017_amd import sharding
     assert g["width"] == sharding.REC_WIDTH
     assert line["em_stats"]["ok_images"] == 12 and line["parity"]["all_criteria"] == 12
-    assert line["alt_precision"]["value"] > 0 and line["from_lines"]["results_equal_unpipelined_pass"] is True   # their gathers too
+    assert line["alt_exact_operands"]["value"] > 0 and line["from_lines"]["results_equal_unpipelined_pass"] is True   # their gathers too
 
 
 def test_sharded_benchmark_on_the_rccl_backend_one_rank(tmp_path):
