@@ -240,6 +240,33 @@ def test_default_path_is_no_further_from_the_float64_net_than_the_f32_direct_ker
     print({k: {n: round(e[0] / v[1], 9) for n, e in v[0].items()} for k, v in report.items()})
 
 
+def test_forward_is_bit_reproducible_at_the_bench_batch():
+    """Twelve forwards of bench.py's batch must give the same bits (and every tap twice): the persistent tile queues hand tiles to
+    workgroups in a different order every launch, LDS patches are filled by DMA a channel group ahead and weights arrive by hand-counted
+    waits -- a wait that lets a matrix instruction read a patch one DMA instruction early shows up as a rare wrong tile (round 5: one
+    forward in six, 1e-3 off at conv2), not as a consistent error, and only repetition finds it."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn, sphere_mapping, synth
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=102)])
+    ref = cnn_torch.forward(w, mean, sphere)
+    net = cnn.Net(w, mean)
+    try:
+        for algorithm in (4, 2):
+            net.set_algorithm(algorithm)
+            first = net.forward(sphere)
+            assert np.abs(first - ref).max() <= 2e-5, algorithm
+            for _ in range(11):
+                assert np.array_equal(net.forward(sphere), first), algorithm
+            for tap in (2, 4, 5, 6, 8):                        # conv2, conv3, conv4, conv5, fc6
+                a = net.forward(sphere, tap=tap)[1]
+                for _ in range(2):
+                    assert np.array_equal(net.forward(sphere, tap=tap)[1], a), (algorithm, tap)
+    finally:
+        net.set_algorithm(4)
+
+
 def test_fp16_pairs_over_the_operand_range():
     """The fp16 pairs of vpk_cnn_set_algorithm(4) live in fp16's exponent range: weights are brought there by a power of two per layer,
     activations by a fixed 2^-3 (cnn_conv_pieces.hpp).  Nets whose blobs are 128 x larger / smaller than the synthetic net's -- conv2's

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
             // this step's weights have landed; younger in the queue: the next D - 1 steps' (fewer at the tile's end), and the patch
             // instructions issued behind step 0 of this block (of the previous one at step 0 when D = FP) for D steps
             constexpr int AHEAD = NP * (D - 1), AHEAD_TAIL = NP * (FP - 1 - k < D - 1 ? FP - 1 - k : D - 1);
-            const bool dma_out = (k >= 1 && k <= D) ? dma_block : (k == 0 && D == FP ? dma_prev : false);
+            // (not at a channel group's first step: the patch it is about to read includes the previous block's instructions)
+            const bool dma_out = (k >= 1 && k <= D) ? dma_block : (k == 0 && D == FP ? dma_prev && !gs : false);
             if (tail) cp_wait<AHEAD_TAIL>();
             else if (dma_out) cp_wait<AHEAD + NPWB>();
             else cp_wait<AHEAD>();
