@@ -21,11 +21,15 @@ def main(db, out, skip_passes=0, passes=0):
         per = {}
         for name, start, dur in cur.execute("select s.%s, d.start, d.end - d.start from %s d join %s s on d.kernel_id = s.id "
                                             "order by d.start" % (name_col, disp, sym)):
-            per.setdefault(name, []).append(dur)
+            per.setdefault(name, []).append((start, dur))
+        # the kept part of the trace starts with the first kept dispatch of a kernel of the repeated pass: what ran before it (model
+        # load: weight re-packing, the calibration forwards of vpk_cnn_load, warm-up passes) is dropped for every kernel
+        t_keep = min(v[len(v) // passes * skip_passes][0] for v in per.values() if len(v) % passes == 0 and len(v) >= passes)
         rows = []
-        for name, durs in per.items():
-            if len(durs) % passes == 0:                      # a kernel of the repeated pass: drop the warm-up share
-                durs = durs[len(durs) // passes * skip_passes:]
+        for name, v in per.items():
+            durs = [d for (st, d) in v if st >= t_keep]
+            if not durs:
+                continue
             rows.append((name, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs)))
         rows.sort(key=lambda r: -r[2])
     else:

@@ -175,6 +175,11 @@ def test_split_path_beyond_4_gib_of_activations():
     assert np.abs(out[:6] - native).max() <= 2e-5
     twins = out.reshape(300, 6, 20, 20)
     assert np.array_equal(twins, np.broadcast_to(twins[:1], twins.shape))
+    # the default path (fp16 pairs): conv2's f32 blob is 3.8 MB per image -- image 1128 starts 4 GiB into it --, the piece planes
+    # 1.6 MB; per-image bases are 64-bit, offsets inside an image 32-bit (cnn_conv_pieces.hpp, cnn_norm_pool_planes.hpp)
+    out = net.forward(sphere)
+    twins = out.reshape(300, 6, 20, 20)
+    assert np.array_equal(twins, np.broadcast_to(native[None], twins.shape))
 
 
 def test_misaligned_rasters_are_refused_and_the_fused_input_path_equals_the_pre_pass(net_and_ref):
