@@ -95,8 +95,8 @@ class Net(object):
         if layer in ("conv2", "conv3", "conv4", "conv5"):
             if precision == 1:
                 return 6.0 * alg, "bf16"
-            if algorithm == 4:      # fp16 pairs: tiles of 128 channels x 4 rows x 32 columns, 4 waves x 12 v_mfma_f32_32x32x16_f16 per K16 step
-                tiles, steps = {"conv2": (2 * 16 * 2 * 1, 75), "conv3": (1 * 8 * 1 * 3, 16 * 9), "conv4": (2 * 8 * 1 * 2, 12 * 9),
+            if algorithm == 4:      # fp16 pairs: tiles of 128 channels x 4 rows (conv4: 64 x 8) x 32 columns, 4 waves x 12 v_mfma_f32_32x32x16_f16 per K16 step
+                tiles, steps = {"conv2": (2 * 16 * 2 * 1, 75), "conv3": (1 * 8 * 1 * 3, 16 * 9), "conv4": (2 * 4 * 1 * 3, 12 * 9),
                                 "conv5": (2 * 8 * 1 * 1, 12 * 9)}[layer]       # (groups x row tiles x column tiles x channel tiles, K16 steps)
                 return tiles * steps * 4 * 12 * 2.0 * 32 * 32 * 16, "f16"
             if layer == "conv2" and algorithm >= 2:      # 64 tiles x 4 waves x 75 steps x 24 v_mfma_f32_32x32x16_bf16

@@ -138,21 +138,28 @@ __device__ __forceinline__ void cp_gload16(bf16x8& dst, const void* sbase, unsig
 // together (pipe 62 % busy, whatever the memory schedule).  Here a BLOCK of FP steps (a kernel row of conv2; all nine taps of
 // a 3 x 3 layer) is straight-line code: tap offsets are immediates of the LDS reads, the weight pieces immediates of one
 // scalar pointer, waits are constants, and the only branches are per block.
-template <int KH, int NB, int NP>
+// RH = 1: the four waves own four 32-channel blocks x the tile's 4 rows (128 channels x 4 rows x 32 columns).  RH = 2: two blocks x two
+// row halves (64 channels x 8 rows x 32 columns) -- conv4's: its 192 channels per group are three such tiles (as 128-channel tiles they
+// were two, a quarter of the second one padding: 0.36 -> 0.32 ms); conv3 and conv5 measured 6-9 % SLOWER in this shape and keep RH = 1.
+template <int KH, int NB, int NP, int RH>
 __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d, const unsigned short* __restrict__ act,
                                                                      const unsigned short* __restrict__ wfrag,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      unsigned short* __restrict__ out_planes,
                                                                      int* __restrict__ tile_counter, int total_tiles) {
-    constexpr int MB = 4;                                    // 32-row blocks per tile
-    constexpr int PR = NB + KH - 1, PC = CP_TC + KH - 1;     // patch rows / columns
-    constexpr int KPP = (PC + 7) / 8;                        // DMA instructions per plane: 8 rows x 8 columns each
-    constexpr int GST = 1024 + 128;                          // bytes between column groups: 8 rows x 128 bytes, + 128 so that the two or three
+    constexpr int MB = 4 / RH;                               // 32-row blocks per tile
+    constexpr int TR = RH * NB;                              // rows of a tile
+    constexpr int PR = TR + KH - 1, PC = CP_TC + KH - 1;     // patch rows / columns
+    constexpr int KPP = (PC + 7) / 8;                        // column groups of 8 per plane
+    constexpr int PARTS = PR > 8 ? 2 : 1;                    // DMA instructions per column group: 8 rows x 8 columns each (the second: PR - 8 rows)
+    constexpr int GST = (PR > 8 ? PR * 128 : 1024) + 128;    // bytes between column groups: the rows x 128 bytes, + 128 so that the two or three
                                                              // groups a 16-lane quarter of a ds_read_b128 touches fall on different banks
+    static_assert(GST % 256 == 128, "odd multiple of 128 bytes");
     constexpr int PLANE = KPP * GST;                         // bytes per plane in LDS: [column group of 8][row (8)][column] 16-byte words
     constexpr int NPL = 2 * NP;                              // planes per channel group: piece x k half
     constexpr int PBUF = NPL * PLANE;                        // bytes per patch buffer
-    constexpr int NPW = (NPL * KPP + 3) / 4;                 // patch DMA instructions per wave and channel group
+    constexpr int NDMA = NPL * KPP * PARTS;                  // patch DMA instructions per channel group
+    constexpr int NPW = (NDMA + 3) / 4;                      //   ... and wave
     constexpr int NPR = NP == 3 ? 6 : 3;                     // products per K16 step and 32 x 32 block
     // weight register sets = how many steps ahead the weights are requested.  fp16 pairs (8 registers a set): one per step of a
     // kernel row (5) / three for the nine taps -- the set is a function of the step's place in the block, every block is the same
@@ -164,12 +171,13 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
     constexpr int KHB = KH == 5 ? 5 : 1;                     // blocks per channel group
     constexpr int FP = KH == 5 ? 5 : 9;                      // K16 steps per block = per block sum (a kernel row of conv2, all taps of a 3 x 3 layer)
     constexpr int NPWB = (NPW + KHB - 1) / KHB;              // patch DMA instructions per wave and block
-    static_assert(PR <= 8 && NB == 4 && KH * KH == KHB * FP && (NP == 2 || NP == 3), "8 row slots per DMA instruction; two halves");
+    static_assert(PR <= 16 && NB == 4 && (RH == 1 || RH == 2) && KH * KH == KHB * FP && (NP == 2 || NP == 3), "8 row slots per DMA instruction; two halves");
     __shared__ __attribute__((aligned(16))) unsigned char cp_lds[2 * PBUF];
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wmq = wave;                                    // this wave: block wmq of the tile's output channels, all four rows
+    const int wmq = RH == 1 ? wave : (wave & 1);             // this wave: block wmq of the tile's output channels,
+    const int rh = RH == 1 ? 0 : (wave >> 1);                //            rows rh * NB .. + NB - 1 of the tile
     const int n31 = lane & 31, kh_ = lane >> 5;
     const unsigned lds0 = lds_addr(cp_lds);
     typedef __attribute__((address_space(3))) const bf16x8 lds_cbf8;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
 #pragma unroll
     for (int kw = 0; kw < KH; ++kw) {
         const unsigned c = (unsigned)(n31 + kw);
-        vb[kw] = lds0 + (unsigned)(kh_ * PLANE) + (c >> 3) * (unsigned)GST + (c & 7u) * 16u;
+        vb[kw] = lds0 + (unsigned)(kh_ * PLANE + rh * NB * 128) + (c >> 3) * (unsigned)GST + (c & 7u) * 16u;
     }
     const unsigned voff_a = (unsigned)lane * 16u;
     int parity = 0;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         const int rt = t % d.rtiles; t /= d.rtiles;
         const int b = t % d.B;
         const int g = t / d.B;
-        const int y0 = rt * NB, x0 = ct * CP_TC;
+        const int y0 = rt * TR, x0 = ct * CP_TC;
         // ---- patch loader: a DMA instruction brings 8 rows x 8 columns of one plane (lane = row * 8 + column); the lane part of
         //      its address is the same for all of them (rows past the plane repeat the last one; columns past the row read on into
         //      the next row or plane -- finite data for output pixels that are never stored) ----
@@ -201,12 +209,17 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         const size_t plane_bytes = (size_t)d.Hp * d.Wp * 16;
         const int yr = y0 + (lane >> 3) < d.Hp ? y0 + (lane >> 3) : d.Hp - 1;
         const unsigned voff_p = (unsigned)(yr * d.Wp + x0 + (lane & 7)) * 16u;
+        const int yr2 = y0 + 8 + (lane >> 3) < d.Hp ? y0 + 8 + (lane >> 3) : d.Hp - 1;       // (PARTS = 2: rows 8 .. PR - 1, lanes 0 .. 8 (PR - 8) - 1)
+        const unsigned voff_p2 = (unsigned)(yr2 * d.Wp + x0 + (lane & 7)) * 16u;
         auto issue_dma = [&](int cg, int k) __attribute__((always_inline)) {   // this wave's k-th instruction of channel group cg
             int q = wave * NPW + k;
-            q = q < NPL * KPP ? q : NPL * KPP - 1;           // (surplus instructions repeat the last one)
-            const int pl = q / KPP, kk = q - pl * KPP;       // wave-uniform
-            dma16(voff_p, in_g + ((size_t)cg * NPL + pl) * plane_bytes + (size_t)kk * 128,
-                  __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((cg & 1) * PBUF + pl * PLANE + kk * GST)));
+            q = q < NDMA ? q : NDMA - 1;                     // (surplus instructions repeat the last one)
+            const int part = q / (NPL * KPP), q1 = q - part * (NPL * KPP);
+            const int pl = q1 / KPP, kk = q1 - pl * KPP;     // wave-uniform
+            const unsigned char* src = in_g + ((size_t)cg * NPL + pl) * plane_bytes + (size_t)kk * 128;
+            const unsigned dst = lds0 + (unsigned)((cg & 1) * PBUF + pl * PLANE + kk * GST);
+            if (PARTS == 1 || part == 0) dma16(voff_p, src, __builtin_amdgcn_readfirstlane(dst));
+            else if (lane < 8 * (PR - 8)) dma16(voff_p2, src, __builtin_amdgcn_readfirstlane(dst + 1024u));   // (masked lanes write nothing)
         };
         // ---- weights: this wave's three fragments (pieces) of a K16 step, 16 bytes per lane each, straight from L2 into registers ----
         const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(wfrag) +
@@ -391,7 +404,8 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
             // store -- 64-bit multiplies in the first version -- was a tenth of the kernel's VALU time)
             const unsigned plane = (unsigned)(d.OHp * d.OWp);
             const unsigned char* obase = reinterpret_cast<const unsigned char*>(out + ((size_t)e_b * d.groups + e_g) * d.OC * plane);
-            const unsigned vo0 = ((unsigned)(4 * e_kh) * plane + (unsigned)((e_rt * NB + d.opad) * d.OWp + ow + d.opad)) * 4u;
+            const int oh0 = e_rt * TR + rh * NB;             // this wave's first row of the blob
+            const unsigned vo0 = ((unsigned)(4 * e_kh) * plane + (unsigned)((oh0 + d.opad) * d.OWp + ow + d.opad)) * 4u;
             f32x4v bl[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                    // this lane's 4 rows of each 8-row slice (the packed weights' padding rows: clamped)
@@ -404,10 +418,10 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                 // the two halves of the wave complete to whole words.
                 unsigned char* pbase = reinterpret_cast<unsigned char*>(out_planes) + (size_t)e_b * d.o_cgtot * 4 * d.o_Hp * d.o_Wp * 16;
                 const unsigned wplane = (unsigned)(d.o_Hp * d.o_Wp) * 16u;
-                const unsigned vo_p = (unsigned)((e_rt * NB + d.o_pad) * d.o_Wp + ow + d.o_pad) * 16u + 8u * (unsigned)e_kh;
+                const unsigned vo_p = (unsigned)((oh0 + d.o_pad) * d.o_Wp + ow + d.o_pad) * 16u + 8u * (unsigned)e_kh;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    if (ow >= d.OW || e_rt * NB + j >= d.OH) continue;
+                    if (ow >= d.OW || oh0 + j >= d.OH) continue;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int m0 = __builtin_amdgcn_readfirstlane(m_blk + 8 * q);
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
             } else
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (ow >= d.OW || e_rt * NB + j >= d.OH) continue;       // (one exec-mask region per row of the tile)
+                if (ow >= d.OW || oh0 + j >= d.OH) continue;       // (one exec-mask region per row of the tile)
                 const unsigned vo = vo0 + (unsigned)(j * d.OWp) * 4u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -1262,16 +1262,17 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         pd.B = batch;
         if (planes_next) { const PieceDims& nx = S->L[li + 1].pdh; pd.o_cgtot = nx.CGtot; pd.o_Hp = nx.Hp; pd.o_Wp = nx.Wp; pd.o_pad = 1; pd.o_ascale = S->L[li + 1].ascale; }
         if (halves) pd.oscale = 1.f / (S->L[li].hscale * S->L[li].ascale);
-        constexpr int nb = 4;                                               // rows of a tile
-        pd.rtiles = (pd.OH + nb - 1) / nb;
+        constexpr int nb = 4;                                               // rows of a wave's four 32 x 32 blocks
+        const int tile_rows = halves && li == 3 ? 2 * nb : nb;              // (conv4 on pairs: 64 channels x 8 rows per tile)
+        pd.rtiles = (pd.OH + tile_rows - 1) / tile_rows;
         const int total = pd.groups * batch * pd.rtiles * pd.ctiles * pd.mtiles;
         const unsigned blocks = (unsigned)std::min(total, 2 * h->num_cu);   // two workgroups per CU (LDS: two patch buffers each)
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CP_THREADS), 0, st, pd, src6, halves ? S->L[li].whalf : S->L[li].wsplit, S->L[li].bias,
                                dst, planes_next, ctr + li, total);
         };
-        if (halves) { if (li == 1) go(conv_pieces_kernel<5, nb, 2>); else go(conv_pieces_kernel<3, nb, 2>); }
-        else { if (li == 1) go(conv_pieces_kernel<5, nb, 3>); else go(conv_pieces_kernel<3, nb, 3>); }
+        if (halves) { if (li == 1) go(conv_pieces_kernel<5, nb, 2, 1>); else if (li == 3) go(conv_pieces_kernel<3, nb, 2, 2>); else go(conv_pieces_kernel<3, nb, 2, 1>); }
+        else { if (li == 1) go(conv_pieces_kernel<5, nb, 3, 1>); else go(conv_pieces_kernel<3, nb, 3, 1>); }
     };
     unsigned short* p6_2 = reinterpret_cast<unsigned short*>(R[R_P6_2]);
     unsigned short* p6_3 = reinterpret_cast<unsigned short*>(R[R_P6_3]);
@@ -1609,11 +1610,12 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             pd.in_image = (long long)pd.CGtot * 6 * d.Hp * d.Wp * 16;
             pd.oscale = 1.f;
             // the same layer on fp16 pairs: weights x 2^k (the largest in [2^13, 2^14)), two pieces each; 32-row blocks padded to
-            // whole tiles of four (conv4: 6 -> 8)
+            // whole tiles (none needed: 4 per tile, conv4 2)
             PieceDims& ph = l.pdh;
             ph = pd;
-            ph.mblocks = (t.OC / 32 + 3) / 4 * 4;
-            ph.mtiles = ph.mblocks / 4;
+            const int mbt = li == 3 ? 2 : 4;                          // 32-row blocks per tile: 128 channels x 4 rows; conv4 (192 channels per group) 64 x 8
+            ph.mblocks = (t.OC / 32 + mbt - 1) / mbt * mbt;
+            ph.mtiles = ph.mblocks / mbt;
             ph.in_image = (long long)ph.CGtot * 4 * d.Hp * d.Wp * 16;
             float wmax = 0.f;
             for (size_t i = 0; i < w_floats; ++i) wmax = std::max(wmax, std::fabs(wsrc[i]));
