@@ -92,7 +92,7 @@ def parse():
                          "the library's default); 2 = conv2 / fc6 on exact bf16 triples (six products) + conv3..5 Winograd F(2x2,3x3) on the "
                          "f32 matrix cores; 1 = Winograd everywhere (conv2: F(2x2,5x5)); 0 = direct implicit GEMM on the f32 matrix cores "
                          "(vpk_cnn_set_algorithm)")
-    ap.add_argument("--cnn-fusion", type=int, default=3, choices=[0, 1, 2, 3],
+    ap.add_argument("--cnn-fusion", type=int, default=3, choices=[0, 1, 2, 3, 4],
                     help="conv1 + norm1 + pool1: 3 = direct convolution on the bf16 matrix cores with exact operands (uint8 raster = one "
                          "bf16 piece, weights = three; default), 1 = direct convolution on the f32 matrix cores, 2 = implicit-GEMM "
                          "kernel with the fused epilogue, 0 = separate kernels")
@@ -490,6 +490,7 @@ def extra_workloads(args, local_rank):
 
 def cnn_algorithm_text(args):
     c1 = {3: "conv1: direct on the bf16 matrix cores, exact operands (uint8 raster = 1 bf16 piece, weights = 3 pieces: 3 products per f32 product)",
+          4: "conv1: direct on the fp16 matrix cores (uint8 raster = 1 exact fp16 piece, weights = scaled fp16 pairs: 2 products per f32 product)",
           1: "conv1: direct on v_mfma_f32", 2: "conv1: implicit GEMM on v_mfma_f32", 0: "conv1: implicit GEMM on v_mfma_f32, separate LRN / pool"}[args.cnn_fusion]
     fc = "fc6-8: v_mfma_f32"
     if args.cnn_precision == 1:
@@ -513,6 +514,8 @@ def dtype_text(args):
     bf, hf = [], []
     if args.cnn_fusion == 3:
         bf.append("conv1")
+    elif args.cnn_fusion == 4:
+        hf.append("conv1")
     if args.cnn_precision == 1:
         bf.append("conv2-5")
     elif args.cnn_algorithm == 4:

@@ -155,6 +155,8 @@ int vpk_cnn_forward_tap(vpk_handle* h, const uint8_t* sphere, int batch, float* 
  *   3 (default)  ONE kernel on the bf16 matrix cores with EXACT operands: the uint8 raster is one bf16 piece, each weight the sum
  *                of three, `- mean` (evaluation.py:35) a constant map made in float64 at load -- three bf16 products per f32
  *                product, none of them rounded (csrc/cnn_conv1_pieces.hpp).  The 96 x 123 x 123 conv1 blob is never written.
+ *   4            the same kernel with the weights as scaled fp16 PAIRS (two products: the raster's integers are exact fp16 numbers too);
+ *                no faster -- the kernel is bound by its LDS epilogue, not by the matrix pipe (0.366 against 0.375 ms) -- and not the default
  *   1            ONE kernel on the f32-input matrix instructions (v_mfma_f32_16x16x4_f32: an f32 FMA chain over the 121 taps)
  *   2            the implicit-GEMM kernel with the fused LRN / pooling epilogue
  *   0            separate conv1 and LRN / pooling kernels (also used whenever tap 0 is requested) */

@@ -89,6 +89,8 @@ class Net(object):
         if layer == "conv1":
             if fusion == 3:      # 168 tiles x 12 waves x 72 v_mfma_f32_16x16x32_bf16 (cnn_conv1_pieces.hpp)
                 return 168 * 12 * 72 * 2.0 * 16 * 16 * 32, "bf16"
+            if fusion == 4:      # ... x 48 v_mfma_f32_16x16x32_f16
+                return 168 * 12 * 48 * 2.0 * 16 * 16 * 32, "f16"
             if fusion == 1:      # 168 tiles x 8 waves x 186 v_mfma_f32_16x16x4_f32
                 return 168 * 8 * 186 * 2.0 * 16 * 16 * 4, "f32"
             return alg * 128.0 / 121.0, "f32"
@@ -110,8 +112,9 @@ class Net(object):
         return alg * pad, "f32"
 
     def set_fusion(self, on=3):
-        """conv1 + norm1 + pool1: 3 (default) one kernel on the bf16 matrix cores with exact operands, 1 one kernel on the f32
-        matrix cores, 2 the implicit-GEMM kernel with the fused epilogue, 0 separate kernels (include/vpk.h)."""
+        """conv1 + norm1 + pool1: 3 (default) one kernel on the bf16 matrix cores with exact operands, 4 the same kernel on scaled fp16
+        pairs of the weights, 1 one kernel on the f32 matrix cores, 2 the implicit-GEMM kernel with the fused epilogue, 0 separate
+        kernels (include/vpk.h)."""
         self.rt.check(self.rt.lib.vpk_cnn_set_fusion(self.rt.h, int(on)))
 
     def set_algorithm(self, mode):
