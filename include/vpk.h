@@ -169,7 +169,7 @@ int vpk_cnn_set_precision(vpk_handle* h, int mode);
 /* Algorithm of conv2..conv5 and fc6 (precision 0):
  *   4  (default) DIRECT convolutions (and fc6's weight stream) on the fp16 matrix cores, every f32 operand as a SCALED PAIR of fp16
  *      numbers h0 = fp16(s x), h1 = fp16(s x - h0) -- 22 of its 24 significand bits, the remainder below 2^-23 |x| -- and THREE exact
- *      products per f32 product (h0 h0', h0 h1', h1 h0'; the fourth is below 2^-24 of the product).  s is a power of two: per layer
+ *      products per f32 product (h0 h0', h0 h1', h1 h0'; the fourth, h1 h1', is at most 2^-22 and typically 2^-24 of the product).  s is a power of two: per layer
  *      for the weights (the largest lands in [2^13, 2^14)), 2^-3 for activations; the epilogue multiplies by the exact reciprocal.
  *      Sums as in 2: the products of a kernel row x 16 channels (all taps of a 3 x 3 layer) accumulate from zero and join the f32
  *      accumulator with ONE rounding.  Half the matrix instructions of 2 -- which matters because the matrix cores are

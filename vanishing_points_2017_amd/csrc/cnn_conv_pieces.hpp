@@ -59,15 +59,16 @@ struct PieceDims {
 };
 
 // fp16 PAIRS (round 5): an f32 operand x is h0 + h1 with h0 = fp16(x), h1 = fp16(x - h0): 22 significand bits of its 24 (the
-// remainder is below 2^-23 |x|), and of the four partial products h_i h_j (each EXACT in f32: 11 x 11 bits) the three with
-// i + j <= 1 carry everything above 2^-24 of the product -- HALF the matrix instructions of the bf16 triples, for operands that are
-// a bit short of exact.  fp16's exponent range is what needs care, and powers of two take care of it (exactly):
+// remainder is at most 2^-23 |x|), and of the four partial products h_i h_j (each EXACT in f32: 11 x 11 bits) the three with
+// i + j <= 1 leave out h1 h1' -- at most 2^-22, typically 2^-24 of the product (|h1| <= 2^-11 |x|) -- HALF the matrix instructions of the
+// bf16 triples, for a product that is within 8 x 2^-24 of exact in the worst case and 2^-24 in the median
+// (tests/test_split_precision_math.py) where an f32 FMA chain rounds every partial sum to 2^-24 of ITS magnitude.  fp16's exponent range is what needs care, and powers of two take care of it (exactly):
 //   * weights: x 2^k per layer, the largest in [2^13, 2^14): every weight down to 2^-17 of the largest keeps a normal second piece;
 //   * activations: x a power of two per CONSUMING layer, fixed at load by a calibration forward (vpk_cnn.hip: calibrate): the layer's
-//     input blob for a synthetic raster, computed by the f32 direct kernels, is brought to a maximum in [64, 128).  An activation
-//     keeps both pieces normal (full precision) from 2^-10 to 2^+9 of that calibration maximum; below, the second piece becomes
-//     denormal -- the matrix cores multiply fp16 denormals, measured with scripts/ubench/mfma_f16_pairs.hip -- and the ABSOLUTE
-//     error stays below 2^-25 / scale; 2^9 above it fp16 overflows (a net whose activations for real rasters are 500 x those of the
+//     input blob for a synthetic raster, computed by the f32 direct kernels, is brought to a maximum in [64, 128).  The pair misses
+//     the scaled value x by at most max(2^-23 |x|, 2^-25) (tests/test_split_precision_math.py): full precision from 2^-8 to 2^+9 of
+//     the calibration maximum; below, the second piece is a denormal -- the matrix cores multiply fp16 denormals, measured with
+//     scripts/ubench/mfma_f16_pairs.hip -- and the ABSOLUTE error stays below 2^-25 / scale; 2^9 above it fp16 overflows (a net whose activations for real rasters are 500 x those of the
 //     calibration raster; CP_DEFAULT_ASCALE is the uncalibrated fallback);
 //   * the epilogue multiplies by the exact reciprocal of both.
 // Whether a layer may use this is decided by MEASUREMENT against the float64 net (tests/test_gpu_cnn.py: no further from it than the
