@@ -34,7 +34,8 @@
 // row by row with the next step's operands requested behind each row, and the accumulators are touched only by inline asm
 // (so that the register allocator cannot move them): ~25 other instructions per 12 (24) matrix instructions, 0 spills.
 // Where it stands (B = 102, kernels alone): conv2 0.60-0.67 ms (was 1.20 on triples with the first loop, 1.46 Winograd), conv3 / 4 / 5
-// 0.40 / 0.36 / 0.21 ms (Winograd: 0.73 / 0.55 / 0.37): 1.3-1.5 PFLOP/s executed = 80-90 % of the sustained ceiling.
+// 0.40 / 0.34 / 0.21 ms (Winograd: 0.73 / 0.55 / 0.37): 1.2-1.4 PFLOP/s executed = 72-85 % of the sustained ceiling; the rest is memory latency
+// (timing ablations in DESIGN.md section 8: the patch DMA's completion is tied to the weight waits by the in-order vmcnt).
 #ifndef VPK_CNN_CONV_PIECES_HPP_
 #define VPK_CNN_CONV_PIECES_HPP_
 
