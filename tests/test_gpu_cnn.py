@@ -268,6 +268,10 @@ def test_forward_is_bit_reproducible_at_the_bench_batch():
                 a = net.forward(sphere, tap=tap)[1]
                 for _ in range(2):
                     assert np.array_equal(net.forward(sphere, tap=tap)[1], a), (algorithm, tap)
+        # a second load of the same model calibrates to the same activation scales: the same bits again
+        net.set_algorithm(4)
+        first = net.forward(sphere[:7])
+        assert np.array_equal(cnn.Net(w, mean).forward(sphere[:7]), first)
     finally:
         net.set_algorithm(4)
 
