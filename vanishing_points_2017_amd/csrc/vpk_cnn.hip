@@ -1407,10 +1407,13 @@ int calibrate(vpk_handle* h) {
     }
     uint8_t* d_img = nullptr;
     float *d_out = nullptr, *d_tap = nullptr;
-    VPK_HIP(h, hipMalloc((void**)&d_img, img.size()));
-    VPK_HIP(h, hipMalloc((void**)&d_out, 400 * sizeof(float)));
-    VPK_HIP(h, hipMalloc((void**)&d_tap, A_POOL1 * sizeof(float)));        // (the largest tapped blob)
-    VPK_HIP(h, hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+    auto release = [&]() { (void)hipFree(d_img); (void)hipFree(d_out); (void)hipFree(d_tap); };
+    if (hipMalloc((void**)&d_img, img.size()) != hipSuccess || hipMalloc((void**)&d_out, 400 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&d_tap, A_POOL1 * sizeof(float)) != hipSuccess ||        // (the largest tapped blob)
+        hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        release();
+        return vpk_fail(h, VPK_ERR_HIP, "vpk_cnn_load: buffers of the calibration forward");
+    }
     const int keep_alg = S->algorithm, keep_fuse = S->fuse_conv1, keep_prec = S->precision;
     S->algorithm = 0; S->fuse_conv1 = 1; S->precision = 0;
     const int layer_tap[6][2] = {{1, 1}, {2, 3}, {3, 4}, {4, 5}, {5, 7}, {6, 8}};       // (layer, tap of its input: pool1, pool2, conv3, conv4, pool5, fc6)
@@ -1432,7 +1435,7 @@ int calibrate(vpk_handle* h) {
         S->L[layer_tap[i][0]].ascale = sc;
     }
     S->algorithm = keep_alg; S->fuse_conv1 = keep_fuse; S->precision = keep_prec;
-    (void)hipFree(d_img); (void)hipFree(d_out); (void)hipFree(d_tap);
+    release();
     return rc;
 }
 
