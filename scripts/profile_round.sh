@@ -54,5 +54,6 @@ bash scripts/pmc_kernel.sh conv_pieces_kernelILi5 > $R/summary/${N}_pmc_conv2_is
 VPK_ALGORITHM=2 bash scripts/pmc_kernel.sh conv_pieces_kernelILi5 >> $R/summary/${N}_pmc_conv2_issue.txt 2>&1
 bash scripts/pmc_kernel.sh conv1_pieces > $R/summary/${N}_pmc_conv1_issue.txt 2>&1
 # what the matrix cores sustain with operands that change between instructions
+[ -x scripts/ubench/mfma_f16_pairs ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/mfma_f16_pairs.hip -o scripts/ubench/mfma_f16_pairs > /dev/null 2>&1
 ./scripts/ubench/mfma_f16_pairs > $R/summary/${N}_mfma_sustained.txt 2>&1
 du -sh $R
