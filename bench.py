@@ -378,6 +378,11 @@ def hlw_pass(local_rank, n_batches=10, em_wgs=128):
             gem.em_batch_device(lane, b["d"]["offsets"], b["l_tmp"], b["d"]["lp"], b["d"]["cnn"], b["sphere"], None, params, max_vp=64)
     em_s = stage_alone(em_only)
     rasters_same = all(bool(torch.equal(b["sphere"], b["d"]["sphere"])) for b in batches)
+    # the CNN's maps are not the EM's prior in this pass, but they are computed on 1000-line rasters: assert that the default
+    # arithmetic stayed inside its calibrated range on them and produced finite maps (include/vpk.h: vpk_cnn_range_flags)
+    cnn_range = net.range_flags()
+    cnn_finite = all(bool(torch.isfinite(b["step"].resp).all().item()) for b in batches)
+    assert cnn_range == 0 and cnn_finite, "HLW pass: CNN left the fp16-pair range (flags %#x) or produced non-finite maps" % cnn_range
     results = [None] * len(scenes)
     iters = np.zeros(len(scenes)); nvp = np.zeros(len(scenes)); status = np.zeros(len(scenes), dtype=np.int64)
     for b in batches:
@@ -410,6 +415,7 @@ def hlw_pass(local_rank, n_batches=10, em_wgs=128):
            "cnn_roofline": hlw_cnn_roofline(net, len(scenes), cnn_s),
            "horizon_auc": float(auc_mod.calc_auc(errs.copy(), cutoff=0.25)[0]),
            "rasters_equal_untimed_pass": rasters_same,
+           "cnn_range_check": {"range_flags": cnn_range, "response_maps_finite": cnn_finite},
            "setup_s_outside_timing": setup_s,
            "note": "timed (host clock around the whole pass): per batch vpk_sphere_raster on its own stream -> vpk_pipeline_step (CNN "
                    "stream -> one of three EM lanes, %d workgroups each; priors = the generator's response maps, the CNN's output is "
@@ -468,7 +474,7 @@ def extra_workloads(args, local_rank):
     a.em_wgs, a.cnn_precision = -1, 0
     s = run_workload(a, None, 0, local_rank, 1)
     out["stress"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "stage_ms",
-                                       "cnn_layer_ms", "em_stats", "roofline")}
+                                       "cnn_layer_ms", "em_stats", "roofline", "cnn_range_check")}
     out["stress"]["roofline_secondary"] = {
         "kernel": s["roofline_secondary"]["kernel"], "achieved": None, "frac": None,
         "note": "not reported for this shape: the EM holds every CU, so the CNN's kernels run parked behind it (in a kernel trace of this run "
@@ -692,6 +698,12 @@ def run_workload(args, dist, rank, local_rank, world):
     sync_all()
     elapsed = time.perf_counter() - t0
     layer_ms, layer_passes = net.mean_layer_ms()         # averaged over the timed steps' passes (HIP events on the CNN stream)
+    # the default arithmetic's value range (include/vpk.h: vpk_cnn_range_flags): no activation of any forward so far was clamped, and
+    # the last step's response maps are finite -- a run that left the calibrated range is not a measurement
+    cnn_range = net.range_flags()
+    resp_last = alive[-1][0] if sliced else ring[(args.warmup + args.steps - 1) % len(ring)].resp
+    cnn_finite = bool(torch.isfinite(resp_last).all().item())
+    assert cnn_range == 0 and cnn_finite, "CNN left the fp16-pair range (flags %#x) or produced non-finite maps" % cnn_range
     out = {q: (v.clone() if torch.is_tensor(v) else v) for q, v in out.items()}   # the ring's buffers are reused by the legs below
     rank_elapsed = [elapsed]
     if dist is not None:
@@ -1000,6 +1012,9 @@ def run_workload(args, dist, rank, local_rank, world):
                          if sliced else
                          {"cnn": cnn_ms, "em": em_ms, "em_mode": "lanes", "em_lanes": n_lanes, "em_workgroups": em_wgs,
                           "note": "stages of consecutive steps overlap (1 CNN stream + em_lanes EM streams)"}),
+            "cnn_range_check": {"range_flags": cnn_range, "response_maps_finite": cnn_finite,
+                                "note": "vpk_cnn_range_flags over every forward up to the end of the timed steps (0 = no scaled fp16-pair "
+                                        "activation was clamped); asserted"},
             "cnn_layer_ms": {k: round(v, 4) for k, v in layer_ms.items()},
             "cnn_layer_ms_note": "mean over the %d timed steps' passes (HIP events between the layers on the CNN stream)" % layer_passes,
             "em_stats": {"iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),

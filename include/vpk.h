@@ -38,7 +38,8 @@ enum vpk_status {
     VPK_ERR_HIP = -2,       /* a HIP runtime call failed                        */
     VPK_ERR_NO_DEVICE = -3, /* no usable gfx950 device                          */
     VPK_ERR_STATE = -4,     /* call order (e.g. cnn_forward before cnn_load)    */
-    VPK_ERR_LIMIT = -5      /* problem exceeds a compiled-in limit (max VPs...) */
+    VPK_ERR_LIMIT = -5,     /* problem exceeds a compiled-in limit (max VPs...) */
+    VPK_ERR_RANGE = -6      /* the CNN's fp16-pair arithmetic left its calibrated value range (vpk_cnn_range_flags) */
 };
 
 /* per-image EM result status (status_out of vpk_em_batch) */
@@ -134,8 +135,36 @@ int vpk_em_flush(vpk_handle* h);
  * (evaluation.py:17-31).  blobs [host]: 16 host pointers to fp32 arrays in Caffe layout,
  * order conv1.w, conv1.b, conv2.w, conv2.b, ..., conv5.b, fc6.w, fc6.b, fc7.w, fc7.b, fc8.w,
  * fc8.b (OIHW / (out,in)); mean [host]: 500*500 fp32 (mean.binaryproto, 1x1x500x500).
- * Copies to HBM (synchronous). */
+ * Copies to HBM (synchronous), packs the weights for every arithmetic mode, and CALIBRATES the default mode's activation
+ * scales: six forwards of three built-in rasters (batch 3) on the f32 direct kernels, tapped at the inputs of conv2..5, fc6 and
+ * fc7 -- ~20 ms of GPU time; see vpk_cnn_calibrate.  The response maps of the default mode depend on those scales (to rounding,
+ * not beyond: tests/test_gpu_cnn.py), which are a function of the weights and the mean alone -- two loads of one model give
+ * the same bits.  If calibration fails the model stays unloaded. */
 int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean);
+/* The value range of the default arithmetic (vpk_cnn_set_algorithm(4): scaled fp16 pairs) and how it is kept.
+ * A layer's input x reaches the matrix cores as the fp16 pair of s x, s a power of two per consuming layer (conv2..5, fc6, fc7).
+ * s is chosen so that the LARGEST |x| of that blob over a calibration set lands in [32, 64): rasters whose activations are up to
+ * 2^10 x those of the calibration set stay finite, and smaller values keep full precision (22 bits) down to 2^-13 of the
+ * calibration maximum and an absolute error below 2^-31 of it beyond that.  The built-in set is a sparse raster, a raster of
+ * 1000 blended strokes (the density of a 1000-line sphere image, evaluation.py:12-14) and the all-255 raster.
+ *   vpk_cnn_calibrate      rasters: n x 500 x 500 uint8 (DEVICE, 4-byte aligned) of the caller's choice -- the scales are set
+ *                          from THESE rasters' blob maxima alone; n = 0 (rasters ignored): the built-in set again.  Runs
+ *                          6 x ceil(n / 8) forwards on the f32 direct kernels and waits for them.
+ *   vpk_cnn_get/set_activation_scales   the six powers of two (inputs of conv2, conv3, conv4, conv5, fc6, fc7); set: each
+ *                          must be a power of two (VPK_ERR_ARG otherwise).  Restoring a saved vector restores the bits.
+ *   vpk_cnn_range_flags    fp16's largest finite number is 65 504.  Every kernel that writes a scaled pair clamps to it and ORs
+ *                          bit li (1 = conv2 ... 4 = conv5, 5 = fc6, 6 = fc7: the CONSUMING layer) into a device word when a value
+ *                          reached it; nothing non-finite is ever produced by the scaling.  This call waits for the handle's
+ *                          stream, returns the word in *flags_out (may be NULL), clears it, and returns VPK_ERR_RANGE when it
+ *                          was non-zero (vpk_last_error names the layers), VPK_OK otherwise: it covers every forward on the
+ *                          handle since the previous call.  A flagged response map was computed from clamped activations -- it
+ *                          is finite but NOT the net's: recalibrate, or switch to vpk_cnn_set_algorithm(2) (exact operands, no
+ *                          range to leave).  The reference's f32 Caffe forward (evaluation.py:34-38) has no such limit; this
+ *                          is how the limit of the faster arithmetic is made impossible to miss. */
+int vpk_cnn_calibrate(vpk_handle* h, const uint8_t* rasters, int n);
+int vpk_cnn_get_activation_scales(vpk_handle* h, float scales[6]);
+int vpk_cnn_set_activation_scales(vpk_handle* h, const float scales[6]);
+int vpk_cnn_range_flags(vpk_handle* h, uint32_t* flags_out);
 /* replaces: caffe_forward (evaluation.py:34-38) for a batch: sphere B x 500 x 500 uint8 ->
  * out B x 20 x 20 fp32 (sigout).  max batch per call is unbounded (internally chunked).  `sphere` must be 4-byte
  * aligned (device allocations are). */
@@ -170,7 +199,8 @@ int vpk_cnn_set_precision(vpk_handle* h, int mode);
  *   4  (default) DIRECT convolutions (and fc6's weight stream) on the fp16 matrix cores, every f32 operand as a SCALED PAIR of fp16
  *      numbers h0 = fp16(s x), h1 = fp16(s x - h0) -- 22 of its 24 significand bits, the remainder below 2^-23 |x| -- and THREE exact
  *      products per f32 product (h0 h0', h0 h1', h1 h0'; the fourth, h1 h1', is at most 2^-22 and typically 2^-24 of the product).  s is a power of two: per layer
- *      for the weights (the largest lands in [2^13, 2^14)), 2^-3 for activations; the epilogue multiplies by the exact reciprocal.
+ *      for the weights (the largest lands in [2^13, 2^14)), per consuming layer for the activations (calibrated at load: vpk_cnn_calibrate
+ *      above, with the range check that goes with it); the epilogue multiplies by the exact reciprocal.
  *      Sums as in 2: the products of a kernel row x 16 channels (all taps of a 3 x 3 layer) accumulate from zero and join the f32
  *      accumulator with ONE rounding.  Half the matrix instructions of 2 -- which matters because the matrix cores are
  *      power-limited with real operands (1.7 PFLOP/s sustained against the 2.5 dense peak, scripts/ubench/mfma_f16_pairs.hip).

@@ -278,9 +278,11 @@ def test_forward_is_bit_reproducible_at_the_bench_batch():
 
 def test_fp16_pairs_over_the_operand_range():
     """The fp16 pairs of vpk_cnn_set_algorithm(4) live in fp16's exponent range: weights are brought there by a power of two per layer,
-    activations by a fixed 2^-3 (cnn_conv_pieces.hpp).  Nets whose blobs are 128 x larger / smaller than the synthetic net's -- conv2's
-    weights and bias x 2^7, conv3's weights x 2^-7 (and the other way round: small activations fall into fp16's denormals, which the
-    matrix cores multiply) -- must still be no further from the float64 net than the f32 direct kernels, at every tap behind conv2."""
+    activations by a power of two per consuming layer that vpk_cnn_load CALIBRATES on the loaded weights (include/vpk.h:
+    vpk_cnn_calibrate).  Nets whose blobs are 128 x larger / smaller than the synthetic net's -- conv2's weights and bias x 2^7, conv3's
+    weights x 2^-7, and the other way round -- must therefore come out like the synthetic net: no further from the float64 net than the
+    f32 direct kernels, at every tap behind conv2.  (What calibration canNOT absorb -- an INPUT whose activations are far from the
+    calibration rasters' -- is test_default_path_on_dense_rasters_and_the_all_255_image and test_range_guard_* below.)"""
     from oracle import cnn_torch
     from vanishing_points_2017_amd import cnn, sphere_mapping, synth
     base = cnn.synthetic_weights(0)
@@ -340,3 +342,125 @@ def test_winograd_convolutions_against_the_float64_net():
     finally:
         net.set_algorithm(4)                                       # the library's default
     print({k: ([round(e[0] / v[1], 9) for e in v[0]]) for k, v in report.items()})
+
+
+def _dense_rasters():
+    """Rasters of the densities the YUD-shape tests never reach: an ECD-shape scene with > 1000 lines (configs[2]), an HLW-shape scene
+    (configs[3]) with > 800, a stress scene (configs[4], N = 1000), and the largest input the uint8 boundary admits."""
+    from vanishing_points_2017_amd import sphere_mapping, synth
+    picks = []
+    for cid, lo in ((3, 1000), (4, 800), (5, 1000)):
+        for sc in synth.config_scenes(cid, count=40):
+            if sc["l"].shape[0] >= lo:
+                picks.append(sc["l"])
+                break
+    assert len(picks) == 3
+    sphere = sphere_mapping.raster_batch(picks)
+    return np.concatenate([sphere, np.full((1, 500, 500), 255, np.uint8)]), [p.shape[0] for p in picks]
+
+
+def test_default_path_on_dense_rasters_and_the_all_255_image():
+    """The factor-1 rule of test_default_path_is_no_further_... where the fp16 pairs are EXPOSED: the activation
+    scales are fixed at load, so what matters is an input whose blobs are far larger than a sparse raster's.  Rasters of 1000-line
+    scenes (configs[2], [3], [4]: evaluation.py:12-14 with those line counts) and the all-255 image, every tap and the output,
+    against the float64 net: the default (fusion 3, algorithm 4) no further from it than the f32 direct kernels, nothing clamped."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere, counts = _dense_rasters()
+    assert min(counts) >= 800 and sphere[:3].mean() > 40 and sphere[:3].max() > 200, (counts, sphere.mean(), sphere.max())
+    net = cnn.Net(w, mean)
+    ref, taps = cnn_torch.forward(w, mean, sphere, want_taps=True, dtype=np.float64)
+    report = {}
+    try:
+        for tap in (1, 2, 3, 4, 5, 6, 7, 8, 9):                    # pool1 .. fc7
+            want = taps[cnn_torch.TAPS[tap]]
+            scale = float(np.abs(want).max())
+            err = {}
+            for name, (fusion, algorithm) in (("direct_f32", (1, 0)), ("default", (3, 4))):
+                net.set_fusion(fusion)
+                net.set_algorithm(algorithm)
+                out, got = net.forward(sphere, tap=tap)            # (raises VpkRangeError if anything was clamped)
+                assert np.isfinite(got).all() and np.isfinite(out).all()
+                err[name] = (float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(out - ref).max()))
+            report[cnn_torch.TAPS[tap]] = {n: round(e[0] / scale, 9) for n, e in err.items()}
+            assert err["default"][0] <= err["direct_f32"][0] + 6e-8 * scale, (cnn_torch.TAPS[tap], err, scale)
+            assert err["default"][1] <= err["direct_f32"][1] + 6e-8, (cnn_torch.TAPS[tap], err)
+            assert err["default"][1] <= 2e-5
+        assert net.range_flags() == 0
+    finally:
+        net.set_fusion(3)
+        net.set_algorithm(4)
+    print(report)
+
+
+def test_calibration_covers_the_dense_rasters_with_headroom():
+    """The scales vpk_cnn_load picks come from the built-in calibration set (sparse noise, 1000 blended strokes, all-255): every
+    blob of a dense raster and of the all-255 image, multiplied by its layer's scale, must stay below 2^7 -- at least 2^9 of headroom
+    to fp16's 65 504 -- and the largest must not be tiny either (> 2^-3: the pairs keep 22 bits down to 2^-13 of the calibration
+    maximum).  Recalibrating on caller rasters and restoring the saved scales gives back the same bits."""
+    from oracle import cnn_torch
+    from vanishing_points_2017_amd import cnn
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere, _ = _dense_rasters()
+    net = cnn.Net(w, mean)
+    scales = net.activation_scales()
+    assert scales.shape == (6,) and all(np.frexp(float(x))[0] == 0.5 for x in scales)
+    _, taps = cnn_torch.forward(w, mean, sphere, want_taps=True)
+    for sc, tap in zip(scales, (1, 3, 4, 5, 7, 8)):                # inputs of conv2, conv3, conv4, conv5, fc6, fc7
+        m = float(np.abs(taps[cnn_torch.TAPS[tap]]).max()) * float(sc)
+        assert 0.125 < m < 128.0, (cnn_torch.TAPS[tap], m, sc)
+    first = net.forward(sphere)
+    net.calibrate(sphere[:2])                                       # the caller's rasters alone decide
+    mine = net.activation_scales()
+    assert all(np.frexp(float(x))[0] == 0.5 for x in mine)
+    again = net.forward(sphere)
+    assert np.abs(again - first).max() <= 2e-6
+    net.calibrate(None)                                             # the built-in set again
+    assert np.array_equal(net.activation_scales(), scales)
+    assert np.array_equal(net.forward(sphere), first)
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2, 3, 4, 5])
+def test_range_guard_reports_a_clamped_activation_and_never_lets_a_nan_out(layer):
+    """split2h_guard (cnn_conv_pieces.hpp): a scaled activation that reaches fp16's 65 504 is clamped and the consuming layer's bit set;
+    vpk_cnn_range_flags turns that into VPK_ERR_RANGE.  Provoked by setting ONE layer's scale far too high (the other five stay
+    calibrated): the forward must report exactly that layer, its response maps must be finite (round 5: inf - inf = NaN from there on),
+    the flag must clear on reading, and restoring the calibrated scales must restore the bits."""
+    from vanishing_points_2017_amd import cnn, sphere_mapping, synth
+    from vanishing_points_2017_amd._lib import VpkError, VpkRangeError
+    w = cnn.synthetic_weights(0)
+    mean = cnn.synthetic_mean(0)
+    sphere = sphere_mapping.raster_batch([s["l"] for s in synth.config_scenes(2, count=5, start=30)])
+    net = cnn.Net(w, mean)
+    rt = net.rt
+    good = net.activation_scales()
+    first = net.forward(sphere)
+    assert net.range_flags() == 0
+    bad = good.copy()
+    bad[layer] = good[layer] * np.float32(2.0 ** 16)               # (a YUD raster's blobs are up to 8 x below the calibration maximum of 32..64)
+    try:
+        net.set_activation_scales(bad)
+        with pytest.raises(VpkRangeError) as ei:
+            net.forward(sphere)
+        assert ei.value.flags == 1 << (layer + 1), (ei.value.flags, layer)
+        assert cnn.Net.RANGE_LAYERS[layer] in str(ei.value)
+        d = rt.torch.from_numpy(sphere).to(rt.tdev)
+        out = net.forward_device(d)
+        rt.synchronize()
+        assert np.isfinite(out.cpu().numpy()).all()
+        assert net.range_flags() == 1 << (layer + 1)
+        assert net.range_flags() == 0                               # (read and cleared)
+        for tap in (2, 4, 6, 8):                                    # the f32 taps stay finite as well
+            d_out, d_tap = net.forward_device(d, tap=tap)
+            rt.synchronize()
+            assert np.isfinite(d_tap.cpu().numpy()).all() and np.isfinite(d_out.cpu().numpy()).all()
+        net.range_flags()
+        with pytest.raises(VpkError):
+            net.set_activation_scales([1.0, 2.0, 3.0, 4.0, 8.0, 16.0])      # 3 is not a power of two
+    finally:
+        net.set_activation_scales(good)
+    assert np.array_equal(net.forward(sphere), first)
+    assert net.range_flags() == 0

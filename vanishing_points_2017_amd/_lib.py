@@ -15,6 +15,16 @@ class VpkError(RuntimeError):
     pass
 
 
+class VpkRangeError(VpkError):
+    """VPK_ERR_RANGE (include/vpk.h): the CNN's scaled fp16-pair activations reached fp16's largest finite number and were
+    clamped -- the response maps since the last check are finite but not the net's.  ``flags``: bit li = the consuming layer
+    (1 = conv2 ... 4 = conv5, 5 = fc6, 6 = fc7)."""
+
+    def __init__(self, msg, flags):
+        VpkError.__init__(self, msg)
+        self.flags = flags
+
+
 class EmParams(ctypes.Structure):
     """vpk_em_params: mirrors the keyword defaults of expectation_maximisation
     (reference vp_localisation.py:168-172)."""
@@ -48,6 +58,7 @@ EXPORTS = [
     "vpk_create", "vpk_destroy", "vpk_set_stream", "vpk_get_stream", "vpk_synchronize", "vpk_last_error", "vpk_version",
     "vpk_em_default_params", "vpk_device_info", "vpk_em_set_workgroups", "vpk_em_set_smoother", "vpk_em_set_lds_panel", "vpk_em_set_time_slice", "vpk_em_flush", "vpk_em_set_distribution_out", "vpk_cnn_load", "vpk_cnn_forward", "vpk_cnn_forward_tap",
     "vpk_cnn_set_profiling", "vpk_cnn_set_fusion", "vpk_cnn_set_precision", "vpk_cnn_set_algorithm", "vpk_cnn_last_layer_ms", "vpk_cnn_mean_layer_ms",
+    "vpk_cnn_calibrate", "vpk_cnn_get_activation_scales", "vpk_cnn_set_activation_scales", "vpk_cnn_range_flags",
     "vpk_sphere_raster", "vpk_sphere_raster_flags", "vpk_sphere_raster_set_alternative", "vpk_em_batch", "vpk_em_workspace_bytes", "vpk_pairwise", "vpk_init_vps",
     "vpk_estep", "vpk_weight_matrix", "vpk_mstep", "vpk_line_counts", "vpk_cluster2", "vpk_horizon_batch", "vpk_lsd_detect",
     "vpk_pipeline_step", "vpk_build_records", "vpk_record_width", "vpk_math_probe",
@@ -111,6 +122,10 @@ def load():
     lib.vpk_cnn_set_algorithm.argtypes = [c_void, ctypes.c_int]
     lib.vpk_cnn_last_layer_ms.argtypes = [c_void, ctypes.POINTER(ctypes.c_float)]
     lib.vpk_cnn_mean_layer_ms.argtypes = [c_void, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    lib.vpk_cnn_calibrate.argtypes = [c_void, c_void, ctypes.c_int]
+    lib.vpk_cnn_get_activation_scales.argtypes = [c_void, ctypes.POINTER(ctypes.c_float)]
+    lib.vpk_cnn_set_activation_scales.argtypes = [c_void, ctypes.POINTER(ctypes.c_float)]
+    lib.vpk_cnn_range_flags.argtypes = [c_void, ctypes.POINTER(ctypes.c_uint32)]
     lib.vpk_sphere_raster.argtypes = [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void]
     lib.vpk_sphere_raster_flags.argtypes = [c_void, ctypes.c_int, c_void]
     lib.vpk_sphere_raster_set_alternative.argtypes = [c_void, ctypes.c_int]

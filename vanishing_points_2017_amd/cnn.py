@@ -4,6 +4,7 @@ import ctypes
 
 import numpy as np
 
+from ._lib import VpkRangeError
 from .runtime import get_runtime
 
 # (name, weight shape in Caffe layout, fan-in) per cnn/deploy.prototxt
@@ -129,6 +130,50 @@ class Net(object):
         Mode 1 overrides the algorithm setting."""
         self.rt.check(self.rt.lib.vpk_cnn_set_precision(self.rt.h, int(mode)))
 
+    RANGE_LAYERS = ["conv2", "conv3", "conv4", "conv5", "fc6", "fc7"]      # the layers whose INPUT is a scaled fp16 pair
+
+    def activation_scales(self):
+        """The six powers of two the inputs of conv2..5, fc6, fc7 are multiplied by under set_algorithm(4) (calibrated at load)."""
+        sc = (ctypes.c_float * 6)()
+        self.rt.check(self.rt.lib.vpk_cnn_get_activation_scales(self.rt.h, sc))
+        return np.array([float(x) for x in sc], dtype=np.float32)
+
+    def set_activation_scales(self, scales):
+        sc = (ctypes.c_float * 6)(*[float(x) for x in scales])
+        self.rt.check(self.rt.lib.vpk_cnn_set_activation_scales(self.rt.h, sc))
+
+    def calibrate(self, rasters=None):
+        """Set the activation scales from the blob maxima of `rasters` (n x 500 x 500 uint8, host or device) -- None: the built-in
+        set of vpk_cnn_load (include/vpk.h: vpk_cnn_calibrate)."""
+        rt = self.rt
+        if rasters is None:
+            rt.check(rt.lib.vpk_cnn_calibrate(rt.h, None, 0))
+            return
+        t = rt.torch
+        if not isinstance(rasters, t.Tensor):
+            rasters = t.from_numpy(np.ascontiguousarray(rasters, dtype=np.uint8).reshape(-1, 500, 500))
+        with rt.on_stream():
+            d = rasters.to(rt.tdev).contiguous()
+        rt.synchronize()
+        rt.check(rt.lib.vpk_cnn_calibrate(rt.h, rt.ptr(d), int(d.shape[0])))
+
+    def range_flags(self):
+        """Waits for the handle's stream; the range word of every forward since the last call (and clears it): 0 = every scaled
+        activation stayed inside fp16's range.  Does not raise."""
+        w = ctypes.c_uint32(0)
+        rc = self.rt.lib.vpk_cnn_range_flags(self.rt.h, ctypes.byref(w))
+        if rc not in (0, -6):
+            self.rt.check(rc)
+        return int(w.value)
+
+    def check_range(self):
+        """Raise VpkRangeError if a forward since the last check clamped an activation (include/vpk.h: vpk_cnn_range_flags)."""
+        w = ctypes.c_uint32(0)
+        rc = self.rt.lib.vpk_cnn_range_flags(self.rt.h, ctypes.byref(w))
+        if rc == -6:
+            raise VpkRangeError("libvpk error -6: %s" % self.rt.lib.vpk_last_error(self.rt.h).decode(), int(w.value))
+        self.rt.check(rc)
+
     def set_profiling(self, on=True):
         self.rt.check(self.rt.lib.vpk_cnn_set_profiling(self.rt.h, int(bool(on))))
 
@@ -156,7 +201,7 @@ class Net(object):
         with rt.on_stream():
             d = rt.torch.from_numpy(sphere_u8).to(rt.tdev)
         res = self.forward_device(d, tap)
-        rt.synchronize()
+        self.check_range()          # (waits for the stream) a clamped activation is an error here, never a silently wrong map
         if tap is None:
             return res.cpu().numpy()
         return res[0].cpu().numpy(), res[1].cpu().numpy()

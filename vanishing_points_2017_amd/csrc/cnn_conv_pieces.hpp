@@ -56,6 +56,8 @@ struct PieceDims {
     long long in_image;                         // bytes per image of the input tensor (planes of 16-byte words)
     int o_cgtot, o_Hp, o_Wp, o_pad;             // the NEXT layer's piece planes (written instead of the f32 planes when the kernel gets them)
     float o_ascale;                             //   and its activation scale
+    unsigned* range_word;                       //   and where an activation beyond fp16's range is reported (split2h_guard), as bit
+    unsigned range_bit;                         //   range_bit (the consuming layer's)
     float oscale;                               // 1 / (weight scale x activation scale) of the fp16-pair operands (a power of two); 1 for bf16 pieces
 };
 
@@ -83,15 +85,30 @@ __device__ __forceinline__ void split2h(float x, unsigned short& h0, unsigned sh
     h1 = __builtin_bit_cast(unsigned short, b);
 }
 
+// The GUARDED split every activation writer uses (round 6).  fp16's largest finite number is 65 504: a scaled activation beyond it would
+// become h0 = inf, h1 = x - inf = -inf and the next layer's products NaN -- silently.  Instead the value is clamped to +-65 504 (NaN too:
+// fmax / fmin return the other operand) and `bad` remembers it; the kernel ORs the consuming layer's bit into the handle's range word
+// (range_report), which vpk_cnn_range_flags reads: a net whose activations leave the calibrated range is an ERROR the caller sees
+// (VPK_ERR_RANGE), never a response map of NaNs.  Cost: a compare, a scalar OR and a v_med3 per stored value, in the epilogues only.
+constexpr float CP_H_MAX = 65504.f;
+__device__ __forceinline__ void split2h_guard(float x, unsigned short& h0, unsigned short& h1, bool& bad) {
+    bad |= !(__builtin_fabsf(x) < CP_H_MAX);
+    split2h(__builtin_fminf(__builtin_fmaxf(x, -CP_H_MAX), CP_H_MAX), h0, h1);
+}
+__device__ __forceinline__ void range_report(bool bad, unsigned* __restrict__ range_word, unsigned bit) {
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(range_word, bit);
+}
+
 // f32 NCHW planes (with their zero border) -> piece planes: [image][channel group of 16][piece x k half (2 NP)][y][x] 16-byte words
 // (8 values = the B operand of one lane for one pixel).  NP = 3: bf16 triples; NP = 2: fp16 pairs of ascale x.  One workgroup
 // per (image, channel group, row): 16 channels x Wp values in, 2 NP x Wp words out.
 template <int NP>
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int Hp,
-                                                        int Wp, float ascale) {
+                                                        int Wp, float ascale, unsigned* __restrict__ range_word, unsigned range_bit) {
     const int y = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
     const float* src = in + (((size_t)b * C + cg * 16) * Hp + y) * Wp;
     u32x4* dst = reinterpret_cast<u32x4*>(out) + (((size_t)b * (C >> 4) + cg) * (2 * NP) * Hp + y) * Wp;
+    bool bad = false;
     for (int idx = threadIdx.x; idx < 2 * Wp; idx += 256) {      // (k half, x)
         const int h = idx / Wp, x = idx - h * Wp;
         unsigned short p[3][8];
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
         for (int e = 0; e < 8; ++e) {
             const float v = src[(size_t)(8 * h + e) * Hp * Wp + x];
             if (NP == 3) split3(v, p[0][e], p[1][e], p[2][e]);
-            else split2h(v * ascale, p[0][e], p[1][e]);
+            else split2h_guard(v * ascale, p[0][e], p[1][e], bad);
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -109,6 +126,7 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
             dst[(size_t)(2 * q + h) * Hp * Wp + x] = w4;
         }
     }
+    if (NP == 2) range_report(bad, range_word, range_bit);
 }
 
 template <int N>
@@ -419,6 +437,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                 // arena's zeros).  A lane holds 4 consecutive channels of an 8-channel word, lane + 32 the other 4: 8-byte stores that
                 // the two halves of the wave complete to whole words.
                 unsigned char* pbase = reinterpret_cast<unsigned char*>(out_planes) + (size_t)e_b * d.o_cgtot * 4 * d.o_Hp * d.o_Wp * 16;
+                bool bad = false;
                 const unsigned wplane = (unsigned)(d.o_Hp * d.o_Wp) * 16u;
                 const unsigned vo_p = (unsigned)((oh0 + d.o_pad) * d.o_Wp + ow + d.o_pad) * 16u + 8u * (unsigned)e_kh;
 #pragma unroll
@@ -434,13 +453,14 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                         for (int e = 0; e < 4; ++e) {
                             float v = acc[j][2 * q + e / 2][e % 2] * d.oscale + bl[q][e];
                             if (d.relu) v = v > 0.f ? v : 0.f;
-                            split2h(v * d.o_ascale, h0[e], h1[e]);
+                            split2h_guard(v * d.o_ascale, h0[e], h1[e], bad);
                         }
                         const unsigned w0 = ((unsigned)(c0 >> 4) * 4u + (unsigned)((c0 >> 3) & 1)) * wplane + vo_p + (unsigned)(j * d.o_Wp) * 16u;
                         *reinterpret_cast<u32x2*>(pbase + w0) = u32x2{(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
                         *reinterpret_cast<u32x2*>(pbase + (w0 + 2u * wplane)) = u32x2{(unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16)};
                     }
                 }
+                range_report(bad, d.range_word, d.range_bit);
             } else
 #pragma unroll
             for (int j = 0; j < NB; ++j) {

@@ -39,7 +39,7 @@ struct DenseDims {
 // NP = 2 fp16 pairs of ascale x (cnn_conv_pieces.hpp)
 template <int NP>
 __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int N, int K,
-                                                          int chunks, float ascale) {
+                                                          int chunks, float ascale, unsigned* __restrict__ range_word, unsigned range_bit) {
     const int c = blockIdx.x, nt = blockIdx.y;
     const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = nt * DP_BN + 32 * j + (lane & 31), h = lane >> 5;
@@ -56,11 +56,13 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float* __restric
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
     }
     unsigned short p[3][16];
+    bool bad = false;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         if (NP == 3) split3(v[e], p[0][e], p[1][e], p[2][e]);
-        else split2h(v[e] * ascale, p[0][e], p[1][e]);
+        else split2h_guard(v[e] * ascale, p[0][e], p[1][e], bad);
     }
+    if (NP == 2) range_report(bad, range_word, range_bit);
     u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)nt * chunks + c) * (DP_STAGE<NP> / 2));
 #pragma unroll
     for (int q = 0; q < NP; ++q)

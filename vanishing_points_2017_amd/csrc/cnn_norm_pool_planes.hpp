@@ -21,7 +21,8 @@ namespace {
 template <int TPH>
 __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
                                                                   unsigned short* __restrict__ out_planes, int C, int H, int W, int PH,
-                                                                  int PW, float alpha, int PHp, int PWp, int opad, int cgroups, float ascale) {
+                                                                  int PW, float alpha, int PHp, int PWp, int opad, int cgroups, float ascale,
+                                                                  unsigned* __restrict__ range_word, unsigned range_bit) {
     constexpr int CB = 8, TR = 2 * TPH + 1, SLOTS = 4, PMAX = 256 * SLOTS;
     __shared__ __attribute__((aligned(16))) float plane[2][CB][PMAX];
     const int tiles_h = (PH + TPH - 1) / TPH;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* _
     const size_t out_pix = (size_t)(ph0 + oy + opad) * PWp + ox + opad;
     const float an = alpha / 5.f;
     int buf = 0;
+    bool bad = false;                                    // a scaled value beyond fp16's range (split2h_guard)
     float nx[CB][SLOTS], nn[CB][SLOTS];                  // raw values of this batch's / the next batch's channels (+2)
     auto fetch = [&](int cb, float (&dst)[CB][SLOTS]) {
         const int cmax = C - 1;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* _
             if (out_planes) {                            // conv3's input: word (channel group of 16, piece x k half, y, x)
                 unsigned short h0_[CB], h1_[CB];
 #pragma unroll
-                for (int k = 0; k < CB; ++k) split2h(m[k] * ascale, h0_[k], h1_[k]);
+                for (int k = 0; k < CB; ++k) split2h_guard(m[k] * ascale, h0_[k], h1_[k], bad);
                 u32x4 a, c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* _
         }
         buf ^= 1;
     }
+    if (out_planes) range_report(bad, range_word, range_bit);
 }
 
 }  // namespace
