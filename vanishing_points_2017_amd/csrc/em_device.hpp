@@ -236,15 +236,16 @@ VPK_DEV void eig3_full(double a00, double a01, double a02, double a11, double a1
 // re-accumulates the scatter IN THE ROTATED BASIS V^T l, where the entries that couple to the small
 // direction are sums of small numbers (no cancellation against the large ones), and applies the
 // Jacobi correction -- an implicit one-sided Jacobi SVD, accurate like LAPACK's after 2-3 passes.
-template <int G, class RowWeight>
+template <int G, int LB = 4, class RowWeight>
 VPK_DEV void group_null_vector(cgdp l, int N, RowWeight rw, double out[3]) {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     double ev[3] = {0, 0, 0};
     for (int pass = 0; pass < 5; ++pass) {
         double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
-        // four lines per step with all their loads issued first: with 16 lanes per VP a lane walks N/16
-        // lines, and one L2 round trip per line was most of the M-step
-        constexpr int LB = 4;
+        // LB = four lines per step with all their loads issued first: with 16 lanes per VP a lane walks N/16
+        // lines, and one L2 round trip per line was most of the M-step.  (Round 6 measured LB = 8 -- same chains, same
+        // bits -- SLOWER: M-step 57.9 -> 60.3 ms of workgroup time per YUD batch; the walk is bound by its divisions
+        // and the eigen-solve, not by loads in flight.)
         for (int n0 = lane() % G; n0 < N; n0 += LB * G) {
             double r[LB], a0[LB], a1[LB], a2[LB];
 #pragma unroll
@@ -1037,6 +1038,82 @@ VPK_DEVFN void estep(EmCtx& c, const double* X) {
     cgdp gmx = c.drow, gmy = c.drow + c.ldn, gvx = c.drow + 2 * (size_t)c.ldn, gvy = c.drow + 3 * (size_t)c.ldn,
          gn2 = c.drow + 4 * (size_t)c.ldn;
     constexpr int EU = 4;
+    // LANES PER LINE (round 6).  One thread per line leaves 512 - N threads idle and the busy ones with M dependent sqrt / div / exp
+    // chains each: at the YUD shape (N ~ 250, M ~ 22) the line part took as long as the smoother's row loops.  When the panel is in
+    // LDS and T N <= 512, T = 2, 4 or 8 ADJACENT lanes share a line, each a contiguous run of ceil(M / T) VPs.  Every (line, VP) value
+    // is the same expression as below; p_l (:116) is still ONE chain over the VPs in ascending order -- lane h takes the running sum
+    // from lane h - 1 and continues it over its own terms, re-read from the line's panel row -- so every output has the same bits.
+    int T = 1;
+    if (panel && WAVE == 64 && c.smoother != 1)              // (vpk_em_set_smoother(1): the forms of the earlier rounds, for the bit-equality test)
+        while (T < 8 && 2 * T * N <= nthreads()) T *= 2;
+    if (T > 1) {
+        const int n_ = tid() / T, h = tid() - n_ * T;
+        const bool on = n_ < N;
+        const int n = on ? n_ : N - 1;
+        const int Mh = (M + T - 1) / T;
+        const int m_lo = on ? (h * Mh < M ? h * Mh : M) : 0, m_hi = on ? (m_lo + Mh < M ? m_lo + Mh : M) : 0;
+        const double lmx = gmx[n], lmy = gmy[n], v2x = gvx[n], v2y = gvy[n], n2 = gn2[n];
+        const double lw = c.lweight[n];
+        gdp lvq = c.lvsq + n, pvq = c.pvl + n;
+        double* wl = wt + (plan == 2 ? (size_t)rs_row(n, rs_jch, rs_S, Wp) : (size_t)n * Wp);
+        int m = m_lo;
+        for (; m + EU <= m_hi; m += EU) {
+            double lv[EU], tt[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const double v1x = lmx - sh.vx[m + u], v1y = lmy - sh.vy[m + u];
+                const double n1 = norm2(v1x, v1y);
+                const double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
+                lv[u] = cc * cc;                             // :174
+            }
+#pragma unroll
+            for (int u = 0; u < EU; ++u)
+                tt[u] = (exp_underflow(-(lv[u] / (2 * sh.s[m + u]))) * sh.k2[m + u]) * sh.pv[m + u];   // calc_plv :137-145
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                lvq[(size_t)(m + u) * c.ldn] = lv[u];
+                wl[m + u] = tt[u];
+            }
+        }
+        for (; m < m_hi; ++m) {
+            const double v1x = lmx - sh.vx[m], v1y = lmy - sh.vy[m];
+            const double n1 = norm2(v1x, v1y);
+            const double cc = 1 - fabs(dot2(v1x, v1y, v2x, v2y) / (n1 * n2));
+            const double lv1 = cc * cc;
+            lvq[(size_t)m * c.ldn] = lv1;
+            wl[m] = (exp_underflow(-(lv1 / (2 * sh.s[m]))) * sh.k2[m]) * sh.pv[m];
+        }
+        double pl = 0.0;                                     // p_l = dot(p_lv, p_v) :116, in VP order, handed from lane to lane
+        for (int hh = 0; hh < T; ++hh) {
+            const double prev = wave_bcast(pl, (lane() + WAVE - 1) & (WAVE - 1));
+            if (h == hh) {
+                if (hh > 0) pl = prev;
+                for (m = m_lo; m < m_hi; ++m) pl += wl[m];
+            }
+        }
+        pl = wave_bcast(pl, lane() | (T - 1));               // the line's last lane holds the whole sum
+        pl = (pl > 1e-12 || is_nan(pl)) ? pl : 1e-12;        // :117
+        m = m_lo;
+        for (; m + EU <= m_hi; m += EU) {
+            double q[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) q[u] = wl[m + u];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) q[u] = q[u] / pl;   // calc_pvl :128
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                pvq[(size_t)(m + u) * c.ldn] = q[u];
+                wl[m + u] = q[u] * lw;                       // weight_matrix :519
+            }
+        }
+        for (; m < m_hi; ++m) {
+            const double q1 = wl[m] / pl;
+            pvq[(size_t)m * c.ldn] = q1;
+            wl[m] = q1 * lw;
+        }
+        if (on && h == T - 1)
+            for (m = M; m < Wp; ++m) wl[m] = 0.0;            // padding of the last VP tile
+    } else
     for (int n = tid(); n < N; n += nthreads()) {
         const double lmx = gmx[n], lmy = gmy[n], v2x = gvx[n], v2y = gvy[n], n2 = gn2[n];
         gdp lvq = c.lvsq + n, pvq = c.pvl + n;
@@ -1855,6 +1932,34 @@ VPK_DEVFN void count_lines(EmCtx& c) {
 // remove the VPs flagged in sh.removed from cur / nxt / s (np.delete along the VP axis)
 VPK_DEVFN void compact_vps(EmCtx& c) {
     Shared& sh = SH();
+    static_assert(MAXM <= 64, "compact_vps: one lane per hypothesis");
+    if (WAVE == 64 && c.smoother != 1) {
+        // MAXM = 64 hypotheses = the lanes of one wave: lane m keeps its VP's values in registers, a ballot of the survivors gives
+        // every survivor its new index (popcount of the survivors below it), and the common case -- nothing removed, every
+        // iteration of a settled image -- writes nothing at all.  (One thread walking the list cost ~2 us per call.)
+        if (wave_id() == 0) {
+            const int M = sh.M, m = lane();
+            const bool keep = m < M && !sh.removed[m];
+            const unsigned long long km = wave_ballot(keep);
+            const int kept = popcount64(km);
+            if (kept != M) {
+                double v[7];
+                if (keep) {
+                    for (int d = 0; d < 3; ++d) { v[d] = sh.cur[3 * m + d]; v[3 + d] = sh.nxt[3 * m + d]; }
+                    v[6] = sh.s[m];
+                }
+                wave_lds_order();
+                const int k = popcount64(km & lanes_below());
+                if (keep && k != m) {
+                    for (int d = 0; d < 3; ++d) { sh.cur[3 * k + d] = v[d]; sh.nxt[3 * k + d] = v[3 + d]; }
+                    sh.s[k] = v[6];
+                }
+                if (m == 0) sh.M = kept;
+            }
+        }
+        block_sync();
+        return;
+    }
     if (tid() == 0) {
         int k = 0;
         for (int m = 0; m < sh.M; ++m) {
