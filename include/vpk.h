@@ -102,7 +102,10 @@ int vpk_em_set_workgroups(vpk_handle* h, int max_workgroups);
  * p_vl * lweight is exactly zero -- more than four in five -- are left out; a wave per group of VPs, lsim staged through
  * LDS by DMA once per call; measured slower than the dense kernel, kept as an option).  All of them sum every (column,
  * VP) in the same order, so every output of vpk_em_batch / vpk_weight_matrix is bit-identical under the three settings
- * (tests/test_gpu_em.py): the switch exists for that test and for A/B timing. */
+ * (tests/test_gpu_em.py): the switch exists for that test and for A/B timing.  Mode 1 also selects the earlier forms of the
+ * other phases that have been rebuilt with the same arithmetic since (round 6: the E-step's one thread per line, the serial
+ * VP compaction, the row-by-row pair pass of calc_lsim for images of 512 lines and more, the M-step's four loads in flight
+ * there; vpk_pairwise honours it too) -- the same test therefore pins those rebuilds bit for bit. */
 int vpk_em_set_smoother(vpk_handle* h, int mode);
 /* LDS the EM workgroup may plan with for its weight_matrix operand panel and the split's cluster matrix, in doubles;
  * 0 (default) = everything a CU has beside the workgroup's state (~18 800).  A smaller budget sends images down the

@@ -337,6 +337,21 @@ def test_row_sliced_smoother_gives_the_bits_of_the_round2_kernels():
     assert ok >= 112
 
 
+@pytest.mark.parametrize("n", [511, 512, 513, 700, 1000, 1023, 1200])
+def test_tiled_pair_pass_gives_the_bits_of_the_row_by_row_pass(n):
+    """calc_lsim + line_rating_knn for images of 512 lines and more (round 6): pass 1 walks tiles of 16 rows x 64 columns so that a
+    mirrored 128-byte line is written whole by one wave (em_device.hpp: pairwise_tiles).  Same pair function, same positions:
+    lsim, the kNN score and the line angles must equal the row-by-row pass (vpk_em_set_smoother(1)) bit for bit; 511 lines
+    take the row-by-row pass under both settings."""
+    from vanishing_points_2017_amd import kernels, synth
+    sc = synth.make_scene(4400 + n, n, 5)
+    new = _with_smoother(0, lambda: kernels.pairwise(sc["lp"]))
+    old = _with_smoother(1, lambda: kernels.pairwise(sc["lp"]))
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b)
+    assert np.array_equal(new[0], new[0].T)
+
+
 @pytest.mark.parametrize("n,m", [(100, 25), (245, 22), (380, 24), (400, 32), (64, 3), (65, 9), (9, 2), (500, 17),
                                  (900, 8), (1000, 8), (1100, 8), (700, 30), (1100, 20), (1500, 12), (1700, 9), (1800, 8), (600, 40)])
 def test_weight_matrix_row_sliced_vs_round2_vs_numpy(n, m):

@@ -457,11 +457,83 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 // row in the order the one-pass version did (so rowsum keeps its bits) and rates the line from its distance row.
 // The pair functions are symmetric bit for bit (tests/test_gpu_em.py asserts lsim == lsim.T), so nothing moves.
 // Without weights only the distances matter and the one-pass version below runs (every ordered pair, no matrix).
+//
+// LARGE images (N >= PW_TILED_MIN; round 6): pass 1 walks TILES of 16 rows x 64 columns instead of whole rows.  Row by row, the mirrored
+// store (j, i) of a row's pairs touches N different 128-byte lines with 8 bytes each, and the other 15 entries of such a line arrive with
+// the next 15 rows -- other waves, tens of microseconds later.  At N = 1000 that is 128 KB of partially written lines in flight per
+// row, 256 workgroups share 32 MB of L2, the lines are evicted half-written and written again: profiles/r05_pmc_traffic.json counts
+// 25.8 GB of HBM writes per 512-image stress launch against 7.6 GB algorithmic (DESIGN r5 blamed the smoother's partials,
+// which N = 1000 does not have).  In a tile, one wave writes all 16 entries of a line within 16 consecutive pairs, the line is complete
+// before it can be evicted, and the geometry of column j's line is computed once per 16 pairs instead of once per pair.  Same pair
+// function, same argument order, same positions: every byte of lsim / pdist is the row-by-row version's (tests/test_gpu_em.py).
+constexpr int PW_TILED_MIN = 512;
+constexpr int PW_RB = 16;                                      // rows of a tile
+VPK_DEV void pairwise_tiles(EmCtx& c) {
+    const int N = c.N;
+    double* gs = SCRATCH() + wave_id() * (PW_RB * 10);          // this wave's 16 row geometries (LineGeom = 10 doubles)
+    static_assert(8 * PW_RB * 10 <= PART_DOUBLES, "row geometries of eight waves in the setup scratch");
+    const int nb = (N + PW_RB - 1) / PW_RB;
+    int t = 0;
+    for (int I = 0; I < nb; ++I) {
+        const int i0 = I * PW_RB;
+        const int ilast = (i0 + PW_RB < N ? i0 + PW_RB : N) - 1;    // the block's last row; its pairs are the columns j < ilast
+        const int nch = (ilast + WAVE - 1) / WAVE;
+        for (int jc = 0; jc < nch; ++jc, ++t) {
+            if (t % nwaves() != wave_id()) continue;            // tiles are dealt to the waves in turn
+            if (lane() < PW_RB) {
+                const int i = i0 + lane() < N ? i0 + lane() : N - 1;
+                double a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = c.lp[4 * (size_t)i + q];
+                const LineGeom g = line_geom(a);
+                double* o = gs + lane() * 10;
+                o[0] = g.x1; o[1] = g.y1; o[2] = g.x2; o[3] = g.y2; o[4] = g.dx; o[5] = g.dy; o[6] = g.nn; o[7] = g.vx; o[8] = g.vy; o[9] = g.nv;
+            }
+            wave_lds_order();
+            const int j = jc * WAVE + lane();
+            const int jj = j < N ? j : N - 1;
+            double b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = c.lp[4 * (size_t)jj + q];
+            const LineGeom gb = line_geom(b);
+            auto row_geom = [&](int r) {
+                const double* o = gs + r * 10;
+                LineGeom g;
+                g.x1 = o[0]; g.y1 = o[1]; g.x2 = o[2]; g.y2 = o[3]; g.dx = o[4]; g.dy = o[5]; g.nn = o[6]; g.vx = o[7]; g.vy = o[8]; g.nv = o[9];
+                return g;
+            };
+            auto put = [&](int i, double d, double sim) {      // pair (i, j), j < i: both halves of the symmetric matrices
+                if (!(j < i && i < N)) return;
+                c.lsim[(size_t)i * c.ld + j] = sim;
+                c.lsim[(size_t)j * c.ld + i] = sim;
+                c.pdist[(size_t)i * c.ld + j] = d;
+                c.pdist[(size_t)j * c.ld + i] = d;
+            };
+            for (int r = 0; r < PW_RB; r += 2) {                // two independent pairs per trip (see the row-by-row loop)
+                const LineGeom g0 = row_geom(r), g1 = row_geom(r + 1);
+                const double d0 = line_distance_closest(g0, gb);
+                const double d1 = line_distance_closest(g1, gb);
+                const double s0 = lines_cosangle(g0, gb, 9.0) * proximity(d0, g0.nv, gb.nv, 1.0);
+                const double s1 = lines_cosangle(g1, gb, 9.0) * proximity(d1, g1.nv, gb.nv, 1.0);
+                put(i0 + r, d0, s0);
+                put(i0 + r + 1, d1, s1);
+            }
+            wave_lds_order();                                   // (the next tile overwrites the row geometries)
+        }
+    }
+    for (int i = tid(); i < N; i += nthreads()) {
+        c.lsim[(size_t)i * c.ld + i] = 0.0;                     // :104 (the row's own entry stays 0)
+        c.pdist[(size_t)i * c.ld + i] = 4.0;                    // :82
+    }
+}
+
 VPK_DEVFN void pairwise_setup(EmCtx& c, bool want_lsim) {
     const int N = c.N;
     if (want_lsim) {
         // Row i has i pairs and row N - 1 - i has N - 1 - i: a wave takes the two together, N - 1 pairs for every
         // wave (whole trips of 2 x 64 pairs; row by row the short rows leave most lanes idle at N ~ 100..400).
+        if (N >= PW_TILED_MIN && WAVE == 64 && c.smoother != 1) pairwise_tiles(c);
+        else
         for (int r = wave_id(); 2 * r < N; r += nwaves()) {
             const int i0 = r, i1 = N - 1 - r;                      // i0 <= i1
             const int len = i0 == i1 ? i0 : i0 + i1;
@@ -1984,7 +2056,12 @@ VPK_DEVFN void compact_vps(EmCtx& c) {
 // One group of VPG lanes per VP (four VPs per wave: the serial 3x3 eigen-solves of four VPs then run in
 // the lanes of one wave instead of four waves' worth of rounds).  mode 0: soft (all lines, weights w[m]); mode 1: hard (lines with
 // assoc == m, :353-392).  On return sh.removed[] / sh.err[] are set; nxt and s updated.
-VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
+// LB = lines whose loads are in flight per lane (group_null_vector).  Four at the sizes whose arrays live in L2 (measured: eight is slower
+// there); large images (N >= 512: ECD / HLW / the stress shape) walk N / 16 >= 32 lines per lane through arrays that come from HBM beside
+// 255 other workgroups' lsim streams -- there the walk is a chain of memory round trips (73 us per M-step at the stress shape, 42 alone)
+// and twice the loads in flight halve it.  Same lines in the same order per lane: same bits.
+template <int LB>
+VPK_DEVFN void mstep_lb(EmCtx& c, int mode, double max_stdd) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
     constexpr int G = VPG;
@@ -1997,7 +2074,6 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         double sv = 0, sp = 0;
         cgdp lvs = c.lvsq + (size_t)m * c.ldn;
         cgdp pvl = c.pvl + (size_t)m * c.ldn;
-        constexpr int LB = 4;                                 // loads of four lines in flight (see group_null_vector)
         for (int n0 = gl; n0 < N; n0 += LB * G) {
             double pq[LB], lq[LB], wq[LB];
             int aq[LB];
@@ -2034,7 +2110,7 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         if (valid && nsel > 1) {
             const VPK_GLOBAL int* assoc = c.assoc;
             // row weight w / max w (:462; hard mode: :358 then / 1 at :462)
-            group_null_vector<G>(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
+            group_null_vector<G, LB>(c.l, N, [=](int n) { return (mode == 1 && assoc[n] != m) ? 0.0 : wm[n] / wmax; }, vp);
         }
         if (gl == 0) {
             int rem = 0;
@@ -2069,6 +2145,10 @@ VPK_DEVFN void mstep(EmCtx& c, int mode, double max_stdd) {
         }
     }
     block_sync();
+}
+
+VPK_DEV void mstep(EmCtx& c, int mode, double max_stdd) {
+    if (c.N >= 512 && c.smoother != 1) mstep_lb<8>(c, mode, max_stdd); else mstep_lb<4>(c, mode, max_stdd);
 }
 
 // max over the per-VP errors with np.maximum semantics (NaN sticks); VPs without an error are -1

@@ -286,9 +286,9 @@ __global__ void em_rotate_kernel(int* ctr, int cap_waiting, int cap_started) {
 // ---- fine-grained kernels (one workgroup, unit parity) ------------------------------------------
 __global__ __launch_bounds__(EM_BOUND) void pairwise_kernel(int n, const double* lp, EmLayout L, double* ws,
                                                               double* lsim_out, double* lscore_out,
-                                                              double* langle_out) {
+                                                              double* langle_out, int smoother) {
     EmCtx c;
-    c.N = n; c.lp = (cgdp)lp; c.wt_doubles = WT_DOUBLES;
+    c.N = n; c.lp = (cgdp)lp; c.wt_doubles = WT_DOUBLES; c.smoother = smoother;
     c.prm.use_weights = 1;
     bind_scratch(c, ws, L, false);
     pairwise_setup(c, true);
@@ -781,7 +781,7 @@ int vpk_pairwise(vpk_handle* h, int n, const double* lp, double* lsim_out, doubl
     int rc = vpk_reserve(h, &h->small_ws, &h->small_ws_bytes, L.total_doubles * 8, "hipMalloc(workspace)");
     if (rc) return rc;
     hipLaunchKernelGGL(pairwise_kernel, dim3(1), dim3(EM_THREADS), EM_LDS_BYTES, h->stream, n, lp, L, (double*)h->small_ws,
-                       lsim_out, lscore_out, langle_out);
+                       lsim_out, lscore_out, langle_out, h->em_smoother);
     VPK_HIP(h, hipGetLastError());
     return VPK_OK;
 }
