@@ -4,7 +4,7 @@
 # Summaries land in gpurun_out/prof/summary (copy them to profiles/).   ROUND=r03 bash scripts/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/prof
-N=${ROUND:-r05}
+N=${ROUND:-r06}
 rm -rf $R; mkdir -p $R/summary
 BENCH="python3 bench.py --workload yud --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/yud_trace -o t -- $BENCH > $R/yud_trace.log 2>&1

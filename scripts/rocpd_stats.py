@@ -22,9 +22,22 @@ def main(db, out, skip_passes=0, passes=0):
         for name, start, dur in cur.execute("select s.%s, d.start, d.end - d.start from %s d join %s s on d.kernel_id = s.id "
                                             "order by d.start" % (name_col, disp, sym)):
             per.setdefault(name, []).append((start, dur))
-        # the kept part of the trace starts with the first kept dispatch of a kernel of the repeated pass: what ran before it (model
-        # load: weight re-packing, the calibration forwards of vpk_cnn_load, warm-up passes) is dropped for every kernel
-        t_keep = min(v[len(v) // passes * skip_passes][0] for v in per.values() if len(v) % passes == 0 and len(v) >= passes)
+        # What ran before the repeated passes -- the model load: weight re-packing and the calibration forwards of vpk_cnn_load, which
+        # use kernels of the passes too (round 6: each calibration forward ends with absmax_kernel) -- is cut off first: everything up
+        # to the last dispatch of a load-only kernel.  After that every kernel's dispatch count is a multiple of `passes`, and the
+        # kept part starts with the first kept dispatch of any of them.  (Round 5's rule -- counts over the WHOLE trace -- found no
+        # kernel whose count was a multiple under VPK_ALGORITHM=0 and wrote an empty summary: ADVICE r5.)
+        load_only = ("pack_weights_kernel", "dense_tile_weights_kernel", "absmax_kernel")
+        t_load = max([st for name, v in per.items() if any(k in name for k in load_only) for (st, _) in v] or [-1])
+        starts = []
+        for name, v in per.items():
+            after = [st for (st, _) in v if st > t_load]
+            if after and len(after) % passes == 0:
+                starts.append(after[len(after) // passes * skip_passes])
+        if not starts:
+            raise SystemExit("rocpd_stats: no kernel with a dispatch count that is a multiple of %d after the model load -- "
+                             "wrong --passes, or the trace is not one of repeated passes" % passes)
+        t_keep = min(starts)
         rows = []
         for name, v in per.items():
             durs = [d for (st, d) in v if st >= t_keep]
