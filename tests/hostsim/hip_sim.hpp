@@ -60,6 +60,7 @@ VPK_DEV int wave_bcast_int(int v, int) { return v; }
 template <int C> VPK_DEV void load_cols(cgdp p, double (&out)[C]) {
     for (int q = 0; q < C; ++q) out[q] = p[q];
 }
+VPK_DEV void store_cols2(gdp p, double a, double b) { p[0] = a; p[1] = b; }
 VPK_DEV void sched_fence() {}
 // never executed with one lane (the row-sliced smoother needs a 64-lane wave); present so that the source compiles
 template <int BASE> VPK_DEV void fmac8_row_bcast(double* a, double op, double b) { for (int q = 0; q < 8; ++q) a[q] = fma(op, b, a[q]); }

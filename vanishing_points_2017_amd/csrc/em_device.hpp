@@ -466,12 +466,21 @@ VPK_DEVFN void normalise_lines(EmCtx& c) {
 // which N = 1000 does not have).  In a tile, one wave writes all 16 entries of a line within 16 consecutive pairs, the line is complete
 // before it can be evicted, and the geometry of column j's line is computed once per 16 pairs instead of once per pair.  Same pair
 // function, same argument order, same positions: every byte of lsim / pdist is the row-by-row version's (tests/test_gpu_em.py).
+// The mirrored half of an interior tile goes through a wave-private LDS transpose: lane L then stores 16 bytes of row j = 8 q + L / 8 at
+// columns i0 + 2 (L % 8) -- eight rows x 128 contiguous bytes per store instruction, whole lines like the direct half.  (Measured with the
+// mirrored entries as 8-byte stores, 64 rows per instruction: the set-up of 256 stress images wrote 11.1 GB where the matrices are
+// 4.1 GB -- profiles/r06_pmc_em_traffic.txt -- the L2 writes such sectors out more than once.)
 constexpr int PW_TILED_MIN = 512;
 constexpr int PW_RB = 16;                                      // rows of a tile
+constexpr int PW_TLD = WAVE + 1;                               // row stride of the transpose buffers (doubles)
+constexpr int PW_TBUF = 2 * PW_RB * PW_TLD;                    // per wave: similarity and distance tiles
 VPK_DEV void pairwise_tiles(EmCtx& c) {
     const int N = c.N;
     double* gs = SCRATCH() + wave_id() * (PW_RB * 10);          // this wave's 16 row geometries (LineGeom = 10 doubles)
     static_assert(8 * PW_RB * 10 <= PART_DOUBLES, "row geometries of eight waves in the setup scratch");
+    // the transpose buffers lie behind the setup scratch, if the launch's LDS has room for them (the whole-CU configuration has)
+    const bool tbuf_ok = WAVE == 64 && PART_DOUBLES + nwaves() * PW_TBUF <= c.wt_doubles;
+    double* tb = SCRATCH() + PART_DOUBLES + wave_id() * PW_TBUF;
     const int nb = (N + PW_RB - 1) / PW_RB;
     int t = 0;
     for (int I = 0; I < nb; ++I) {
@@ -509,16 +518,36 @@ VPK_DEV void pairwise_tiles(EmCtx& c) {
                 c.pdist[(size_t)i * c.ld + j] = d;
                 c.pdist[(size_t)j * c.ld + i] = d;
             };
+            // interior tile: every column of the chunk lies in front of the block's first row and every row exists
+            const bool interior = tbuf_ok && jc * WAVE + WAVE - 1 < i0 && i0 + PW_RB <= N;
             for (int r = 0; r < PW_RB; r += 2) {                // two independent pairs per trip (see the row-by-row loop)
                 const LineGeom g0 = row_geom(r), g1 = row_geom(r + 1);
                 const double d0 = line_distance_closest(g0, gb);
                 const double d1 = line_distance_closest(g1, gb);
                 const double s0 = lines_cosangle(g0, gb, 9.0) * proximity(d0, g0.nv, gb.nv, 1.0);
                 const double s1 = lines_cosangle(g1, gb, 9.0) * proximity(d1, g1.nv, gb.nv, 1.0);
-                put(i0 + r, d0, s0);
-                put(i0 + r + 1, d1, s1);
+                if (interior) {
+                    c.lsim[(size_t)(i0 + r) * c.ld + j] = s0;   c.pdist[(size_t)(i0 + r) * c.ld + j] = d0;
+                    c.lsim[(size_t)(i0 + r + 1) * c.ld + j] = s1; c.pdist[(size_t)(i0 + r + 1) * c.ld + j] = d1;
+                    tb[r * PW_TLD + lane()] = s0;               tb[(PW_RB + r) * PW_TLD + lane()] = d0;
+                    tb[(r + 1) * PW_TLD + lane()] = s1;         tb[(PW_RB + r + 1) * PW_TLD + lane()] = d1;
+                } else {
+                    put(i0 + r, d0, s0);
+                    put(i0 + r + 1, d1, s1);
+                }
             }
             wave_lds_order();                                   // (the next tile overwrites the row geometries)
+            if (interior) {
+                const int cp = lane() & 7, jr = lane() >> 3;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int jl = 8 * q + jr;                  // column of the tile = row of the mirrored entries
+                    const size_t at = (size_t)(jc * WAVE + jl) * c.ld + i0 + 2 * cp;
+                    store_cols2(c.lsim + at, tb[(2 * cp) * PW_TLD + jl], tb[(2 * cp + 1) * PW_TLD + jl]);
+                    store_cols2(c.pdist + at, tb[(PW_RB + 2 * cp) * PW_TLD + jl], tb[(PW_RB + 2 * cp + 1) * PW_TLD + jl]);
+                }
+                wave_lds_order();
+            }
         }
     }
     for (int i = tid(); i < N; i += nthreads()) {
@@ -1054,6 +1083,9 @@ VPK_DEV int smooth_plan(const EmCtx& c, int M) {
 // E-step: calc_probabilities (probability_functions.py:99-147, "angle" branch)
 // ---------------------------------------------------------------------------------------------
 // X points at sh.cur or sh.nxt.  Writes lvsq[m][n], pvl[m][n], wsrc[n][m]; floors sh.s (:139).
+// (Round 6, measured: the body inlined into em_run's main loop -- to save the callee-saved register traffic of one call per iteration,
+//  which did pay for the smoother's thin wrappers -- makes the E-step 2.5 x SLOWER, 51 -> 130 ms of workgroup time per YUD batch: inside
+//  em_run's register allocation the line loop spills.  The phases stay functions of their own.)
 VPK_DEVFN void estep(EmCtx& c, const double* X) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
@@ -1904,13 +1936,15 @@ VPK_DEVFN void smooth_sparse_any(EmCtx& c, int m0) {
     }
 }
 
-VPK_DEVFN void smooth_dispatch(EmCtx& c);
-VPK_DEVFN void smooth(EmCtx& c) {
+// (smooth and smooth_dispatch are inlined into their callers: as functions of their own they cost two more levels of callee-saved
+//  register saves and restores -- scratch memory, i.e. HBM round trips at the stress shape -- per E-step for a chain of ifs)
+VPK_DEV void smooth_dispatch(EmCtx& c);
+VPK_DEV void smooth(EmCtx& c) {
     smooth_dispatch(c);
     if (tid() == 0) SH().ibuf[5] = 0;               // the E-step's panel is valid for one smoothing only
     block_sync();
 }
-VPK_DEVFN void smooth_dispatch(EmCtx& c) {
+VPK_DEV void smooth_dispatch(EmCtx& c) {
     Shared& sh = SH();
     const int M = sh.M, N = c.N;
     if (!c.prm.use_weights) {   // lsim == 0 and lweight == 1 (:180,:235): w = p_vl

@@ -167,6 +167,13 @@ template <> VPK_DEV void load_cols<2>(cgdp p, double (&out)[2]) {
     out[1] = v.y;
 }
 
+// two adjacent doubles as one 16-byte store (p must be 16-byte aligned)
+VPK_DEV void store_cols2(gdp p, double a, double b) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t v = {a, b};
+    *reinterpret_cast<VPK_GLOBAL d2_t*>(p) = v;                     // one global_store_dwordx4
+}
+
 // scheduling fence: the compiler may not move instructions across it (keeps the unrolled rows of the
 // smoother from hoisting all their LDS operand reads to the top and spilling)
 VPK_DEV void sched_fence() {
