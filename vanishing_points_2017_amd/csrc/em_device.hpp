@@ -2036,7 +2036,7 @@ VPK_DEVFN void count_lines(EmCtx& c) {
 }
 
 // remove the VPs flagged in sh.removed from cur / nxt / s (np.delete along the VP axis)
-VPK_DEVFN void compact_vps(EmCtx& c) {
+VPK_DEV void compact_vps(EmCtx& c) {
     Shared& sh = SH();
     static_assert(MAXM <= 64, "compact_vps: one lane per hypothesis");
     if (WAVE == 64 && c.smoother != 1) {
