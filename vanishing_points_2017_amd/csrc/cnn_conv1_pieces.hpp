@@ -98,7 +98,9 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
                                                                       const unsigned short* __restrict__ wfrag,
                                                                       const float* __restrict__ cmap, float* __restrict__ out,
                                                                       int OHp, int OWp, int opad, int batch, int group, float oscale,
-                                                                      int* __restrict__ item_counter, int total_items) {
+                                                                      int* __restrict__ item_counter, int total_items,
+                                                                      unsigned short* __restrict__ out_planes, float p_ascale,
+                                                                      unsigned* __restrict__ range_word) {
     __shared__ __attribute__((aligned(16))) unsigned short Xs[2][C1B_XS];
     __shared__ __attribute__((aligned(16))) float Cs[96 + 4][C1D_LD];     // channel c in row c + 2; rows 0, 1, 98, 99 stay 0 (LRN halo)
     __shared__ int s_next[2];
@@ -149,6 +151,14 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
     const bool pool_on = tid < 96 * C1_QR * 2;                           // pooling: (channel, pooled row, half of its 8 outputs)
     const int pk = pool_on ? tid / (C1_QR * 2) : 95, prem = tid % (C1_QR * 2), ppy = prem >> 1, phalf = prem & 1;
     const float* pool_src = &Cs[pk + 2][2 * ppy * C1_PC + 8 * phalf];
+    // pooling straight into conv2's piece planes (round 6; out_planes != nullptr): thread t < 24 x 24 owns one pooled PIXEL of the patch
+    // and FOUR channels = half of a 16-byte word -- [image][channel group of 16][piece x k half][y][x], cnn_conv_pieces.hpp -- as scaled
+    // fp16 pairs (split2h_guard: clamped, flagged): 8-byte stores that two threads complete to a word (as the conv epilogues do); the f32
+    // pool1 blob and to_planes_kernel's pass over it are not needed then
+    const bool pl_on = tid < 24 * C1_QR * C1_QC;
+    const int pl_g = pl_on ? tid / (C1_QR * C1_QC) : 0, pl_pix = tid % (C1_QR * C1_QC), pl_y = pl_pix / C1_QC, pl_x = pl_pix % C1_QC;
+    const float* pl_src = &Cs[4 * pl_g + 2][2 * pl_y * C1_PC + 2 * pl_x];
+    bool pl_bad = false;
 
     int item = blockIdx.x, parity = 0, buf = 0;
     if (item >= total_items) return;
@@ -265,6 +275,31 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         if (n_fresh && tid == 0 && n_on) s_next[parity ^ 1] = atomicAdd(item_counter, 1) + (int)gridDim.x;
         lds_barrier();
         // ---- 3 x 3 / stride 2 max pool: (channel, pooled row, half) = 4 outputs from 3 x 9 values ----
+        if (out_planes) {
+            if (pl_on) {
+                const int ph = C1_QR * pr + pl_y, pw = C1_QC * pc + pl_x;
+                unsigned short h0[4], h1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* w0 = pl_src + k * C1D_LD;
+                    float m = 0.f;                                   // (every value is >= 0: ReLU, then a positive factor)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+                        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(w0[dy * C1_PC], w0[dy * C1_PC + 1]), w0[dy * C1_PC + 2]));
+                    split2h_guard(m * p_ascale, h0[k], h1[k], pl_bad);
+                }
+                if (ph < C1_POOL && pw < C1_POOL) {
+                    const u32x2 a = {(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
+                    const u32x2 c = {(unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16)};
+                    const size_t wpl = (size_t)OHp * OWp;
+                    const int cg8 = pl_g >> 1;                       // the word's eight channels; this thread: its half pl_g & 1
+                    u32x2* dst = reinterpret_cast<u32x2*>(reinterpret_cast<u32x4*>(out_planes) + (((size_t)b * 6 + (cg8 >> 1)) * 4 + (cg8 & 1)) * wpl +
+                                                          (size_t)(ph + opad) * OWp + pw + opad) + (pl_g & 1);
+                    dst[0] = a;                                      // piece 0, this k half
+                    dst[4 * wpl] = c;                                // piece 1 (2 planes x 2 halves of a word further)
+                }
+            }
+        } else
         if (pool_on) {
             float cm[9];
 #pragma unroll
@@ -283,6 +318,7 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         item = n_item; pr = n_pr; pc = n_pc; b = n_b; b1 = n_b1; fresh = n_fresh;
         buf ^= 1;
     }
+    if (out_planes) range_report(pl_bad, range_word, 1u << 1);         // (conv2 is the consuming layer)
 }
 
 }  // namespace

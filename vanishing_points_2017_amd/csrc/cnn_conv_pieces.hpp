@@ -76,28 +76,7 @@ struct PieceDims {
 //   * the epilogue multiplies by the exact reciprocal of both.
 // Whether a layer may use this is decided by MEASUREMENT against the float64 net (tests/test_gpu_cnn.py: no further from it than the
 // f32 direct kernels, at every tap, also for nets whose blobs are 128 x larger / smaller than the synthetic net's).
-constexpr float CP_DEFAULT_ASCALE = 0.125f;
-
-__device__ __forceinline__ void split2h(float x, unsigned short& h0, unsigned short& h1) {
-    const _Float16 a = (_Float16)x;
-    const _Float16 b = (_Float16)(x - (float)a);
-    h0 = __builtin_bit_cast(unsigned short, a);
-    h1 = __builtin_bit_cast(unsigned short, b);
-}
-
-// The GUARDED split every activation writer uses (round 6).  fp16's largest finite number is 65 504: a scaled activation beyond it would
-// become h0 = inf, h1 = x - inf = -inf and the next layer's products NaN -- silently.  Instead the value is clamped to +-65 504 (NaN too:
-// fmax / fmin return the other operand) and `bad` remembers it; the kernel ORs the consuming layer's bit into the handle's range word
-// (range_report), which vpk_cnn_range_flags reads: a net whose activations leave the calibrated range is an ERROR the caller sees
-// (VPK_ERR_RANGE), never a response map of NaNs.  Cost: a compare, a scalar OR and a v_med3 per stored value, in the epilogues only.
-constexpr float CP_H_MAX = 65504.f;
-__device__ __forceinline__ void split2h_guard(float x, unsigned short& h0, unsigned short& h1, bool& bad) {
-    bad |= !(__builtin_fabsf(x) < CP_H_MAX);
-    split2h(__builtin_fminf(__builtin_fmaxf(x, -CP_H_MAX), CP_H_MAX), h0, h1);
-}
-__device__ __forceinline__ void range_report(bool bad, unsigned* __restrict__ range_word, unsigned bit) {
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(range_word, bit);
-}
+// (CP_DEFAULT_ASCALE, split2h, split2h_guard, range_report: cnn_pairs.hpp -- conv1's pooling stage writes pairs too)
 
 // f32 NCHW planes (with their zero border) -> piece planes: [image][channel group of 16][piece x k half (2 NP)][y][x] 16-byte words
 // (8 values = the B operand of one lane for one pixel).  NP = 3: bf16 triples; NP = 2: fp16 pairs of ascale x.  One workgroup

@@ -954,6 +954,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 #include "cnn_split_gemm.hpp"
+#include "cnn_pairs.hpp"
 #include "cnn_conv1_pieces.hpp"
 #include "cnn_conv_pieces.hpp"
 #include "cnn_norm_pool_planes.hpp"
@@ -1169,6 +1170,8 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
     int rc;
     mark();
 
+    // (conv1's fused kernel on pieces hands conv2 its input planes when conv2 runs on fp16 pairs and nobody asks for pool1)
+    const bool conv1_hands_planes = S->precision == 0 && S->algorithm == 4 && S->fuse_conv1 >= 3 && tap != 0 && tap != 1;
     // conv1 + relu1: uint8 raster - mean -> fp32 (pre-pass), then the DMA kernel
     const bool direct = !(tap == 0 || !S->fuse_conv1) && S->fuse_conv1 != 2;   // conv1_direct_kernel reads the rasters itself
     if (!direct)
@@ -1189,12 +1192,16 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         if (S->fuse_conv1 >= 3) {                         // exact bf16 pieces (3) / scaled fp16 pairs (4) on the matrix cores (cnn_conv1_pieces.hpp)
             const int group = S->conv1_group;
             const int total = C1B_PATCHES * ((batch + group - 1) / group);
+            // fp16 pairs downstream and pool1 not tapped: the pooling stage writes conv2's piece planes itself (no f32 pool1 blob)
+            unsigned short* c2planes = conv1_hands_planes ? reinterpret_cast<unsigned short*>(R[R_P6_2]) : nullptr;
             if (S->fuse_conv1 == 4)
                 hipLaunchKernelGGL(conv1_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
-                                   S->L[0].c1half, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f / S->L[0].c1scale, ctr + 0, total);
+                                   S->L[0].c1half, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f / S->L[0].c1scale, ctr + 0, total,
+                                   c2planes, S->L[1].ascale, S->range_word);
             else
                 hipLaunchKernelGGL(conv1_pieces_kernel<3>, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
-                                   S->L[0].c1frag, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f, ctr + 0, total);
+                                   S->L[0].c1frag, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f, ctr + 0, total,
+                                   c2planes, S->L[1].ascale, S->range_word);
         } else if (S->fuse_conv1 == 2) {                  // the implicit-GEMM kernel with the fused epilogue (kept for comparison)
             ConvDims df = dims(0);
             df.N = batch * C1_TR * C1_TC * 128;           // one 128-column tile per patch
@@ -1299,7 +1306,7 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
         if (S->precision == 1) return conv_split(li, src, nullptr, dst, false);
         launch_dma(h, conv_gemm_dma_kernel<2, 2, 2, 2, false>, dims(li), 128, src, S->L[li], dst, 1, ctr + li);
     };
-    if (pieces) { to_p6(R[R_POOL1], p6_2, 96, 65, 65, 1); conv_pieces(1, p6_2, R[R_CONV2]); }
+    if (pieces) { if (!conv1_hands_planes) to_p6(R[R_POOL1], p6_2, 96, 65, 65, 1); conv_pieces(1, p6_2, R[R_CONV2]); }
     else conv_main(1, R[R_POOL1], R[R_CONV2]);
     mark();
     if ((rc = tapcopy(2, R[R_CONV2], A_CONV2))) return rc;
