@@ -981,6 +981,7 @@ struct Layer {
     Wino5Dims wd5;
     PieceDims pd;               // conv2..5 on exact bf16 pieces from an LDS-resident patch (cnn_conv_pieces.hpp)
     float* wraw = nullptr;      // fc6, fc7: the f32 weights in tile order (dense_tile_weights_kernel), streamed by dense_pieces_kernel (cnn_dense_pieces.hpp)
+    unsigned short* wpair = nullptr;   // fc6, fc7: the same weights as scaled fp16 pairs in A-fragment order (dense_pair_weights_kernel): the default's stream
 };
 
 int ceil_pool(int in, int k, int s) { return (in - k + s - 1) / s + 1; }
@@ -1007,6 +1008,7 @@ struct vpk_cnn_state {
     int fuse_conv1 = 3;      // conv1 + norm1 + pool1 as one kernel (vpk_cnn_set_fusion): 0 = separate kernels, 1 = direct f32,
                              // 2 = GEMM-fused, 3 (default) = direct on the bf16 matrix cores with exact operands
     int conv1_group = 4;     // images per work item of conv1_pieces_kernel (VPK_CONV1_GROUP: development knob)
+    int dense_presplit = 1;  // fc6 / fc7 on fp16 pairs: stream the pre-split fragments (VPK_DENSE_PRESPLIT=0: split the f32 stream in registers, round 5)
     bool profiling = false;
     static constexpr int EV_RING = 64;   // event sets of the last 64 profiled passes (vpk_cnn_mean_layer_ms)
     hipEvent_t ev[EV_RING][14] = {};
@@ -1028,6 +1030,7 @@ void vpk_cnn_free(vpk_handle* h) {
         if (l.c1half) (void)hipFree(l.c1half);
         if (l.c1map) (void)hipFree(l.c1map);
         if (l.wraw) (void)hipFree(l.wraw);
+        if (l.wpair) (void)hipFree(l.wpair);
     }
     if (h->cnn->mean) (void)hipFree(h->cnn->mean);
     if (h->cnn->act) (void)hipFree(h->cnn->act);
@@ -1378,6 +1381,10 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
             if (halves) {
                 hipLaunchKernelGGL(dense_split_kernel<2>, dim3((unsigned)dd.chunks, (unsigned)dd.ntiles), dim3(256), 0, st, fc_in, S->xfrag, batch,
                                    d.K, dd.chunks, S->L[li].ascale, S->range_word, 1u << li);
+                if (S->dense_presplit)
+                    hipLaunchKernelGGL(dense_pairs_kernel, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wpair,
+                                       S->xfrag, R[R_PART], ctr + li, total);
+                else
                 hipLaunchKernelGGL(dense_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(DP_THREADS), 0, st, dd, S->L[li].wraw,
                                    S->xfrag, R[R_PART], ctr + li, total);
             } else {
@@ -1645,12 +1652,18 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             hipLaunchKernelGGL(dense_tile_weights_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, h->stream, raw, l.wraw, t.OC, d.K,
                                chunks, total4);
             VPK_HIP(h, hipStreamSynchronize(h->stream));
-            VPK_HIP(h, hipFree(raw));
             float wmax = 0.f;
             for (size_t i = 0; i < w_floats; ++i) wmax = std::max(wmax, std::fabs(blobs[2 * li][i]));
             int ex = 0;
             if (wmax > 0.f) (void)std::frexp(wmax, &ex);
             l.hscale = std::ldexp(1.f, wmax > 0.f ? 14 - ex : 0);
+            // ... and as scaled fp16 pairs in the A-fragment order of dense_pairs_kernel (4 bytes per weight, like the f32 copy)
+            const long long total16 = (long long)mtiles * chunks * 8 * 2 * 2 * 64;
+            VPK_HIP(h, hipMalloc((void**)&l.wpair, (size_t)total16 * 16));
+            hipLaunchKernelGGL(dense_pair_weights_kernel, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, h->stream, raw, l.wpair, t.OC,
+                               d.K, chunks, l.hscale, total16);
+            VPK_HIP(h, hipStreamSynchronize(h->stream));
+            VPK_HIP(h, hipFree(raw));
         }
         else VPK_HIP(h, hipFree(raw));
         if (li < 5) {   // convolution: byte offset of tap k from the patch origin, in the bordered planes;
@@ -1762,6 +1775,7 @@ int vpk_cnn_load(vpk_handle* h, const float* const blobs[16], const float* mean)
             VPK_HIP(h, hipMalloc((void**)&l.c1map, cm.size() * sizeof(float)));
             VPK_HIP(h, hipMemcpy(l.c1map, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
             if (const char* e = getenv("VPK_CONV1_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 64) S->conv1_group = v; }
+            if (const char* e = getenv("VPK_DENSE_PRESPLIT")) S->dense_presplit = atoi(e) != 0;
         }
         if (li == 1) {              // conv2: G g G^T of every 5 x 5 filter (F(2 x 2, 5 x 5))
             std::vector<float> u;
