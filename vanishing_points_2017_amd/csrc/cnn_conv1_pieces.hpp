@@ -149,15 +149,12 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
     // ---- epilogue roles ----
     const int lp = tid & 127, lcg = tid >> 7;                            // LRN: column, group of 16 channels
     const bool pool_on = tid < 96 * C1_QR * 2;                           // pooling: (channel, pooled row, half of its 8 outputs)
-    const int pk = pool_on ? tid / (C1_QR * 2) : 95, prem = tid % (C1_QR * 2), ppy = prem >> 1, phalf = prem & 1;
-    const float* pool_src = &Cs[pk + 2][2 * ppy * C1_PC + 8 * phalf];
     // pooling straight into conv2's piece planes (round 6; out_planes != nullptr): thread t < 24 x 24 owns one pooled PIXEL of the patch
     // and FOUR channels = half of a 16-byte word -- [image][channel group of 16][piece x k half][y][x], cnn_conv_pieces.hpp -- as scaled
     // fp16 pairs (split2h_guard: clamped, flagged): 8-byte stores that two threads complete to a word (as the conv epilogues do); the f32
     // pool1 blob and to_planes_kernel's pass over it are not needed then
+    // (the roles' indices are derived per tile: kept across the K loop they cost registers the loop does not have)
     const bool pl_on = tid < 24 * C1_QR * C1_QC;
-    const int pl_g = pl_on ? tid / (C1_QR * C1_QC) : 0, pl_pix = tid % (C1_QR * C1_QC), pl_y = pl_pix / C1_QC, pl_x = pl_pix % C1_QC;
-    const float* pl_src = &Cs[4 * pl_g + 2][2 * pl_y * C1_PC + 2 * pl_x];
     bool pl_bad = false;
 
     int item = blockIdx.x, parity = 0, buf = 0;
@@ -277,6 +274,10 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         // ---- 3 x 3 / stride 2 max pool: (channel, pooled row, half) = 4 outputs from 3 x 9 values ----
         if (out_planes) {
             if (pl_on) {
+                int tl = tid;
+                asm volatile("" : "+v"(tl));                         // (not hoisted out of the tile loop)
+                const int pl_g = tl / (C1_QR * C1_QC), pl_pix = tl % (C1_QR * C1_QC), pl_y = pl_pix / C1_QC, pl_x = pl_pix % C1_QC;
+                const float* pl_src = &Cs[4 * pl_g + 2][2 * pl_y * C1_PC + 2 * pl_x];
                 const int ph = C1_QR * pr + pl_y, pw = C1_QC * pc + pl_x;
                 unsigned short h0[4], h1[4];
 #pragma unroll
@@ -301,6 +302,10 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
             }
         } else
         if (pool_on) {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));                                 // (derived per tile, like the plane-writing roles)
+            const int pk = tl / (C1_QR * 2), prem = tl % (C1_QR * 2), ppy = prem >> 1, phalf = prem & 1;
+            const float* pool_src = &Cs[pk + 2][2 * ppy * C1_PC + 8 * phalf];
             float cm[9];
 #pragma unroll
             for (int x = 0; x < 9; ++x)

@@ -164,8 +164,12 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
     // kernel row (5) / three for the nine taps -- the set is a function of the step's place in the block, every block is the same
     // code, and a request has 5 (3) steps to come back from L2 (with two sets the pairs' steps, half as long as the triples',
     // waited for their weights 29 % of the time: SQ_WAIT_ANY).  bf16 triples (12 registers a set): two sets alternating per step,
-    // two blocks make a period when FP is odd.
-    constexpr int NSETS = NP == 3 ? 2 : (KH == 5 ? 5 : 3);
+    // two blocks make a period when FP is odd.  Round 6 measured SIX sets for the 3 x 3 layers (a request then has six steps, and a patch
+    // DMA instruction issued behind a block's first step seven, before the in-order vmcnt makes a weight wait a wait for it -- DESIGN.md
+    // section 8's lead): conv3 0.413 -> 0.413 ms, conv5 0.217 -> 0.220, conv4 (RH = 2: ten patch rows, two DMA instructions per column
+    // group) 0.348 -> 0.335, same box.  Kept where it pays: six sets for RH = 2 (two blocks then make a period: 9 steps, sets 0..5, 0..2 |
+    // 3..5, 0..5), three elsewhere.  So the unhidden latency of these kernels is not the DMA's place in the vmcnt queue.
+    constexpr int NSETS = NP == 3 ? 2 : (KH == 5 ? 5 : (RH == 2 ? 6 : 3));
     constexpr int D = NSETS;                                 // steps between a weight request and its use
     constexpr int KHB = KH == 5 ? 5 : 1;                     // blocks per channel group
     constexpr int FP = KH == 5 ? 5 : 9;                      // K16 steps per block = per block sum (a kernel row of conv2, all taps of a 3 x 3 layer)
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
         load_a(wgrp + wstep, std::integral_constant<int, 1>());
         if constexpr (NSETS > 2) load_a(wgrp + 2 * wstep, std::integral_constant<int, 2>());
         if constexpr (NSETS > 3) { load_a(wgrp + 3 * wstep, std::integral_constant<int, 3>()); load_a(wgrp + 4 * wstep, std::integral_constant<int, 4>()); }
+        if constexpr (NSETS > 5) load_a(wgrp + 5 * wstep, std::integral_constant<int, 5>());
         const unsigned char* anext = wgrp + (size_t)D * wstep;   // the next weights to request (step s + D behind step s; none behind the last D)
         cp_wait<0>();
         if (tid == 0) s_next[parity] = nx + (int)gridDim.x;
@@ -366,8 +371,8 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
             const unsigned sb = (unsigned)((cg & 1) * PBUF + kb * 128);
             const bool tail = !more && cg + 1 == d.Cg16;
             static_assert(FP == 5 || FP == 9, "the steps of a block are written out for 5 and 9");
-            static_assert(NP == 3 || FP % NSETS == 0, "a block must be a whole number of set rotations");
-#define CP_STEP(n) step(std::integral_constant<int, (NP == 3 ? (a + n) & 1 : n % NSETS)>(), std::integral_constant<int, n>(), gs, dma_block, dma_prev, more, tail, sb);
+            static_assert(NP == 3 || (2 * FP) % NSETS == 0, "two blocks must be a whole number of set rotations");
+#define CP_STEP(n) step(std::integral_constant<int, (NP == 3 ? (a + n) & 1 : (a + n) % NSETS)>(), std::integral_constant<int, n>(), gs, dma_block, dma_prev, more, tail, sb);
             CP_STEP(0) CP_STEP(1) CP_STEP(2) CP_STEP(3) CP_STEP(4)
             if constexpr (FP == 9) { CP_STEP(5) CP_STEP(6) CP_STEP(7) CP_STEP(8) }
 #undef CP_STEP
@@ -382,8 +387,15 @@ __global__ __launch_bounds__(CP_THREADS, 2) void conv_pieces_kernel(PieceDims d,
                 block(std::integral_constant<int, FP & 1>());
             }
             if (bi < nblocks) block(std::integral_constant<int, 0>());
-        } else {
+        } else if constexpr (FP % NSETS == 0) {
             for (int bi = 0; bi < nblocks; ++bi) block(std::integral_constant<int, 0>());
+        } else {                                             // (six sets, nine steps: two blocks make a period)
+            int bi = 0;
+            for (; bi + 2 <= nblocks; bi += 2) {
+                block(std::integral_constant<int, 0>());
+                block(std::integral_constant<int, FP % NSETS>());
+            }
+            if (bi < nblocks) block(std::integral_constant<int, 0>());
         }
         // ---- epilogue: bias + ReLU -> f32 NCHW planes; accumulator register 4 q + e = row 8 q + 4 (lane / 32) + e of the block.
         //      The tile's coordinates are derived AGAIN from the (laundered) tile index and lane offset: kept from the top of the
