@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int C1B_THREADS = 768;
+constexpr int C1T_LD = 108;                            // row stride (floats) of the [column][channel + 4] output patch
 constexpr int C1B_PROWS = 36, C1B_PCOLS = 80;          // raw patch in LDS (pixels): rows 4 * 6 + 12, columns 4 * 16 + 16
 constexpr int C1B_XS = C1B_PROWS * C1B_PCOLS;          // bf16 per patch buffer (5760 bytes)
 constexpr int C1B_STEPS = 6;                           // K steps of 32
@@ -102,13 +103,22 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
                                                                       unsigned short* __restrict__ out_planes, float p_ascale,
                                                                       unsigned* __restrict__ range_word) {
     __shared__ __attribute__((aligned(16))) unsigned short Xs[2][C1B_XS];
-    __shared__ __attribute__((aligned(16))) float Cs[96 + 4][C1D_LD];     // channel c in row c + 2; rows 0, 1, 98, 99 stay 0 (LRN halo)
+    // The output patch as [column][channel] (round 6; it was [channel][column]): a lane's four accumulator values are four consecutive
+    // channels of one column, the LRN's window runs along the channels and a pooling thread takes four channels of a pixel -- every
+    // phase of the epilogue moves 16 bytes per LDS instruction where it moved 4 (wave-level LDS instructions per tile: ~870 -> ~250;
+    // counters of the old layout: LDS 0.72 busy, 42 % bank conflicts, matrix pipes 0.30 -- profiles/r05_pmc_conv1_issue.txt).  Channel c
+    // sits at index c + 4 (16-byte aligned groups of four), indices 2, 3 and 100, 101 are the LRN's zero halo; the row stride of 108
+    // floats = 27 x 16 bytes keeps the 16 lanes of a quarter wave (consecutive columns) on different banks.
+    __shared__ __attribute__((aligned(16))) float Ct[128][C1T_LD];
     __shared__ int s_next[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mtile = wave % 6, chalf = wave / 6;
     const int q = lane >> 4, c16 = lane & 15;
-    if (tid < C1D_LD) Cs[0][tid] = Cs[1][tid] = Cs[98][tid] = Cs[99][tid] = 0.f;
+    if (tid < 128) {
+        *reinterpret_cast<f32x4*>(&Ct[tid][0]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&Ct[tid][100]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // ---- this wave's weight fragments: 18 x 16 bytes per lane, for the lifetime of the workgroup ----
     bf16x8 A[C1B_STEPS][NP];
 #pragma unroll
@@ -147,7 +157,6 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         }
     };
     // ---- epilogue roles ----
-    const int lp = tid & 127, lcg = tid >> 7;                            // LRN: column, group of 16 channels
     const bool pool_on = tid < 96 * C1_QR * 2;                           // pooling: (channel, pooled row, half of its 8 outputs)
     // pooling straight into conv2's piece planes (round 6; out_planes != nullptr): thread t < 24 x 24 owns one pooled PIXEL of the patch
     // and FOUR channels = half of a 16-byte word -- [image][channel group of 16][piece x k half][y][x], cnn_conv_pieces.hpp -- as scaled
@@ -236,21 +245,33 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
             if (n_fresh) poff = patch_offset(n_pr, n_pc);
             pre = *reinterpret_cast<const unsigned*>(sphere + (size_t)n_b * 250000 + poff);
         }
-        // ---- + constant, ReLU -> Cs[channel + 2][column]; positions outside the conv blob become 0 ----
+        // ---- + constant, ReLU -> Ct[column][channel + 4]; positions outside the conv blob become 0 ----
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = 64 * chalf + 16 * j + c16;
+            f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r)                                  // accumulator register r holds row 4 (lane / 16) + r
-                Cs[16 * mtile + 4 * q + r + 2][col] = __builtin_amdgcn_fmed3f(NP == 3 ? acc[j][r] + cin[j][r] : __builtin_fmaf(acc[j][r], oscale, cin[j][r]),
-                                                                              0.f, cap[j]);
+                v[r] = __builtin_amdgcn_fmed3f(NP == 3 ? acc[j][r] + cin[j][r] : __builtin_fmaf(acc[j][r], oscale, cin[j][r]), 0.f, cap[j]);
+            *reinterpret_cast<f32x4*>(&Ct[col][16 * mtile + 4 * q + 4]) = v;
         }
         lds_barrier();
         // ---- LRN across channels (deploy.prototxt:34-44): out = v (1 + alpha / 5 sum of the 5 squares)^-0.75; this thread:
         //      column lp, channels 16 lcg .. 16 lcg + 15 (raw[k] = channel 16 lcg + k - 2; rows 0, 1, 98, 99 are the zero halo)
+        int tl_ = tid;
+        asm volatile("" : "+v"(tl_));                                    // (roles derived per tile: see the pooling roles)
+        const int lp = tl_ & 127, lcg = tl_ >> 7;                        // LRN: column, group of 16 channels
         float raw[20];
+        {
+            const float* rp = &Ct[lp][16 * lcg + 2];                     // channels 16 lcg - 2 ..: 8 bytes, 4 x 16 bytes, 8 bytes
+            const f32x2v a = *reinterpret_cast<const f32x2v*>(rp), z = *reinterpret_cast<const f32x2v*>(rp + 18);
+            raw[0] = a[0]; raw[1] = a[1]; raw[18] = z[0]; raw[19] = z[1];
 #pragma unroll
-        for (int k = 0; k < 20; ++k) raw[k] = Cs[16 * lcg + k][lp];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(rp + 2 + 4 * g4);
+                raw[2 + 4 * g4] = m[0]; raw[3 + 4 * g4] = m[1]; raw[4 + 4 * g4] = m[2]; raw[5 + 4 * g4] = m[3];
+            }
+        }
         lds_barrier();                                                   // every raw value has been read
         {
 #pragma clang fp contract(off)      // (the association and roundings of conv1_direct_kernel's lrn_two)
@@ -258,14 +279,20 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
 #pragma unroll
             for (int k = 0; k < 20; ++k) sq[k] = raw[k] * raw[k];
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {                            // channels 16 lcg + i, + i + 1: windows raw[i .. i + 4], raw[i + 1 .. i + 5]
-                const float psa = sq[i] + sq[i + 1], psb = sq[i + 2] + sq[i + 3];
-                const float c = psb + sq[i + 4];
-                const float w0 = c + psa, w1 = (c + sq[i + 1]) + sq[i + 5];
-                const float s0 = __builtin_fmaf(w0, 1e-4f / 5.f, 1.f), s1 = __builtin_fmaf(w1, 1e-4f / 5.f, 1.f);
-                const float r0 = __builtin_amdgcn_rsqf(s0), r1 = __builtin_amdgcn_rsqf(s1);
-                Cs[16 * lcg + i + 2][lp] = raw[i + 2] * (r0 * __builtin_amdgcn_sqrtf(r0));
-                Cs[16 * lcg + i + 3][lp] = raw[i + 3] * (r1 * __builtin_amdgcn_sqrtf(r1));
+            for (int g4 = 0; g4 < 4; ++g4) {                             // four channels = one 16-byte store
+                f32x4 res;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {                         // channels 16 lcg + i, + i + 1: windows raw[i .. i + 4], raw[i + 1 .. i + 5]
+                    const int i = 4 * g4 + 2 * h2;
+                    const float psa = sq[i] + sq[i + 1], psb = sq[i + 2] + sq[i + 3];
+                    const float c = psb + sq[i + 4];
+                    const float w0 = c + psa, w1 = (c + sq[i + 1]) + sq[i + 5];
+                    const float s0 = __builtin_fmaf(w0, 1e-4f / 5.f, 1.f), s1 = __builtin_fmaf(w1, 1e-4f / 5.f, 1.f);
+                    const float r0 = __builtin_amdgcn_rsqf(s0), r1 = __builtin_amdgcn_rsqf(s1);
+                    res[2 * h2] = raw[i + 2] * (r0 * __builtin_amdgcn_sqrtf(r0));
+                    res[2 * h2 + 1] = raw[i + 3] * (r1 * __builtin_amdgcn_sqrtf(r1));
+                }
+                *reinterpret_cast<f32x4*>(&Ct[lp][16 * lcg + 4 + 4 * g4]) = res;
             }
         }
         if (n_on) patch_store(pre, buf ^ 1);                             // (that buffer was last read in the previous tile's K loop)
@@ -277,18 +304,20 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
                 int tl = tid;
                 asm volatile("" : "+v"(tl));                         // (not hoisted out of the tile loop)
                 const int pl_g = tl / (C1_QR * C1_QC), pl_pix = tl % (C1_QR * C1_QC), pl_y = pl_pix / C1_QC, pl_x = pl_pix % C1_QC;
-                const float* pl_src = &Cs[4 * pl_g + 2][2 * pl_y * C1_PC + 2 * pl_x];
+                const float* pl_src = &Ct[2 * pl_y * C1_PC + 2 * pl_x][4 * pl_g + 4];
                 const int ph = C1_QR * pr + pl_y, pw = C1_QC * pc + pl_x;
                 unsigned short h0[4], h1[4];
+                f32x4 m4 = {0.f, 0.f, 0.f, 0.f};                     // (every value is >= 0: ReLU, then a positive factor)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float* w0 = pl_src + k * C1D_LD;
-                    float m = 0.f;                                   // (every value is >= 0: ReLU, then a positive factor)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-                        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(w0[dy * C1_PC], w0[dy * C1_PC + 1]), w0[dy * C1_PC + 2]));
-                    split2h_guard(m * p_ascale, h0[k], h1[k], pl_bad);
-                }
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(pl_src + (dy * C1_PC + dx) * C1T_LD);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) m4[k] = __builtin_fmaxf(m4[k], t4[k]);
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) split2h_guard(m4[k] * p_ascale, h0[k], h1[k], pl_bad);
                 if (ph < C1_POOL && pw < C1_POOL) {
                     const u32x2 a = {(unsigned)h0[0] | ((unsigned)h0[1] << 16), (unsigned)h0[2] | ((unsigned)h0[3] << 16)};
                     const u32x2 c = {(unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16)};
@@ -305,11 +334,11 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
             int tl = tid;
             asm volatile("" : "+v"(tl));                                 // (derived per tile, like the plane-writing roles)
             const int pk = tl / (C1_QR * 2), prem = tl % (C1_QR * 2), ppy = prem >> 1, phalf = prem & 1;
-            const float* pool_src = &Cs[pk + 2][2 * ppy * C1_PC + 8 * phalf];
+            const float* pool_src = &Ct[2 * ppy * C1_PC + 8 * phalf][pk + 4];
             float cm[9];
 #pragma unroll
             for (int x = 0; x < 9; ++x)
-                cm[x] = __builtin_fmaxf(__builtin_fmaxf(pool_src[x], pool_src[C1_PC + x]), pool_src[2 * C1_PC + x]);
+                cm[x] = __builtin_fmaxf(__builtin_fmaxf(pool_src[x * C1T_LD], pool_src[(C1_PC + x) * C1T_LD]), pool_src[(2 * C1_PC + x) * C1T_LD]);
             const int ph = C1_QR * pr + ppy, pw0 = C1_QC * pc + 4 * phalf;
             if (ph < C1_POOL) {
                 float* o = out + ((size_t)b * 96 + pk) * OHp * OWp + (size_t)(ph + opad) * OWp + pw0 + opad;
