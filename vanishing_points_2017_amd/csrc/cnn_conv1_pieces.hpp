@@ -355,5 +355,14 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
     if (out_planes) range_report(pl_bad, range_word, 1u << 1);         // (conv2 is the consuming layer)
 }
 
+
+// (Round 6, built, measured, removed: the same kernel in workgroups of SIX waves -- a wave per 16-channel tile, both column halves one after
+//  the other, two items per thread in the epilogue -- so that TWO workgroups share a CU and one's K loop runs under the other's epilogue.
+//  Same bits, and 0.455 ms against 0.365: the second workgroup never becomes resident.  The waves of a workgroup are placed on the SIMDs
+//  in turn starting from the first, so two 6-wave workgroups would put 2 + 2 waves on SIMDs 0 and 1, and 4 x 168 VGPRs exceed the
+//  512 of a SIMD (SQ_WAVE_CYCLES per kernel-ms: 0.55 of the 12-wave kernel's).  The serial phases can only be overlapped INSIDE one
+//  workgroup: six producer waves (K loops, 2 + 2 + 1 + 1 on the SIMDs) and six consumer waves (LRN, pooling, patch loads) on a
+//  double-buffered output patch -- DESIGN.md section 8.)
+
 }  // namespace
 #endif
