@@ -1198,13 +1198,6 @@ int run_forward(vpk_handle* h, const uint8_t* sphere, int batch, float* out, int
             // fp16 pairs downstream and pool1 not tapped: the pooling stage writes conv2's piece planes itself (no f32 pool1 blob)
             unsigned short* c2planes = conv1_hands_planes ? reinterpret_cast<unsigned short*>(R[R_P6_2]) : nullptr;
             if (S->fuse_conv1 == 4)
-                    hipLaunchKernelGGL(conv1_pieces6_kernel<2>, dim3(blocks), dim3(C1S_THREADS), 0, st, sphere, S->L[0].c1half, S->L[0].c1map, 65, 65, 2,
-                                       batch, 1.f / S->L[0].c1scale, ctr + 0, items, c2planes, S->L[1].ascale, S->range_word);
-                else
-                    hipLaunchKernelGGL(conv1_pieces6_kernel<3>, dim3(blocks), dim3(C1S_THREADS), 0, st, sphere, S->L[0].c1frag, S->L[0].c1map, 65, 65, 2,
-                                       batch, 1.f, ctr + 0, items, c2planes, S->L[1].ascale, S->range_word);
-            } else
-            if (S->fuse_conv1 == 4)
                 hipLaunchKernelGGL(conv1_pieces_kernel<2>, dim3((unsigned)std::min(total, h->num_cu)), dim3(C1B_THREADS), 0, st, sphere,
                                    S->L[0].c1half, S->L[0].c1map, R[R_POOL1], 65, 65, 2, batch, group, 1.f / S->L[0].c1scale, ctr + 0, total,
                                    c2planes, S->L[1].ascale, S->range_word);
