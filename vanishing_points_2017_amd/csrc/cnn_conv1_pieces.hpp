@@ -29,7 +29,8 @@ namespace {
 constexpr int C1B_THREADS = 768;
 constexpr int C1T_LD = 108;                            // row stride (floats) of the [column][channel + 4] output patch
 constexpr int C1B_PROWS = 36, C1B_PCOLS = 80;          // raw patch in LDS (pixels): rows 4 * 6 + 12, columns 4 * 16 + 16
-constexpr int C1B_XS = C1B_PROWS * C1B_PCOLS;          // bf16 per patch buffer (5760 bytes)
+constexpr int C1B_LDW = C1B_PCOLS;                     // row stride of the raw patch in LDS (bf16 elements; 88 / 96 / 104 / 192 measured: no faster)
+constexpr int C1B_XS = C1B_PROWS * C1B_LDW;            // bf16 per patch buffer
 constexpr int C1B_STEPS = 6;                           // K steps of 32
 constexpr int C1B_PATCHES = C1_TR * C1_TC;             // 168 patch positions per image
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         int c = 64 * chalf + 16 * j + c16;
         c = c < C1_PR * C1_PC ? c : C1_PR * C1_PC - 1;                  // columns 119..127 repeat the last position, unused
         const int crow = c / C1_PC, ccol = c - crow * C1_PC;
-        bp[j] = (lds_cu32x2*)&Xs[0][(4 * crow + (q >> 1)) * C1B_PCOLS + 4 * ccol + 8 * (q & 1)];
+        bp[j] = (lds_cu32x2*)&Xs[0][(4 * crow + (q >> 1)) * C1B_LDW + 4 * ccol + 8 * (q & 1)];
     }
     // ---- patch loader: thread t < 720 brings the four pixels (row t / 20, columns 4 (t % 20) ..) as one 4-byte word ----
     const bool p_on = tid < C1B_PROWS * (C1B_PCOLS / 4);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
                 w2[0] = h(v & 255u) | (h((v >> 8) & 255u) << 16);
                 w2[1] = h((v >> 16) & 255u) | (h(v >> 24) << 16);
             }
-            *reinterpret_cast<u32x2*>(&Xs[buf][p_row * C1B_PCOLS + 4 * p_q]) = w2;
+            *reinterpret_cast<u32x2*>(&Xs[buf][p_row * C1B_LDW + 4 * p_q]) = w2;
         }
     };
     // ---- epilogue roles ----
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
         auto operands = [&](int s) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                lds_cu32x2* src = bp[j] + buf * (C1B_XS / 4) + s * (2 * C1B_PCOLS / 4);
+                lds_cu32x2* src = bp[j] + buf * (C1B_XS / 4) + s * (2 * C1B_LDW / 4);
                 braw[s & 1][j][0] = src[0];
                 braw[s & 1][j][1] = src[1];
             }
