@@ -2094,6 +2094,9 @@ VPK_DEV void compact_vps(EmCtx& c) {
 // there); large images (N >= 512: ECD / HLW / the stress shape) walk N / 16 >= 32 lines per lane through arrays that come from HBM beside
 // 255 other workgroups' lsim streams -- there the walk is a chain of memory round trips (73 us per M-step at the stress shape, 42 alone)
 // and twice the loads in flight halve it.  Same lines in the same order per lane: same bits.
+// (Round 6 also measured a whole WAVE per hypothesis for large images with at most eight hypotheses -- another summation order, so other
+//  bits; every golden and all four config tables stayed green --: the stress shape's M-step 61 -> 39 us per call, and the launch 60.6 ->
+//  59.0 ms: the time moves into the smoother, whose stream then shares the HBM with more workgroups.  Not worth new bits.)
 template <int LB>
 VPK_DEVFN void mstep_lb(EmCtx& c, int mode, double max_stdd) {
     Shared& sh = SH();
