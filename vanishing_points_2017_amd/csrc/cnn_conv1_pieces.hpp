@@ -362,8 +362,12 @@ __global__ __launch_bounds__(C1B_THREADS, 3) void conv1_pieces_kernel(const unsi
 //  Same bits, and 0.455 ms against 0.365: the second workgroup never becomes resident.  The waves of a workgroup are placed on the SIMDs
 //  in turn starting from the first, so two 6-wave workgroups would put 2 + 2 waves on SIMDs 0 and 1, and 4 x 168 VGPRs exceed the
 //  512 of a SIMD (SQ_WAVE_CYCLES per kernel-ms: 0.55 of the 12-wave kernel's).  The serial phases can only be overlapped INSIDE one
-//  workgroup: six producer waves (K loops, 2 + 2 + 1 + 1 on the SIMDs) and six consumer waves (LRN, pooling, patch loads) on a
-//  double-buffered output patch -- DESIGN.md section 8.)
+//  workgroup -- and that was built and measured too: six PRODUCER waves (a wave per 16-channel tile, both column halves, the K loops of
+//  tile t) beside six CONSUMER waves (LRN, pooling, stores and the next raw patch for tile t - 1) on a double-buffered output patch,
+//  three barriers per tile, work items (patch position, image) two tiles ahead.  Same bits, no deadlock, and 0.55 ms: six waves spread
+//  2 + 2 + 1 + 1 over the SIMDs do not keep the matrix pipes fed the way twelve do (a wave's K loop is a chain of LDS operand reads and
+//  dependent matrix instructions; three waves per SIMD hide that, one or two do not), and the two roles in one kernel spill (51 dwords).
+//  So this kernel's 0.355 ms stand: its phases are serial, but each of them runs at the occupancy it needs.)
 
 }  // namespace
 #endif
