@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256) void lrn5_pool3s2_planes_kernel(const float* _
                                                                   unsigned short* __restrict__ out_planes, int C, int H, int W, int PH,
                                                                   int PW, float alpha, int PHp, int PWp, int opad, int cgroups, float ascale,
                                                                   unsigned* __restrict__ range_word, unsigned range_bit) {
-    constexpr int CB = 8, TR = 2 * TPH + 1, SLOTS = 4, PMAX = 256 * SLOTS;
+    // PMAX: floats per normalised plane in LDS.  832 (>= TR x (W + 1) = 13 x 62 at this shape; it was 1024 = the thread slots) makes the
+    // double-buffered batch 53 KB, so that THREE workgroups share a CU instead of two (round 6)
+    // (four per CU with tiles of four pooled rows, 37 KB: no faster, 0.126 against 0.124 ms)
+    constexpr int CB = 8, TR = 2 * TPH + 1, SLOTS = 4, PMAX = 832;
     __shared__ __attribute__((aligned(16))) float plane[2][CB][PMAX];
     const int tiles_h = (PH + TPH - 1) / TPH;
     const int th = blockIdx.x % tiles_h, cgi = (blockIdx.x / tiles_h) % cgroups, b = blockIdx.x / (tiles_h * cgroups);
