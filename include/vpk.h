@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VPK_VERSION 100
+#define VPK_VERSION 110   /* 110 (round 6): + vpk_cnn_calibrate, vpk_cnn_get/set_activation_scales, vpk_cnn_range_flags, VPK_ERR_RANGE */
 
 typedef struct vpk_handle vpk_handle;
 

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for sym in declared:
         assert hasattr(lib, sym), "libvpk.so does not export %s" % sym
     assert set(_lib.EXPORTS) == set(declared)
-    assert lib.vpk_version() == 100
+    assert lib.vpk_version() == 110
 
 
 def test_no_cpu_fallback():
