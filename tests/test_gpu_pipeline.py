@@ -309,6 +309,27 @@ def test_pipeline_step_equals_separate_calls():
         cnn_ms, em_ms = st.stage_ms()
         assert cnn_ms > 0 and em_ms > 0
     assert torch.equal(l0, d["l"])                      # the resident lines are inputs only
+    # the asynchronous steps' value-range check (include/vpk.h: vpk_cnn_range_flags): clean here, and an error -- not a silently
+    # different response map -- when a layer's activation scale is far too high for these rasters
+    ring[0].check_cnn_range()
+    from vanishing_points_2017_amd._lib import VpkRangeError
+    good = net.activation_scales()
+    bad = good.copy()
+    bad[2] = good[2] * np.float32(2.0 ** 16)
+    try:
+        net.set_activation_scales(bad)
+        ring[0].enqueue()
+        with pytest.raises(VpkRangeError) as ei:
+            ring[0].check_cnn_range()
+        assert ei.value.flags == 1 << 3                 # conv4's input
+        rt_em.synchronize()
+        assert bool(torch.isfinite(ring[0].resp).all().item())
+    finally:
+        net.set_activation_scales(good)
+    ring[0].enqueue()
+    ring[0].check_cnn_range()
+    rt_em.synchronize()
+    assert torch.equal(ring[0].resp, resp)
     host = {k: v.cpu().numpy() for k, v in ref.items() if v is not None}
     res = [{"status": int(host["status"][b]), "vp": host["vp"][b, :host["num_vp"][b]], "counts": host["counts"][b, :host["num_vp"][b]]}
            for b in range(len(scenes))]

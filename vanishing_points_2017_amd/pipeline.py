@@ -82,6 +82,17 @@ class Step(object):
         self.rt_em.check(self.rt_em.lib.vpk_pipeline_step(self.rt_cnn.h, self.rt_em.h, ctypes.byref(self._args)))
         return self.out
 
+    def check_cnn_range(self):
+        """The steps enqueued so far ran the CNN asynchronously: nothing has looked at its value range yet (include/vpk.h:
+        vpk_cnn_range_flags).  Waits for the CNN stream and raises VpkRangeError if a scaled fp16-pair activation of ANY forward on
+        that handle since the last check was clamped -- the response maps (and the EM results refined on them) of those steps are then
+        not the net's.  A pipeline calls this once per run, before it trusts the run's results."""
+        w = ctypes.c_uint32(0)
+        rc = self.rt_cnn.lib.vpk_cnn_range_flags(self.rt_cnn.h, ctypes.byref(w))
+        if rc == -6:
+            raise _lib.VpkRangeError("libvpk error -6: %s" % self.rt_cnn.lib.vpk_last_error(self.rt_cnn.h).decode(), int(w.value))
+        self.rt_cnn.check(rc)
+
     def stage_ms(self):
         """(CNN ms, EM ms) of the last enqueue(), once both streams have passed it."""
         e = self.events
